@@ -1,0 +1,560 @@
+/*
+ * mcq_oracle.c -- TEST INFRASTRUCTURE ONLY.  CPU restatement of the reference's Monte-Carlo equity path.
+ *
+ * This file is the parity oracle for the HIP path in neuron_poker_amd/csrc.  It is NOT part of the
+ * product: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it, and only
+ * as the checker / the reported CPU baseline.  Nothing under neuron_poker_amd/ links, imports or calls it.
+ *
+ * Parity status: PINNED.  tests/test_oracle_golden.py checks every function below against fixtures that
+ * were produced by running the reference itself (tests/golden/gen_golden.py imports
+ * /root/reference/tools/{montecarlo_python,hand_evaluator}.py under np.random.seed): evaluator scores,
+ * showdown winners, per-iteration dealt cards, MT19937 word counts and final tallies.
+ *
+ * It is deliberately a LITERAL restatement (lists with pops, sort-by-count tuples, tuple comparison);
+ * the product computes the same results with bit masks and packed keys, so agreement is meaningful.
+ *
+ * Reference lines followed (paths relative to /root/reference):
+ *   tools/hand_evaluator.py:27-119    _calc_score           -> calc_score()
+ *   tools/hand_evaluator.py:20-24     eval_best_hand        -> best_hand()
+ *   tools/montecarlo_python.py:114-119 create_card_deck     -> deck_init()
+ *   tools/montecarlo_python.py:121-183 distribute_cards_to_players -> deal_players()
+ *   tools/montecarlo_python.py:185-189 distribute_cards_to_table   -> deal_table()
+ *   tools/montecarlo_python.py:191-252 run_montecarlo       -> run_one()
+ *   numpy 1.26.4 (uv.lock:325-326; third party, not under /root/reference):
+ *     numpy/random/src/mt19937/mt19937.c  init_genrand / genrand  -> mt_seed()/mt_next()
+ *     numpy/random/src/distributions/distributions.c  buffered_bounded_masked_uint32 (legacy
+ *     RandomState.randint, use_masked=True, one 32-bit word per trial)             -> np_randint()
+ *
+ * Card id c = 4*rank + suit, rank = "23456789TJQKA".index, suit = "CDHS".index (hand_evaluator.py:5-6).
+ */
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------ MT19937 */
+typedef struct {
+    uint32_t mt[624];
+    int idx;
+    uint64_t words; /* tempered words handed out so far */
+} mt_t;
+
+static void mt_seed(mt_t *s, uint32_t seed) {
+    s->mt[0] = seed;
+    for (int i = 1; i < 624; i++) s->mt[i] = 1812433253u * (s->mt[i - 1] ^ (s->mt[i - 1] >> 30)) + (uint32_t)i;
+    s->idx = 624;
+    s->words = 0;
+}
+
+static void mt_refill(mt_t *s) {
+    uint32_t *mt = s->mt;
+    for (int k = 0; k < 624; k++) {
+        uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+        mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    s->idx = 0;
+}
+
+static uint32_t mt_next(mt_t *s) {
+    if (s->idx >= 624) mt_refill(s);
+    uint32_t y = s->mt[s->idx++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    s->words++;
+    return y;
+}
+
+/* np.random.randint(0, n) of the legacy RandomState: value in [0, n-1] */
+static uint32_t np_randint(mt_t *s, uint32_t n) {
+    uint32_t rng = n - 1;
+    if (rng == 0) return 0; /* no word consumed */
+    uint32_t mask = rng;
+    mask |= mask >> 1;
+    mask |= mask >> 2;
+    mask |= mask >> 4;
+    mask |= mask >> 8;
+    mask |= mask >> 16;
+    uint32_t v;
+    do {
+        v = mt_next(s) & mask;
+    } while (v > rng);
+    return v;
+}
+
+/* ------------------------------------------------------- counter-based front end (product's CTR mode) */
+/* Spec (DESIGN.md "MCQ-CTR v1"): iterations are grouped in streams of 16; stream s of query id q under
+ * seed k starts xoshiro128++ from Philox4x32-10(counter = {q_lo, q_hi, s, 'MCQ1'}, key = {k_lo, k_hi});
+ * a bounded draw is mulhi32(next(), n). */
+#define STREAM_ITERS 16u
+
+static void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+typedef struct { uint32_t s[4]; } xo_t;
+
+static inline uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+
+static uint32_t xo_next(xo_t *x) {
+    uint32_t *s = x->s;
+    uint32_t result = rotl32(s[0] + s[3], 7) + s[0];
+    uint32_t t = s[1] << 9;
+    s[2] ^= s[0];
+    s[3] ^= s[1];
+    s[1] ^= s[2];
+    s[0] ^= s[3];
+    s[2] ^= t;
+    s[3] = rotl32(s[3], 11);
+    return result;
+}
+
+static void xo_seed(xo_t *x, uint64_t seed, uint64_t qid, uint32_t stream) {
+    uint32_t ctr[4] = {(uint32_t)qid, (uint32_t)(qid >> 32), stream, 0x4D435131u};
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    philox4x32_10(ctr, key, x->s);
+    if ((x->s[0] | x->s[1] | x->s[2] | x->s[3]) == 0) x->s[0] = 1;
+}
+
+static uint32_t xo_draw(xo_t *x, uint32_t n) { return (uint32_t)(((uint64_t)xo_next(x) * n) >> 32); }
+
+/* one RNG handle for the dealing code */
+typedef struct {
+    int kind; /* 0 = MT19937 + numpy randint, 1 = xoshiro + mulhi */
+    mt_t *mt;
+    xo_t *xo;
+} rng_t;
+
+static uint32_t draw(rng_t *r, uint32_t n) { return r->kind == 0 ? np_randint(r->mt, n) : xo_draw(r->xo, n); }
+
+/* ------------------------------------------------------------------------------------------ evaluator */
+enum { T_HIGH, T_PAIR, T_TWOPAIR, T_TRIPS, T_STRAIGHT, T_FLUSH, T_FULL, T_QUADS, T_SF };
+
+typedef struct {
+    int nscore, score[8];
+    int nranks, ranks[9];
+    int type;
+} score_t;
+
+/* sort (cnt, rank) pairs descending -- sorted(...)[::-1], hand_evaluator.py:30 */
+static void sort_pairs_desc(int *cnt, int *rank, int n) {
+    for (int i = 1; i < n; i++) {
+        int c = cnt[i], r = rank[i], j = i - 1;
+        while (j >= 0 && (cnt[j] < c || (cnt[j] == c && rank[j] < r))) {
+            cnt[j + 1] = cnt[j];
+            rank[j + 1] = rank[j];
+            j--;
+        }
+        cnt[j + 1] = c;
+        rank[j + 1] = r;
+    }
+}
+
+static void sort_desc(int *a, int n) {
+    for (int i = 1; i < n; i++) {
+        int v = a[i], j = i - 1;
+        while (j >= 0 && a[j] < v) { a[j + 1] = a[j]; j--; }
+        a[j + 1] = v;
+    }
+}
+
+static int tuple_eq(const int *a, int na, const int *b, int nb) {
+    if (na != nb) return 0;
+    for (int i = 0; i < na; i++) if (a[i] != b[i]) return 0;
+    return 1;
+}
+
+static int tuple_cmp(const int *a, int na, const int *b, int nb) { /* python tuple ordering */
+    int n = na < nb ? na : nb;
+    for (int i = 0; i < n; i++) if (a[i] != b[i]) return a[i] < b[i] ? -1 : 1;
+    return na == nb ? 0 : (na < nb ? -1 : 1);
+}
+
+static int has(const int *a, int n, int v) {
+    for (int i = 0; i < n; i++) if (a[i] == v) return 1;
+    return 0;
+}
+
+/* rank histogram of `cards` -> distinct (cnt, rank) sorted descending */
+static int rcounts(const uint8_t *cards, int n, int *cnt, int *rank) {
+    int hist[13] = {0}, m = 0;
+    for (int i = 0; i < n; i++) hist[cards[i] >> 2]++;
+    for (int r = 0; r < 13; r++) if (hist[r]) { cnt[m] = hist[r]; rank[m] = r; m++; }
+    sort_pairs_desc(cnt, rank, m);
+    return m;
+}
+
+static void calc_score(const uint8_t *hand, int ncards, score_t *out) {
+    int score[16], cr[16];
+    int n = rcounts(hand, ncards, score, cr); /* l.29-30 */
+    int nscore = n, ncr = n;
+
+    static const int S22111[] = {2, 2, 1, 1, 1}, S211111[] = {2, 1, 1, 1, 1, 1};
+    int pot_trips = score[0] == 3;                     /* l.32 */
+    int pot_twopair = tuple_eq(score, nscore, S22111, 5);  /* l.33 */
+    int pot_pair = tuple_eq(score, nscore, S211111, 6);    /* l.34 */
+
+    if (nscore >= 2 && score[0] == 3 && (score[1] == 2 || score[1] == 3)) { /* l.36-38 */
+        ncr = 2;
+        score[0] = 3; score[1] = 2; nscore = 2;
+    } else if (nscore >= 4 && score[0] == 2 && score[1] == 2 && score[2] == 2 && score[3] == 1) { /* l.39-42 */
+        int kicker = cr[2] > cr[3] ? cr[2] : cr[3];
+        cr[2] = kicker; ncr = 3;
+        score[0] = 2; score[1] = 2; score[2] = 1; nscore = 3;
+    } else if (score[0] == 4) { /* l.43-46 */
+        sort_desc(cr, ncr);
+        ncr = 2;
+        score[0] = 4; nscore = 1;
+    } else if (nscore >= 5) { /* l.47-83 */
+        int straight = 0, flush;
+        if (has(cr, ncr, 12)) cr[ncr++] = -1; /* l.49-50 */
+        int sorted[16], ns = ncr;
+        memcpy(sorted, cr, sizeof(int) * ncr);
+        sort_desc(sorted, ns); /* l.51 */
+        for (int i = 0; i < ns - 4; i++) { /* l.52-58 */
+            straight = sorted[i] - sorted[i + 4] == 4;
+            if (straight) {
+                for (int k = 0; k < 5; k++) cr[k] = sorted[i + k];
+                ncr = 5;
+                break;
+            }
+        }
+        int sc[4] = {0};
+        for (int i = 0; i < ncards; i++) sc[hand[i] & 3]++; /* l.61-62 */
+        flush = 0;
+        for (int s = 0; s < 4; s++) if (sc[s] >= 5) flush = 1;
+        if (flush) {
+            int fs = 0;
+            for (fs = 0; fs < 4; fs++) if (sc[fs] >= 5) break; /* l.64-66: first suit in "CDHS" order */
+            uint8_t fh[8];
+            int nf = 0;
+            for (int i = 0; i < ncards; i++) if ((hand[i] & 3) == fs) fh[nf++] = hand[i]; /* l.68 */
+            int fcnt[16];
+            ncr = rcounts(fh, nf, fcnt, cr); /* l.69-70 */
+            memcpy(score, fcnt, sizeof(int) * ncr);
+            nscore = ncr;
+            sort_desc(cr, ncr); /* l.71-72 */
+            if (has(cr, ncr, 12) && !has(cr, ncr, -1)) cr[ncr++] = -1; /* l.75-76 */
+            for (int i = 0; i < ncr - 4; i++) { /* l.77-80 */
+                straight = cr[i] - cr[i + 4] == 4;
+                if (straight) break;
+            }
+        }
+        /* l.83 */
+        if (!flush && !straight) { score[0] = 1; nscore = 1; }
+        else if (!flush && straight) { score[0] = 3; score[1] = 1; score[2] = 2; nscore = 3; }
+        else if (flush && !straight) { score[0] = 3; score[1] = 1; score[2] = 3; nscore = 3; }
+        else { score[0] = 5; nscore = 1; }
+    }
+
+    if (nscore == 1 && score[0] == 1 && pot_trips) { score[0] = 3; score[1] = 1; nscore = 2; }        /* l.85-86 */
+    else if (nscore == 1 && score[0] == 1 && pot_twopair) { score[0] = 2; score[1] = 2; score[2] = 1; nscore = 3; }
+    else if (nscore == 1 && score[0] == 1 && pot_pair) { score[0] = 2; score[1] = 1; score[2] = 1; nscore = 3; }
+
+    int type;
+    if (score[0] == 5) type = T_SF; /* l.92-117 */
+    else if (score[0] == 4) type = T_QUADS;
+    else if (nscore >= 2 && score[0] == 3 && score[1] == 2) type = T_FULL;
+    else if (nscore >= 3 && score[0] == 3 && score[1] == 1 && score[2] == 3) { type = T_FLUSH; if (ncr > 5) ncr = 5; }
+    else if (nscore >= 3 && score[0] == 3 && score[1] == 1 && score[2] == 2) { type = T_STRAIGHT; if (ncr > 5) ncr = 5; }
+    else if (nscore >= 2 && score[0] == 3 && score[1] == 1) { type = T_TRIPS; if (ncr > 3) ncr = 3; }
+    else if (nscore >= 2 && score[0] == 2 && score[1] == 2) { type = T_TWOPAIR; if (ncr > 3) ncr = 3; }
+    else if (score[0] == 2) { type = T_PAIR; if (ncr > 4) ncr = 4; }
+    else if (score[0] == 1) { type = T_HIGH; if (ncr > 5) ncr = 5; }
+    else type = -1; /* 'Card Type error!' */
+
+    out->nscore = nscore;
+    memcpy(out->score, score, sizeof(int) * (nscore > 8 ? 8 : nscore));
+    out->nranks = ncr > 9 ? 9 : ncr;
+    memcpy(out->ranks, cr, sizeof(int) * out->nranks);
+    out->type = type;
+}
+
+static int score_cmp(const score_t *a, const score_t *b) {
+    int c = tuple_cmp(a->score, a->nscore, b->score, b->nscore);
+    if (c) return c;
+    return tuple_cmp(a->ranks, a->nranks, b->ranks, b->nranks);
+}
+
+/* eval_best_hand: stable descending sort, first element -> lowest index among the maxima. *tie = 1 when
+ * another hand compares equal to the winner (extension: the reference does not report it). */
+static int best_hand(const uint8_t *hands, int n, int *type, int *tie) {
+    score_t best, s;
+    int w = 0, t = 0;
+    calc_score(hands, 7, &best);
+    for (int i = 1; i < n; i++) {
+        calc_score(hands + 7 * i, 7, &s);
+        int c = score_cmp(&s, &best);
+        if (c > 0) { best = s; w = i; t = 0; }
+        else if (c == 0) t = 1;
+    }
+    if (type) *type = best.type;
+    if (tie) *tie = t;
+    return w;
+}
+
+/* ------------------------------------------------------------------------------------------ dealing */
+typedef struct { uint8_t c[52]; int n; } deck_t;
+
+static void deck_init(deck_t *d) { /* '2C','2D','2H','2S','3C',... == ascending id */
+    for (int i = 0; i < 52; i++) d->c[i] = (uint8_t)i;
+    d->n = 52;
+}
+
+static uint8_t deck_pop(deck_t *d, int i) {
+    uint8_t v = d->c[i];
+    memmove(d->c + i, d->c + i + 1, (size_t)(d->n - i - 1));
+    d->n--;
+    return v;
+}
+
+static int deck_remove(deck_t *d, uint8_t card) {
+    for (int i = 0; i < d->n; i++) if (d->c[i] == card) { deck_pop(d, i); return 1; }
+    return 0;
+}
+
+/* one iteration: fills hands[n_players][7]; returns passes added */
+static uint32_t deal_iteration(rng_t *rng, const uint8_t hero[2], const uint8_t *board, int nb, int n_players,
+                               uint8_t *hands) {
+    deck_t d;
+    uint32_t passes = 0;
+    uint8_t table[5];
+    uint8_t hole[10][2];
+    deck_init(&d);
+    for (int i = 0; i < nb; i++) { deck_remove(&d, board[i]); table[i] = board[i]; } /* l.126-128 */
+    hole[0][0] = hero[0]; hole[0][1] = hero[1];
+    deck_remove(&d, hero[0]); /* l.154-161 */
+    deck_remove(&d, hero[1]);
+    for (int p = 1; p < n_players; p++) { /* l.165-181 */
+        uint32_t r1, r2;
+        for (;;) {
+            passes++;
+            r1 = draw(rng, (uint32_t)d.n);
+            r2 = draw(rng, (uint32_t)d.n - 1);
+            if (r1 != r2) break; /* l.172; the range test l.175 is always true at opponent_range = 1 */
+        }
+        hole[p][0] = deck_pop(&d, (int)r1);
+        hole[p][1] = deck_pop(&d, (int)r2);
+    }
+    for (int k = nb; k < 5; k++) table[k] = deck_pop(&d, (int)draw(rng, (uint32_t)d.n - 1)); /* l.186-188 */
+    for (int p = 0; p < n_players; p++) { /* l.218-220 */
+        hands[7 * p] = hole[p][0];
+        hands[7 * p + 1] = hole[p][1];
+        memcpy(hands + 7 * p + 2, table, 5);
+    }
+    return passes;
+}
+
+/* out[13] = runs, passes, win (strict), tie, by_type[9]; the reference's wins = win + tie = sum(by_type) */
+static void tally(uint64_t *out, const uint8_t *hands, int n_players) {
+    int type, tie;
+    int w = best_hand(hands, n_players, &type, &tie);
+    if (w == 0) {
+        if (tie) out[3]++; else out[2]++;
+        out[4 + type]++;
+    }
+}
+
+static int valid_query(const uint8_t hero[2], const uint8_t *board, int nb, int n_players) {
+    uint64_t seen = 0;
+    if (nb < 0 || nb > 5 || n_players < 1 || n_players > 10) return 0;
+    for (int i = 0; i < 2 + nb; i++) {
+        uint8_t c = i < 2 ? hero[i] : board[i - 2];
+        if (c >= 52 || (seen >> c) & 1) return 0;
+        seen |= 1ull << c;
+    }
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------------ exported */
+int mcqo_version(void) { return 1; }
+
+void mcqo_mt_words(uint32_t seed, uint32_t n, uint32_t *out) {
+    mt_t s;
+    mt_seed(&s, seed);
+    for (uint32_t i = 0; i < n; i++) out[i] = mt_next(&s);
+}
+
+/* draws np.random.randint(0, bounds[i]) for i < n after np.random.seed(seed); returns words consumed */
+uint64_t mcqo_np_randint(uint32_t seed, uint32_t n, const uint32_t *bounds, uint32_t *out) {
+    mt_t s;
+    mt_seed(&s, seed);
+    for (uint32_t i = 0; i < n; i++) out[i] = np_randint(&s, bounds[i]);
+    return s.words;
+}
+
+void mcqo_philox4x32_10(const uint32_t *ctr, const uint32_t *key, uint32_t *out) { philox4x32_10(ctr, key, out); }
+
+void mcqo_xoshiro_stream(uint64_t seed, uint64_t qid, uint32_t stream, uint32_t n, uint32_t *out) {
+    xo_t x;
+    xo_seed(&x, seed, qid, stream);
+    for (uint32_t i = 0; i < n; i++) out[i] = xo_next(&x);
+}
+
+/* out[0]=nscore, out[1..3]=score (padded 0), out[4]=nranks, out[5..13]=ranks (padded -128), out[14]=type */
+void mcqo_calc_score(const uint8_t *cards, int ncards, int32_t *out) {
+    score_t s;
+    calc_score(cards, ncards, &s);
+    out[0] = s.nscore;
+    for (int i = 0; i < 3; i++) out[1 + i] = i < s.nscore ? s.score[i] : 0;
+    out[4] = s.nranks;
+    for (int i = 0; i < 9; i++) out[5 + i] = i < s.nranks ? s.ranks[i] : -128;
+    out[14] = s.type;
+}
+
+/* -1/0/+1: python comparison of _calc_score(a) vs _calc_score(b) */
+int mcqo_compare(const uint8_t *a, const uint8_t *b) {
+    score_t x, y;
+    calc_score(a, 7, &x);
+    calc_score(b, 7, &y);
+    return score_cmp(&x, &y);
+}
+
+int mcqo_best_hand(const uint8_t *hands, int n, int *type, int *tie) { return best_hand(hands, n, type, tie); }
+
+/* mode 0: np.random.seed((uint32)seed) then the reference loop; mode 1: MCQ-CTR v1 with query id qid.
+ * trace (optional): first `keep` iterations' hands [keep][n_players][7]; words (optional, mode 0): MT words
+ * per kept iteration; total_words (optional). Returns 0, or -1 on invalid input. */
+int mcqo_run(int mode, const uint8_t *hero, const uint8_t *board, int nb, int n_players, uint32_t runs,
+             uint64_t seed, uint64_t qid, uint64_t *out, uint8_t *trace, uint32_t keep, uint16_t *words,
+             uint64_t *total_words) {
+    if (!valid_query(hero, board, nb, n_players)) return -1;
+    mt_t mt;
+    xo_t xo;
+    rng_t rng = {mode, &mt, &xo};
+    uint8_t hands[70];
+    memset(out, 0, 13 * sizeof(uint64_t));
+    mt.words = 0;
+    if (mode == 0) mt_seed(&mt, (uint32_t)seed);
+    for (uint32_t it = 0; it < runs; it++) {
+        if (mode == 1 && it % STREAM_ITERS == 0) xo_seed(&xo, seed, qid, it / STREAM_ITERS);
+        uint64_t w0 = mt.words;
+        out[1] += deal_iteration(&rng, hero, board, nb, n_players, hands);
+        out[0]++;
+        tally(out, hands, n_players);
+        if (it < keep) {
+            if (trace) memcpy(trace + (size_t)it * 7 * n_players, hands, (size_t)7 * n_players);
+            if (words) words[it] = (uint16_t)(mt.words - w0);
+        }
+    }
+    if (total_words) *total_words = mode == 0 ? mt.words : 0;
+    return 0;
+}
+
+/* batch: query i = {hole[2], board[5], n_board, n_players, runs(u32 LE)} (16 bytes, the C-ABI's mcq_query);
+ * MT mode seeds query i with (uint32)(seed + first_qid + i); CTR mode uses query id first_qid + i.
+ * out[n][13].  threads >= 1 (pthreads, queries interleaved).  Used as the timed CPU baseline. */
+typedef struct {
+    int mode, tid, nthreads;
+    const uint8_t *q;
+    size_t n;
+    uint64_t seed, first_qid;
+    uint64_t *out;
+    int err;
+} job_t;
+
+static void *batch_worker(void *p) {
+    job_t *j = (job_t *)p;
+    for (size_t i = (size_t)j->tid; i < j->n; i += (size_t)j->nthreads) {
+        const uint8_t *q = j->q + 16 * i;
+        uint32_t runs;
+        memcpy(&runs, q + 12, 4);
+        uint64_t qid = j->first_qid + i;
+        uint64_t seed = j->mode == 0 ? (uint32_t)(j->seed + qid) : j->seed;
+        if (mcqo_run(j->mode, q, q + 2, q[7], q[8], runs, seed, qid, j->out + 13 * i, 0, 0, 0, 0)) j->err = 1;
+    }
+    return 0;
+}
+
+int mcqo_run_batch(int mode, const uint8_t *queries, size_t n, uint64_t seed, uint64_t first_qid, uint64_t *out,
+                   int threads) {
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    pthread_t th[256];
+    job_t jobs[256];
+    int err = 0;
+    for (int t = 0; t < threads; t++) {
+        jobs[t] = (job_t){mode, t, threads, queries, n, seed, first_qid, out, 0};
+        if (t > 0) pthread_create(&th[t], 0, batch_worker, &jobs[t]);
+    }
+    batch_worker(&jobs[0]);
+    for (int t = 1; t < threads; t++) pthread_join(th[t], 0);
+    for (int t = 0; t < threads; t++) err |= jobs[t].err;
+    return err ? -1 : 0;
+}
+
+/* ------------------------------------------------------------------------- exact expectation (small cases)
+ * Exact probabilities of {hero wins strictly, hero wins a tie} under the REFERENCE'S dealing law (the
+ * accepted (r1, r2) pairs are equally likely; each table draw is uniform on [0, L-2]).  Enumerates the
+ * whole tree, so only for n_players <= 3 and enough known board cards.  out[0] = P(win strictly),
+ * out[1] = P(tie, hero credited), out[2] = number of leaves.  Returns -1 if the tree is too large. */
+typedef struct {
+    const uint8_t *hero, *board;
+    int nb, n_players;
+    double win, tie, leaves;
+} enum_t;
+
+static void enum_table(enum_t *e, deck_t *d, uint8_t hole[][2], uint8_t *table, int k, double w) {
+    if (k == 5) {
+        uint8_t hands[70];
+        int type, tie;
+        for (int p = 0; p < e->n_players; p++) {
+            hands[7 * p] = hole[p][0];
+            hands[7 * p + 1] = hole[p][1];
+            memcpy(hands + 7 * p + 2, table, 5);
+        }
+        if (best_hand(hands, e->n_players, &type, &tie) == 0) { if (tie) e->tie += w; else e->win += w; }
+        e->leaves += 1;
+        return;
+    }
+    int choices = d->n - 1;
+    for (int i = 0; i < choices; i++) {
+        deck_t d2 = *d;
+        table[k] = deck_pop(&d2, i);
+        enum_table(e, &d2, hole, table, k + 1, w / choices);
+    }
+}
+
+static void enum_players(enum_t *e, deck_t *d, uint8_t hole[][2], uint8_t *table, int p, double w) {
+    if (p == e->n_players) { enum_table(e, d, hole, table, e->nb, w); return; }
+    int L = d->n;
+    double pairs = (double)(L - 1) * (L - 1); /* accepted ordered (r1, r2): L*(L-1) - (L-1) */
+    for (int r1 = 0; r1 < L; r1++)
+        for (int r2 = 0; r2 < L - 1; r2++) {
+            if (r1 == r2) continue;
+            deck_t d2 = *d;
+            hole[p][0] = deck_pop(&d2, r1);
+            hole[p][1] = deck_pop(&d2, r2);
+            enum_players(e, &d2, hole, table, p + 1, w / pairs);
+        }
+}
+
+int mcqo_exact(const uint8_t *hero, const uint8_t *board, int nb, int n_players, double *out) {
+    if (!valid_query(hero, board, nb, n_players)) return -1;
+    double leaves = 1;
+    int L = 50 - nb;
+    for (int p = 1; p < n_players; p++) { leaves *= (double)(L - 1) * (L - 1); L -= 2; }
+    for (int k = nb; k < 5; k++) { leaves *= L - 1; L--; }
+    if (leaves > 3e8) return -1;
+    enum_t e = {hero, board, nb, n_players, 0, 0, 0};
+    deck_t d;
+    uint8_t hole[10][2], table[5];
+    deck_init(&d);
+    for (int i = 0; i < nb; i++) { deck_remove(&d, board[i]); table[i] = board[i]; }
+    hole[0][0] = hero[0]; hole[0][1] = hero[1];
+    deck_remove(&d, hero[0]);
+    deck_remove(&d, hero[1]);
+    enum_players(&e, &d, hole, table, 1, 1.0);
+    out[0] = e.win; out[1] = e.tie; out[2] = e.leaves;
+    return 0;
+}

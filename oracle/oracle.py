@@ -1,0 +1,184 @@
+"""ctypes binding of oracle/libmcq_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module; nothing under
+neuron_poker_amd/ does.  See the header of oracle/mcq_oracle.c for what the oracle restates and how it is
+pinned to the reference.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libmcq_oracle.so")
+
+TYPES = ["HighCard", "Pair", "TwoPair", "ThreeOfAKind", "Straight", "Flush", "FullHouse", "FoufOfAKind",
+         "StraightFlush"]
+RANKS = "23456789TJQKA"
+SUITS = "CDHS"
+MODE_MT, MODE_CTR = 0, 1
+
+
+def card_id(s):
+    return 4 * RANKS.index(s[0]) + SUITS.index(s[1])
+
+
+def card_str(c):
+    return RANKS[int(c) >> 2] + SUITS[int(c) & 3]
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "mcq_oracle.c")
+    if force or not os.path.exists(_SO) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(_SO)):
+        subprocess.check_call(["make", "-C", _HERE, "libmcq_oracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        u8p, u32p, u64p, i32p = (C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
+                                 C.POINTER(C.c_int32))
+        L.mcqo_mt_words.argtypes = [C.c_uint32, C.c_uint32, u32p]
+        L.mcqo_mt_words.restype = None
+        L.mcqo_np_randint.argtypes = [C.c_uint32, C.c_uint32, u32p, u32p]
+        L.mcqo_np_randint.restype = C.c_uint64
+        L.mcqo_philox4x32_10.argtypes = [u32p, u32p, u32p]
+        L.mcqo_philox4x32_10.restype = None
+        L.mcqo_xoshiro_stream.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, u32p]
+        L.mcqo_xoshiro_stream.restype = None
+        L.mcqo_calc_score.argtypes = [u8p, C.c_int, i32p]
+        L.mcqo_calc_score.restype = None
+        L.mcqo_compare.argtypes = [u8p, u8p]
+        L.mcqo_compare.restype = C.c_int
+        L.mcqo_best_hand.argtypes = [u8p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.mcqo_best_hand.restype = C.c_int
+        L.mcqo_run.argtypes = [C.c_int, u8p, u8p, C.c_int, C.c_int, C.c_uint32, C.c_uint64, C.c_uint64, u64p, u8p,
+                               C.c_uint32, C.POINTER(C.c_uint16), u64p]
+        L.mcqo_run.restype = C.c_int
+        L.mcqo_run_batch.argtypes = [C.c_int, u8p, C.c_size_t, C.c_uint64, C.c_uint64, u64p, C.c_int]
+        L.mcqo_run_batch.restype = C.c_int
+        L.mcqo_exact.argtypes = [u8p, u8p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        L.mcqo_exact.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _ids(cards):
+    return np.array([card_id(c) if isinstance(c, str) else int(c) for c in cards], np.uint8)
+
+
+def mt_words(seed, n):
+    out = np.zeros(n, np.uint32)
+    lib().mcqo_mt_words(seed, n, _p(out, C.c_uint32))
+    return out
+
+
+def np_randint(seed, bounds):
+    b = np.ascontiguousarray(bounds, np.uint32)
+    out = np.zeros(len(b), np.uint32)
+    words = lib().mcqo_np_randint(seed, len(b), _p(b, C.c_uint32), _p(out, C.c_uint32))
+    return out, int(words)
+
+
+def philox4x32_10(ctr, key):
+    c = np.array(ctr, np.uint32)
+    k = np.array(key, np.uint32)
+    out = np.zeros(4, np.uint32)
+    lib().mcqo_philox4x32_10(_p(c, C.c_uint32), _p(k, C.c_uint32), _p(out, C.c_uint32))
+    return out
+
+
+def xoshiro_stream(seed, qid, stream, n):
+    out = np.zeros(n, np.uint32)
+    lib().mcqo_xoshiro_stream(seed, qid, stream, n, _p(out, C.c_uint32))
+    return out
+
+
+def calc_score(cards):
+    """-> (score tuple, card_ranks tuple, type index) like hand_evaluator._calc_score."""
+    c = _ids(cards)
+    out = np.zeros(15, np.int32)
+    lib().mcqo_calc_score(_p(c, C.c_uint8), len(c), _p(out, C.c_int32))
+    return tuple(int(x) for x in out[1:1 + out[0]]), tuple(int(x) for x in out[5:5 + out[4]]), int(out[14])
+
+
+def compare(a, b):
+    a, b = _ids(a), _ids(b)
+    return lib().mcqo_compare(_p(a, C.c_uint8), _p(b, C.c_uint8))
+
+
+def best_hand(hands):
+    """hands: [n][7] -> (winner index, winner type index, tie flag)."""
+    h = np.ascontiguousarray(np.array([_ids(x) for x in hands], np.uint8))
+    t, tie = C.c_int(0), C.c_int(0)
+    w = lib().mcqo_best_hand(_p(h, C.c_uint8), len(h), C.byref(t), C.byref(tie))
+    return w, t.value, tie.value
+
+
+def run(mode, hero, board, n_players, runs, seed, qid=0, keep=0):
+    """One query.  -> dict(runs, passes, win, tie, by_type[9], wins, equity[, trace, words, mt_words])."""
+    h, b = _ids(hero), _ids(board)
+    bb = np.zeros(5, np.uint8)
+    bb[:len(b)] = b
+    out = np.zeros(13, np.uint64)
+    trace = np.zeros((max(keep, 1), n_players, 7), np.uint8)
+    words = np.zeros(max(keep, 1), np.uint16)
+    tw = C.c_uint64(0)
+    rc = lib().mcqo_run(mode, _p(h, C.c_uint8), _p(bb, C.c_uint8), len(b), n_players, runs, seed, qid,
+                        _p(out, C.c_uint64), _p(trace, C.c_uint8), keep, _p(words, C.c_uint16), C.byref(tw))
+    if rc:
+        raise ValueError("invalid query")
+    r = {"runs": int(out[0]), "passes": int(out[1]), "win": int(out[2]), "tie": int(out[3]),
+         "by_type": [int(x) for x in out[4:]], "wins": int(out[2] + out[3]), "mt_words": int(tw.value),
+         "tallies": out}
+    r["equity"] = r["wins"] / r["runs"] if r["runs"] else 0.0
+    if keep:
+        r["trace"] = trace[:keep]
+        r["words"] = words[:keep]
+    return r
+
+
+def pack_queries(hole, board, n_players, runs):
+    """Build the 16-byte mcq_query records.  board: [B,5] with 0xFF for absent cards (left-packed)."""
+    hole = np.asarray(hole, np.uint8).reshape(-1, 2)
+    B = len(hole)
+    board = np.asarray(board, np.uint8).reshape(B, 5)
+    q = np.zeros((B, 16), np.uint8)
+    q[:, 0:2] = hole
+    q[:, 2:7] = board
+    q[:, 7] = (board != 255).sum(1)
+    q[:, 8] = np.broadcast_to(np.asarray(n_players, np.uint8), (B,))
+    q[:, 12:16] = np.broadcast_to(np.asarray(runs, np.uint32), (B,)).astype("<u4").view(np.uint8).reshape(B, 4)
+    return q
+
+
+def run_batch(mode, queries, seed, first_qid=0, threads=1):
+    q = np.ascontiguousarray(queries, np.uint8).reshape(-1, 16)
+    out = np.zeros((len(q), 13), np.uint64)
+    rc = lib().mcqo_run_batch(mode, _p(q, C.c_uint8), len(q), seed, first_qid, _p(out, C.c_uint64), threads)
+    if rc:
+        raise ValueError("invalid query in batch")
+    return out
+
+
+def exact(hero, board, n_players):
+    """Exact (P(strict win), P(tie credited to hero), leaves) under the reference's dealing law."""
+    h, b = _ids(hero), _ids(board)
+    bb = np.zeros(5, np.uint8)
+    bb[:len(b)] = b
+    out = (C.c_double * 3)()
+    rc = lib().mcqo_exact(_p(h, C.c_uint8), _p(bb, C.c_uint8), len(b), n_players, out)
+    if rc:
+        raise ValueError("query invalid or tree too large for exact enumeration")
+    return out[0], out[1], int(out[2])

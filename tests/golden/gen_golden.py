@@ -1,0 +1,322 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING the reference.
+
+Only runnable in the build container (needs /root/reference); the fixtures it writes are
+plain data (card ids, integer tallies, category ids) and are committed, the reference's
+source never is.  Usage:
+
+    PYTHONDONTWRITEBYTECODE=1 python3 tests/golden/gen_golden.py
+
+What is captured (ids follow SURVEY.md section 8c):
+  F1  evaluator_hands.npz   7-card hands -> (category, card_ranks) from tools/hand_evaluator.py:_calc_score
+      evaluator_cases.json  the 14 cases of tests/test_evaluator.py + constructed quirk cases
+      showdowns.npz         N-hand showdowns -> winner index from tools/hand_evaluator.py:eval_best_hand
+  F2  deal_traces.npz       per (seed, hero, board, N): first K iterations' dealt cards, MT words/iteration
+  F3  tallies.json          seeded run_montecarlo tallies (wins, passes, per-type wins, MT words)
+  F4  stat_expectations.json the (hero, board, N, expected %) rows of tests/test_montecarlo_python.py
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REF = "/root/reference"
+sys.path.insert(0, REF)
+sys.dont_write_bytecode = True
+
+from tools import hand_evaluator as he  # noqa: E402
+from tools import montecarlo_python as mp  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+RANKS = "23456789TJQKA"
+SUITS = "CDHS"
+TYPES = ["HighCard", "Pair", "TwoPair", "ThreeOfAKind", "Straight", "Flush", "FullHouse", "FoufOfAKind",
+         "StraightFlush"]
+FAR = time.time() + 1e9
+
+
+def cid(s):
+    return 4 * RANKS.index(s[0]) + SUITS.index(s[1])
+
+
+def cstr(c):
+    return RANKS[c >> 2] + SUITS[c & 3]
+
+
+def score_of(cards):
+    score, ranks, typ = he._calc_score([cstr(c) for c in cards])
+    return TYPES.index(typ), list(ranks), list(score)
+
+
+# ----------------------------------------------------------------------------- F1
+def sample_hands(g):
+    """Uniform hands plus sub-deck hands so that rare categories / quirks are well covered."""
+    out = []
+    for _ in range(30000):
+        out.append(g.choice(52, 7, replace=False))
+    for _ in range(8000):  # two suits only -> many flushes / straight flushes
+        s = g.choice(4, 2, replace=False)
+        sub = np.array([4 * r + x for r in range(13) for x in s])
+        out.append(g.choice(sub, 7, replace=False))
+    for _ in range(8000):  # window of 6 consecutive ranks (ace-low wrap) -> straights, quads, full houses
+        lo = g.integers(-1, 8)
+        rr = [(lo + k) % 13 for k in range(6)]
+        sub = np.array([4 * r + x for r in rr for x in range(4)])
+        out.append(g.choice(sub, 7, replace=False))
+    for _ in range(4000):  # one suit + 10 random other cards -> straight flushes with 6/7 suited cards
+        s = g.integers(0, 4)
+        suited = [4 * r + s for r in range(13)]
+        others = [c for c in range(52) if c & 3 != s]
+        sub = np.array(suited + list(g.choice(others, 6, replace=False)))
+        out.append(g.choice(sub, 7, replace=False))
+    return np.array(out, dtype=np.uint8)
+
+
+def gen_evaluator(g):
+    hands = sample_hands(g)
+    m = len(hands)
+    cat = np.zeros(m, np.uint8)
+    nr = np.zeros(m, np.uint8)
+    ranks = np.full((m, 8), -128, np.int8)
+    for i, h in enumerate(hands):
+        c, r, _ = score_of(h)
+        cat[i] = c
+        nr[i] = len(r)
+        ranks[i, :len(r)] = r
+    np.savez_compressed(os.path.join(HERE, "evaluator_hands.npz"), cards=hands, category=cat, n_ranks=nr,
+                        card_ranks=ranks)
+    print("evaluator_hands:", m, "categories", np.bincount(cat, minlength=9))
+
+
+EVAL_CASES = [  # (hands, expected winner index) -- tests/test_evaluator.py:9-133
+    ([['3H', '3S', '4H', '4S', '8S', '8C', 'QH'], ['KH', '6C', '4H', '4S', '8S', '8C', 'QH']], 1),
+    ([['8H', '8D', 'QH', '7H', '9H', 'JH', 'TH'], ['KH', '6C', 'QH', '7H', '9H', 'JH', 'TH']], 1),
+    ([['AS', 'KS', 'TS', '9S', '7S', '2H', '2H'], ['AS', 'KS', 'TS', '9S', '8S', '2H', '2H']], 1),
+    ([['8S', 'TS', '8H', 'KS', '9S', 'TH', 'KH'], ['TD', '7S', '8H', 'KS', '9S', 'TH', 'KH']], 0),
+    ([['2D', '2H', 'AS', 'AD', 'AH', '8S', '7H'], ['7C', '7S', '7H', 'AD', 'AS', '8S', '8H']], 0),
+    ([['7C', '7S', '7H', 'AD', 'KS', '5S', '8H'], ['2D', '3H', 'AS', '4D', '5H', '8S', '7H']], 1),
+    ([['7C', '7C', 'AC', 'AC', '8C', '8S', '7H'], ['2C', '3C', '4C', '5C', '6C', '8S', 'KH']], 1),
+    ([['AC', 'JS', 'AS', '2D', '5H', '3S', '3H'], ['QD', 'JD', 'TS', '9D', '6H', '8S', 'KH'],
+      ['2D', '3D', '4S', '5D', '6H', '8S', 'KH']], 1),
+    ([['7C', '5S', '3S', 'JD', '8H', '2S', 'KH'], ['AD', '3D', '4S', '5D', '9H', '8S', 'KH']], 1),
+    ([['2C', '2D', '4S', '4D', '4H', '8S', 'KH'], ['7C', '7S', '7D', '7H', '8H', '8S', 'JH']], 1),
+    ([['7C', '5S', '3S', 'JD', '8H', '2S', 'KH'], ['AD', '3D', '3S', '5D', '9H', '8S', 'KH']], 1),
+    ([['7H', '7S', '3S', 'JD', '8H', '2S', 'KH'], ['7D', '3D', '3S', '7C', '9H', '8S', 'KH']], 1),
+    ([['AS', '8H', 'TS', 'JH', '3H', '2H', 'AH'], ['QD', 'QH', 'TS', 'JH', '3H', '2H', 'AH']], 1),
+    ([['9S', '7H', 'KS', 'KH', 'AH', 'AS', 'AC'], ['8D', '2H', 'KS', 'KH', 'AH', 'AS', 'AC']], 0),
+]
+
+QUIRK_CASES = [  # constructed: SURVEY.md 8a-E Q1..Q4 (hole cards first, then the shared board)
+    # Q1 quads: tie-break is the two highest distinct ranks of all seven cards
+    [['KC', 'QD', '5C', '5D', '5H', '5S', '2C'], ['KD', 'JD', '5C', '5D', '5H', '5S', '2C']],
+    [['9C', '9D', '9H', '9S', '5C', '5D', 'KH'], ['5H', '5S', '9H', '9S', '5C', '5D', 'KH']],
+    [['AS', '9S', '7H', 'AH', '7C', '7S', '7D'], ['JD', '9H', '7H', 'AH', '7C', '7S', '7D']],
+    # Q2 straight flush: all suited ranks count, -1 when the suit holds the ace
+    [['AH', '2C', '2H', '3H', '4H', '5H', '9D'], ['6H', '2D', '2H', '3H', '4H', '5H', '9D']],
+    [['KH', '2C', '4H', '5H', '6H', '7H', '8H'], ['9H', '2D', '4H', '5H', '6H', '7H', '8H']],
+    [['2H', '2C', '3H', '4H', '5H', '6H', '7H'], ['8H', '2D', '3H', '4H', '5H', '6H', '7H']],
+    [['AH', 'KH', '2H', '3H', '4H', '5H', 'QH'], ['6H', '7H', '2H', '3H', '4H', '5H', 'QH']],
+    # Q3 flush + off-suit straight -> Flush
+    [['9H', '8D', '7H', '6H', '5C', '2H', 'KH'], ['9D', '8C', '7H', '6H', '5C', '2H', 'KH']],
+    # wheel vs six-high straight, ace-high straight, broadway with pair
+    [['AC', '2D', '3H', '4S', '5C', '9D', 'KH'], ['6C', '2D', '3H', '4S', '5C', '9D', 'KH']],
+    [['AC', 'KD', 'QH', 'JS', 'TC', 'TD', '2H'], ['9C', 'KD', 'QH', 'JS', 'TC', 'TD', '2H']],
+    # three pair, two trips, trips + two pairs
+    [['AC', 'AD', 'KC', 'KD', 'QC', 'QD', '2H'], ['AH', 'AS', 'KC', 'KD', 'QC', 'QD', 'JH']],
+    [['AC', 'AD', 'AH', 'KC', 'KD', 'KH', '2S'], ['KS', 'QS', 'AH', 'KC', 'KD', 'KH', '2S']],
+    [['AC', 'AD', 'AH', 'KC', 'KD', 'QH', 'QS'], ['KH', 'KS', 'AH', 'KC', 'KD', 'QH', 'QS']],
+    # identical ranks, different suits -> exact tie, first hand wins
+    [['AC', 'KD', '2H', '5S', '9C', 'JD', 'QH'], ['AD', 'KC', '2H', '5S', '9C', 'JD', 'QH']],
+]
+
+
+def gen_cases():
+    cases = []
+    for hands, exp in EVAL_CASES:
+        best, typ = he.eval_best_hand(hands)
+        assert hands.index(best) == exp
+        cases.append({"source": "tests/test_evaluator.py", "hands": hands, "winner": exp, "winner_type": typ,
+                      "scores": [list(map(lambda t: list(t) if isinstance(t, tuple) else t, he._calc_score(h)))
+                                 for h in hands]})
+    for hands in QUIRK_CASES:
+        best, typ = he.eval_best_hand(hands)
+        cases.append({"source": "constructed", "hands": hands, "winner": hands.index(best), "winner_type": typ,
+                      "scores": [list(map(lambda t: list(t) if isinstance(t, tuple) else t, he._calc_score(h)))
+                                 for h in hands]})
+    with open(os.path.join(HERE, "evaluator_cases.json"), "w") as f:
+        json.dump(cases, f, indent=0)
+    print("evaluator_cases:", len(cases))
+
+
+def gen_showdowns(g):
+    rows = []
+    for k in range(24000):
+        n = int(g.integers(2, 11))
+        mode = k % 4
+        if mode == 0:
+            sub = np.arange(52)
+        elif mode == 1:  # two suits + a few
+            s = g.choice(4, 2, replace=False)
+            sub = np.array([c for c in range(52) if (c & 3) in s])
+            n = min(n, 10)
+        elif mode == 2:  # 8 consecutive ranks
+            lo = g.integers(-1, 6)
+            rr = [(lo + j) % 13 for j in range(8)]
+            sub = np.array([4 * r + x for r in rr for x in range(4)])
+        else:  # one full suit + 14 others
+            s = g.integers(0, 4)
+            others = [c for c in range(52) if c & 3 != s]
+            sub = np.array([4 * r + s for r in range(13)] + list(g.choice(others, 14, replace=False)))
+        need = 5 + 2 * n
+        if need > len(sub):
+            n = (len(sub) - 5) // 2
+            need = 5 + 2 * n
+        cards = g.choice(sub, need, replace=False)
+        board = list(cards[:5])
+        hands = [[int(cards[5 + 2 * i]), int(cards[6 + 2 * i])] + [int(b) for b in board] for i in range(n)]
+        shands = [[cstr(c) for c in h] for h in hands]
+        best, typ = he.eval_best_hand(shands)
+        rows.append((n, hands, shands.index(best), TYPES.index(typ)))
+    S = len(rows)
+    arr = np.full((S, 10, 7), 255, np.uint8)
+    nn = np.zeros(S, np.uint8)
+    win = np.zeros(S, np.uint8)
+    wt = np.zeros(S, np.uint8)
+    for i, (n, hands, w, t) in enumerate(rows):
+        nn[i] = n
+        arr[i, :n] = np.array(hands, np.uint8)
+        win[i] = w
+        wt[i] = t
+    np.savez_compressed(os.path.join(HERE, "showdowns.npz"), hands=arr, n_players=nn, winner=win, winner_type=wt)
+    print("showdowns:", S, "winner types", np.bincount(wt, minlength=9))
+
+
+# ----------------------------------------------------------------------------- F2 / F3
+class Recorder:
+    """Wraps montecarlo_python.eval_best_hand to capture every iteration's dealt hands and MT position."""
+
+    def __init__(self, keep):
+        self.keep = keep
+        self.hands = []
+        self.words = []
+        self.total_words = 0
+        self.pos = None
+        self.orig = mp.eval_best_hand
+
+    def start(self):
+        self.pos = np.random.get_state()[2]
+
+    def __call__(self, hands):
+        pos = np.random.get_state()[2]
+        d = (pos - self.pos) % 624
+        self.pos = pos
+        self.total_words += d
+        if len(self.hands) < self.keep:
+            self.hands.append([[cid(c) for c in h] for h in hands])
+            self.words.append(d)
+        return self.orig(hands)
+
+
+def run_ref(hero, board, n, runs, seed, keep=0):
+    rec = Recorder(keep)
+    mp.eval_best_hand = rec
+    try:
+        np.random.seed(seed)
+        rec.start()
+        sim = mp.MonteCarlo()
+        sim.run_montecarlo([list(hero)], list(board), n, 1, maxRuns=runs, timeout=FAR, ghost_cards='',
+                           opponent_range=1)
+    finally:
+        mp.eval_best_hand = rec.orig
+    by_type = {t: 0 for t in TYPES}
+    for k, v in sim.winnerCardTypeList.items():
+        by_type[k] = int(round(v * sim.runs))
+    wins = int(round(sim.equity * sim.runs))
+    assert sum(by_type.values()) == wins
+    return {"hero": list(hero), "board": list(board), "n_players": int(n), "runs": int(sim.runs), "seed": int(seed),
+            "wins": wins, "passes": int(sim.passes), "by_type": [by_type[t] for t in TYPES],
+            "mt_words": int(rec.total_words)}, rec
+
+
+TALLY_GRID = [  # (hero, board, n_players, runs, seed)
+    (['AH', 'KH'], [], 2, 10000, 0), (['AH', 'KH'], [], 2, 10000, 1), (['AH', 'KH'], [], 2, 10000, 12345),
+    (['AH', 'KH'], [], 2, 100000, 0), (['AH', 'KH'], [], 2, 100000, 1),
+    (['AH', 'KH'], [], 3, 20000, 0), (['AH', 'KH'], [], 6, 20000, 0),
+    (['2C', '7D'], ['AS', 'KS', 'QS'], 6, 20000, 0),
+    (['TC', 'TH'], ['4D', 'QD', 'KC', '2S'], 3, 20000, 5),
+    (['3H', '3S'], ['8S', '4S', 'QH', '8C', '4H'], 2, 20000, 7),
+    (['8S', 'TS'], [], 5, 20000, 3), (['5C', 'JS'], [], 4, 20000, 11),
+    (['AS', 'AC'], [], 10, 10000, 2), (['2C', '2D'], ['2H', '2S', 'AS'], 10, 10000, 4),
+    (['AS', 'KS'], ['QS', 'JS', 'TS', '2C'], 9, 5000, 6),
+    (['7H', '2C'], [], 1, 3000, 9),
+    (['JD', 'JS'], ['8C', 'TC', 'JC', '5H', 'QC'], 3, 20000, 4294967295),
+    (['AD', 'AS'], ['AC', 'AH', 'KD'], 2, 5000, 2 ** 31),
+]
+
+TRACE_GRID = [  # (hero, board, n_players, seed) -- first 1000 iterations kept
+    (['AH', 'KH'], [], 2, 0), (['AH', 'KH'], [], 3, 1), (['2C', '7D'], ['AS', 'KS', 'QS'], 6, 0),
+    (['TC', 'TH'], ['4D', 'QD', 'KC', '2S'], 6, 5), (['3H', '3S'], ['8S', '4S', 'QH', '8C', '4H'], 4, 7),
+    (['AS', 'AC'], [], 10, 2), (['2C', '3C'], ['AS', 'AH', 'AD', 'AC'], 10, 3),
+]
+
+
+def gen_tallies():
+    out = []
+    for hero, board, n, runs, seed in TALLY_GRID:
+        t0 = time.time()
+        row, _ = run_ref(hero, board, n, runs, seed)
+        out.append(row)
+        print("tally", hero, board, n, runs, seed, "->", row["wins"], row["passes"], row["mt_words"],
+              "%.1fs" % (time.time() - t0))
+    with open(os.path.join(HERE, "tallies.json"), "w") as f:
+        json.dump(out, f, indent=0)
+
+
+def gen_traces():
+    K = 1000
+    d = {}
+    meta = []
+    for i, (hero, board, n, seed) in enumerate(TRACE_GRID):
+        row, rec = run_ref(hero, board, n, K, seed, keep=K)
+        hands = np.array(rec.hands, np.uint8)  # [K, n, 7]
+        d["hands_%d" % i] = hands
+        d["words_%d" % i] = np.array(rec.words, np.uint16)
+        meta.append({"hero": hero, "board": board, "n_players": n, "seed": seed, "runs": K, "wins": row["wins"],
+                     "passes": row["passes"], "mt_words": row["mt_words"]})
+    d["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, "deal_traces.npz"), **d)
+    print("deal_traces:", len(meta))
+
+
+# ----------------------------------------------------------------------------- F4
+STAT_ROWS = [  # tests/test_montecarlo_python.py:44-212 (hero, board, players, expected %); tolerance there: +-3
+    (['3H', '3S'], ['8S', '4S', 'QH', '8C', '4H'], 2, 40.2), (['8H', '8D'], ['QH', '7H', '9H', 'JH', 'TH'], 2, 95.6),
+    (['AS', 'KS'], [], 3, 49.9 + 1.9), (['AS', 'KS'], [], 2, 66.1 + 1.6),
+    (['8S', 'TS'], ['8H', 'KS', '9S', 'TH', 'KH'], 2, 71.5 + 5.9), (['8S', 'TS'], ['2S', '3S', '4S', 'KS', 'AS'], 2, 87),
+    (['8S', '2S'], ['5S', '3S', '4S', 'KS', 'AS'], 2, 100), (['8S', 'TS'], [], 5, 22.6 + 2.9),
+    (['2C', 'QS'], [], 2, 49.6), (['7H', '7S'], ['7C', '8C', '8S', 'AC', 'AH'], 2, 83),
+    (['3S', 'QH'], ['2C', '5H', '7C'], 2, 30.9 + 2.2), (['5C', 'JS'], [], 4, 23),
+    (['TC', 'TH'], ['4D', 'QD', 'KC'], 2, 66.7 + 0.38), (['JH', 'QS'], ['5C', 'JD', 'AS', 'KS', 'QD'], 2, 77),
+    (['2H', '8S'], ['AC', 'AD', 'AS', 'KS', 'KD'], 2, 95), (['KD', 'KS'], ['4D', '6S', '9C', '9S', 'TC'], 2, 88),
+    (['5H', 'KD'], ['KH', 'JS', '2C', 'QS'], 2, 75.6 + 3.6), (['JD', 'JS'], ['8C', 'TC', 'JC', '5H', 'QC'], 3, 26.1),
+    (['TD', '7D'], ['8D', 'QD', '7C', '5D', '6D'], 2, 87),
+]
+
+
+def gen_stats():
+    rows = [{"hero": h, "board": b, "n_players": n, "expected_pct": e, "tol_pct": 3.0} for h, b, n, e in STAT_ROWS]
+    with open(os.path.join(HERE, "stat_expectations.json"), "w") as f:
+        json.dump(rows, f, indent=0)
+    print("stat_expectations:", len(rows))
+
+
+if __name__ == "__main__":
+    g = np.random.default_rng(20261004)
+    gen_stats()
+    gen_cases()
+    gen_evaluator(g)
+    gen_showdowns(g)
+    gen_traces()
+    gen_tallies()
