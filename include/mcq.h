@@ -1,0 +1,118 @@
+/*
+ * mcq.h -- C ABI of libmcq_hip.so: the MI355X (gfx950) Monte-Carlo poker-equity engine.
+ *
+ * This is the drop-in boundary for ONE path of jaronlong52/neuron_poker: the equity query
+ *   tools/montecarlo_python.py:401-406  get_equity(player_cards, table_cards, players, runs) -> float
+ *   tools/montecarlo_python.py:191-252  MonteCarlo.run_montecarlo(...) -> (equity, winTypesDict)
+ * which gym_env/env.py:75-81 selects once and calls at gym_env/env.py:249-262.  The reference has no C ABI
+ * of its own (its native variant is a pybind11 module, tools/montecarlo_cpp/pymontecarlo.cpp:21-23, with the
+ * same four-argument call); the functions below are what a Python binding for this path binds instead --
+ * neuron_poker_amd/montecarlo_hip.py does so through ctypes, and INTEGRATION.md shows the stub.
+ *
+ * Plain C: pointers and sizes only, no C++ or torch types.  All functions return MCQ_OK (0) or a negative
+ * MCQ_E* code and never throw or abort; mcq_last_error() returns a thread-local description of the last
+ * failure.  Card id c = 4*rank + suit with rank = index in "23456789TJQKA", suit = index in "CDHS"
+ * (tools/hand_evaluator.py:5-6; the deck order of tools/montecarlo_python.py:114-119 is ascending c).
+ */
+#ifndef MCQ_H
+#define MCQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__) || defined(__clang__)
+#define MCQ_API __attribute__((visibility("default")))
+#else
+#define MCQ_API
+#endif
+
+#define MCQ_VERSION_MAJOR 0
+#define MCQ_VERSION_MINOR 1
+#define MCQ_VERSION_PATCH 0
+
+/* error codes */
+#define MCQ_OK 0
+#define MCQ_EINVAL (-1)  /* bad argument: card out of range, duplicate card, n_players not in [1,10], ... */
+#define MCQ_EDEVICE (-2) /* HIP runtime failure; mcq_last_error() carries the HIP error string */
+#define MCQ_ENOMEM (-3)  /* host or device allocation failed */
+
+/* random-number front ends (the deal -> evaluate -> tally body is shared) */
+#define MCQ_MODE_PHILOX 0         /* production: counter-based streams, Philox4x32-10 keyed xoshiro128++ */
+#define MCQ_MODE_REPLAY_MT19937 1 /* parity: query i replays np.random.seed((seed + first_query_id + i) mod 2^32)
+                                     exactly as tools/montecarlo_python.py consumes it -> bit-exact tallies */
+
+/* One equity query (16 bytes, no pointers).  Mirrors the arguments of get_equity
+ * (tools/montecarlo_python.py:401): hero's two cards, 0/3/4/5 known table cards, players, runs. */
+typedef struct mcq_query {
+    uint8_t hole[2];     /* hero's cards */
+    uint8_t board[5];    /* known table cards, first n_board entries used */
+    uint8_t n_board;     /* 0..5 */
+    uint8_t n_players;   /* hero + opponents, 1..10 (gym_env/env.py:249 passes sum(alive)) */
+    uint8_t reserved[3]; /* must be 0 */
+    uint32_t runs;       /* iterations (maxRuns); exactly this many are executed, no wall-clock cut-off */
+} mcq_query;
+
+/* Per-query tallies (104 bytes, unsigned integers only).
+ * Reference's wins (montecarlo_python.py:223-229, ties go to hero: hand_evaluator.py:23) = win + tie
+ * = sum(by_type); equity = (win + tie) / runs (montecarlo_python.py:243).
+ * by_type order = HighCard, Pair, TwoPair, ThreeOfAKind, Straight, Flush, FullHouse, FoufOfAKind [sic],
+ * StraightFlush (hand_evaluator.py:92-115): hero's hand type in the iterations he wins.
+ * passes = opponent-deal attempts (montecarlo_python.py:168). */
+typedef struct mcq_result {
+    uint64_t runs;
+    uint64_t passes;
+    uint64_t win; /* hero strictly best */
+    uint64_t tie; /* hero best together with at least one opponent (credited to hero by the reference) */
+    uint64_t by_type[9];
+} mcq_result;
+
+typedef struct mcq_ctx mcq_ctx;
+
+/* Number of HIP devices visible, or a negative MCQ_E* code. */
+MCQ_API int mcq_device_count(void);
+
+/* Create an engine bound to HIP device `device` (one context per GPU / per process rank).  Owns its stream,
+ * device and pinned staging buffers and lookup tables until mcq_destroy.  Not re-entrant: one call in flight
+ * per context.  Returns NULL on failure (see mcq_last_error). flags must be 0. */
+MCQ_API mcq_ctx *mcq_create(int device, int flags);
+MCQ_API void mcq_destroy(mcq_ctx *ctx);
+
+/* Evaluate n queries held in HOST memory; blocks until out[0..n) is written.  The caller owns q and out.
+ * Query i uses query id first_query_id + i, so a batch split into shards (other ranks, other calls) with
+ * the matching first_query_id gives bit-identical per-query tallies.  All queries are validated first;
+ * on MCQ_EINVAL nothing is launched and out is untouched. */
+MCQ_API int mcq_eval_batch(mcq_ctx *ctx, const mcq_query *q, size_t n, uint64_t seed, uint64_t first_query_id, int mode,
+                   mcq_result *out);
+
+/* n == 1 convenience: exactly get_equity's arguments after card-string conversion. */
+MCQ_API int mcq_eval_one(mcq_ctx *ctx, const mcq_query *q, uint64_t seed, int mode, mcq_result *out);
+
+/* Same computation with queries and results RESIDENT IN HBM: d_queries -> mcq_query[n], d_results ->
+ * mcq_result[n] (overwritten), both device pointers on this context's device; hip_stream is a hipStream_t
+ * (NULL = the context's own stream).  Asynchronous: returns after enqueueing; no host synchronisation, so it
+ * can be captured into a hipGraph.  MCQ_MODE_PHILOX only.  Invalid queries cannot be rejected up front here:
+ * their result has runs = 0 and passes = UINT64_MAX. */
+MCQ_API int mcq_eval_batch_device(mcq_ctx *ctx, const void *d_queries, size_t n, uint64_t seed, uint64_t first_query_id,
+                          void *d_results, void *hip_stream);
+
+/* Showdown with the same device evaluator (tools/hand_evaluator.py:9-24 get_winner / eval_best_hand):
+ * hands = n_tables x n_players x 7 card ids (host); winner[t] = index of the best hand (first of equals),
+ * winner_type[t] = its by_type index, keys (optional, n_tables x n_players) = the 32-bit ranking keys. */
+MCQ_API int mcq_showdown(mcq_ctx *ctx, const uint8_t *hands, size_t n_tables, int n_players, uint8_t *winner,
+                 uint8_t *winner_type, uint32_t *keys);
+
+/* Duration in milliseconds of the most recent evaluation kernel launched through this context's host entry
+ * points, measured with HIP events on the context's stream (0 if none). */
+MCQ_API float mcq_last_kernel_ms(mcq_ctx *ctx);
+
+MCQ_API const char *mcq_last_error(void);
+MCQ_API void mcq_version(int *major, int *minor, int *patch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCQ_H */

@@ -1,0 +1,178 @@
+"""ctypes binding of libmcq_hip.so (C ABI: include/mcq.h).  No torch, no cffi.
+
+The library is built in-tree by `python -m neuron_poker_amd.build` (or __graft_entry__.build()).  If it is
+missing, or no HIP device can be opened, this module raises -- it never falls back to a CPU implementation.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+MODE_PHILOX = 0
+MODE_REPLAY_MT19937 = 1
+MCQ_EINVAL, MCQ_EDEVICE, MCQ_ENOMEM = -1, -2, -3
+
+QUERY_DTYPE = np.dtype([("hole", "u1", (2,)), ("board", "u1", (5,)), ("n_board", "u1"), ("n_players", "u1"),
+                        ("reserved", "u1", (3,)), ("runs", "<u4")])
+RESULT_DTYPE = np.dtype([("runs", "<u8"), ("passes", "<u8"), ("win", "<u8"), ("tie", "<u8"),
+                         ("by_type", "<u8", (9,))])
+assert QUERY_DTYPE.itemsize == 16 and RESULT_DTYPE.itemsize == 104
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+_lock = threading.Lock()
+
+
+class McqError(RuntimeError):
+    """HIP / allocation failure reported by libmcq_hip.so (MCQ_EDEVICE, MCQ_ENOMEM)."""
+
+
+def library_path():
+    return os.environ.get("MCQ_LIBRARY", os.path.join(_HERE, "libmcq_hip.so"))
+
+
+def load_library():
+    """Load libmcq_hip.so and declare the prototypes of include/mcq.h.  Loud failure if it is not built."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = library_path()
+        if not os.path.exists(path):
+            raise ImportError("%s not found: build it with `python -m neuron_poker_amd.build` (hipcc, gfx950). "
+                              "neuron_poker_amd has no CPU fallback." % path)
+        L = C.CDLL(path)
+        vp, u64, sz = C.c_void_p, C.c_uint64, C.c_size_t
+        L.mcq_device_count.argtypes = []
+        L.mcq_device_count.restype = C.c_int
+        L.mcq_create.argtypes = [C.c_int, C.c_int]
+        L.mcq_create.restype = vp
+        L.mcq_destroy.argtypes = [vp]
+        L.mcq_destroy.restype = None
+        L.mcq_eval_batch.argtypes = [vp, vp, sz, u64, u64, C.c_int, vp]
+        L.mcq_eval_batch.restype = C.c_int
+        L.mcq_eval_one.argtypes = [vp, vp, u64, C.c_int, vp]
+        L.mcq_eval_one.restype = C.c_int
+        L.mcq_eval_batch_device.argtypes = [vp, vp, sz, u64, u64, vp, vp]
+        L.mcq_eval_batch_device.restype = C.c_int
+        L.mcq_showdown.argtypes = [vp, vp, sz, C.c_int, vp, vp, vp]
+        L.mcq_showdown.restype = C.c_int
+        L.mcq_last_kernel_ms.argtypes = [vp]
+        L.mcq_last_kernel_ms.restype = C.c_float
+        L.mcq_last_error.argtypes = []
+        L.mcq_last_error.restype = C.c_char_p
+        L.mcq_version.argtypes = [C.POINTER(C.c_int)] * 3
+        L.mcq_version.restype = None
+        _lib = L
+        return _lib
+
+
+def _raise(rc):
+    msg = (load_library().mcq_last_error() or b"").decode("utf-8", "replace")
+    if rc == MCQ_EINVAL:
+        raise ValueError(msg)
+    raise McqError("libmcq_hip error %d: %s" % (rc, msg))
+
+
+def pack_queries(hole, board, n_players, runs):
+    """Build mcq_query records.  hole [B,2] card ids; board [B,5] card ids, 0xFF = absent (any position: the
+    known cards are left-packed here); n_players, runs scalar or [B]."""
+    hole = np.asarray(hole, dtype=np.uint8).reshape(-1, 2)
+    B = len(hole)
+    board = np.asarray(board, dtype=np.uint8).reshape(B, 5)
+    q = np.zeros(B, QUERY_DTYPE)
+    q["hole"] = hole
+    present = board != 255
+    order = np.argsort(~present, axis=1, kind="stable")
+    packed = np.take_along_axis(board, order, axis=1)
+    nb = present.sum(1).astype(np.uint8)
+    packed[np.arange(5)[None, :] >= nb[:, None]] = 0
+    q["board"] = packed
+    q["n_board"] = nb
+    npl = np.broadcast_to(np.asarray(n_players), (B,))
+    if (npl < 0).any() or (npl > 255).any():
+        raise ValueError("n_players out of range")
+    q["n_players"] = npl.astype(np.uint8)
+    r = np.broadcast_to(np.asarray(runs), (B,))
+    if (r < 0).any() or (r > 0xffffffff).any():
+        raise ValueError("runs out of range")
+    q["runs"] = r.astype(np.uint32)
+    return q
+
+
+class Engine:
+    """One mcq_ctx: an equity engine bound to one GPU.  Not re-entrant (one call in flight per engine)."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        self._ctx = self._lib.mcq_create(int(device), 0)
+        if not self._ctx:
+            msg = (self._lib.mcq_last_error() or b"").decode("utf-8", "replace")
+            raise McqError("mcq_create(device=%d) failed: %s" % (device, msg))
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.mcq_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def eval_batch(self, queries, seed, first_query_id=0, mode=MODE_PHILOX):
+        """queries: array of QUERY_DTYPE (host).  -> array of RESULT_DTYPE."""
+        q = np.ascontiguousarray(queries, dtype=QUERY_DTYPE).reshape(-1)
+        out = np.zeros(len(q), RESULT_DTYPE)
+        rc = self._lib.mcq_eval_batch(self._ctx, q.ctypes.data, len(q), int(seed) & (2 ** 64 - 1),
+                                      int(first_query_id) & (2 ** 64 - 1), int(mode), out.ctypes.data)
+        if rc:
+            _raise(rc)
+        return out
+
+    def eval_batch_device(self, d_queries, n, seed, d_results, first_query_id=0, stream=None):
+        """Device-resident entry: d_queries / d_results are raw device pointers (ints), stream a hipStream_t
+        handle (int) or None.  Asynchronous."""
+        rc = self._lib.mcq_eval_batch_device(self._ctx, int(d_queries), int(n), int(seed) & (2 ** 64 - 1),
+                                             int(first_query_id) & (2 ** 64 - 1), int(d_results),
+                                             int(stream) if stream else None)
+        if rc:
+            _raise(rc)
+
+    def showdown(self, hands, want_keys=False):
+        """hands [T, P, 7] card ids -> (winner[T], winner_type[T][, keys[T, P]])."""
+        h = np.ascontiguousarray(hands, dtype=np.uint8)
+        if h.ndim != 3 or h.shape[2] != 7:
+            raise ValueError("hands must have shape [tables, players, 7]")
+        T, P = h.shape[0], h.shape[1]
+        win = np.zeros(T, np.uint8)
+        wt = np.zeros(T, np.uint8)
+        keys = np.zeros((T, P), np.uint32) if want_keys else None
+        rc = self._lib.mcq_showdown(self._ctx, h.ctypes.data, T, P, win.ctypes.data, wt.ctypes.data,
+                                    keys.ctypes.data if want_keys else None)
+        if rc:
+            _raise(rc)
+        return (win, wt, keys) if want_keys else (win, wt)
+
+    @property
+    def last_kernel_ms(self):
+        return float(self._lib.mcq_last_kernel_ms(self._ctx))
+
+
+_default = None
+
+
+def default_engine():
+    """Process-wide engine on device $MCQ_DEVICE (else $LOCAL_RANK, else 0), created on first use."""
+    global _default
+    if _default is None:
+        dev = int(os.environ.get("MCQ_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        n = load_library().mcq_device_count()
+        if n <= 0:
+            raise McqError("no HIP device visible: neuron_poker_amd needs an AMD GPU (no CPU fallback). " +
+                           (load_library().mcq_last_error() or b"").decode("utf-8", "replace"))
+        _default = Engine(dev % n)
+    return _default

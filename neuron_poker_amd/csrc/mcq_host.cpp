@@ -1,0 +1,365 @@
+// mcq_host.cpp -- the C ABI of include/mcq.h on top of the gfx950 kernels.
+//
+// Host responsibilities only: argument validation, staging of the 16-byte query / 104-byte result records,
+// the MT19937 walk of the parity mode (mcq_replay.hpp) and kernel launches.  There is no CPU evaluation path:
+// without a HIP device mcq_create fails and every other entry point needs a context.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <atomic>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "mcq_device.hpp"
+#include "mcq_internal.hpp"
+#include "mcq_replay.hpp"
+
+hipError_t mcq_eval_occupancy(int mode, int block, int *blocks_per_cu); /* mcq_kernels.hip */
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *what, const char *detail = nullptr) {
+    g_err = what;
+    if (detail) {
+        g_err += ": ";
+        g_err += detail;
+    }
+    return code;
+}
+
+#define HIP_TRY(expr)                                                        \
+    do {                                                                     \
+        hipError_t e_ = (expr);                                              \
+        if (e_ != hipSuccess) return fail(MCQ_EDEVICE, #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct PinBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+constexpr size_t kReplayChunkBytes = 256u << 20; /* draw bytes staged per launch in parity mode */
+
+}  // namespace
+
+struct mcq_ctx {
+    int device = 0;
+    int n_cu = 0;
+    int occ256[2] = {1, 1}; /* resident 256-thread blocks per CU of the two eval kernels */
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_ms = 0.f;
+    McqLuts *d_luts = nullptr;
+    DevBuf d_q, d_res, d_prefix, d_prefix_dev, d_draws, d_off, d_hands, d_win, d_wt, d_keys;
+    PinBuf h_q, h_res, h_draws, h_off, h_misc;
+};
+
+namespace {
+
+uint32_t tasks_of(const mcq_query &q) { return (q.runs + MCQ_TASK_ITERS - 1) / MCQ_TASK_ITERS; }
+
+/* grid/block for a launch whose total task count is known (host entry) or unknown (0) */
+void pick_geometry(const mcq_ctx *c, int mode, uint64_t total_tasks, uint32_t *grid, uint32_t *block) {
+    const uint32_t full = (uint32_t)c->n_cu * (uint32_t)c->occ256[mode];
+    if (total_tasks == 0) { *block = 256; *grid = full; return; }
+    if (total_tasks <= (uint64_t)c->n_cu * 4) { /* few tasks (single query): one wave per block spreads over CUs */
+        *block = 64;
+        *grid = (uint32_t)total_tasks;
+        return;
+    }
+    uint64_t blocks = (total_tasks + 3) / 4;
+    *block = 256;
+    *grid = (uint32_t)(blocks < full ? blocks : full);
+}
+
+int run_slice(mcq_ctx *c, int mode, const mcq_query *d_q, uint32_t n, mcq_result *d_res, uint64_t seed,
+              uint64_t first_qid, uint64_t total_tasks, const uint8_t *d_draws, const uint64_t *d_off, hipStream_t s,
+              bool timed) {
+    HIP_TRY(c->d_prefix.reserve(((size_t)n + 1) * sizeof(uint32_t)));
+    HIP_TRY(mcq_launch_prep(d_q, n, d_res, (uint32_t *)c->d_prefix.p, s));
+    uint32_t grid, block;
+    pick_geometry(c, mode, total_tasks, &grid, &block);
+    if (timed) HIP_TRY(hipEventRecord(c->ev0, s));
+    HIP_TRY(mcq_launch_eval(mode, d_q, n, (const uint32_t *)c->d_prefix.p, d_res, seed, first_qid, c->d_luts, d_draws,
+                            d_off, grid, block, s));
+    if (timed) HIP_TRY(hipEventRecord(c->ev1, s));
+    return MCQ_OK;
+}
+
+int validate(const mcq_query *q, size_t n) {
+    for (size_t i = 0; i < n; i++)
+        if (!mcq_query_valid(mcq_query_words(q[i]))) {
+            char buf[160];
+            snprintf(buf, sizeof buf,
+                     "query %zu invalid (cards must be distinct ids < 52, n_board <= 5, 1 <= n_players <= 10)", i);
+            return fail(MCQ_EINVAL, buf);
+        }
+    return MCQ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mcq_last_error(void) { return g_err.c_str(); }
+
+void mcq_version(int *major, int *minor, int *patch) {
+    if (major) *major = MCQ_VERSION_MAJOR;
+    if (minor) *minor = MCQ_VERSION_MINOR;
+    if (patch) *patch = MCQ_VERSION_PATCH;
+}
+
+int mcq_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(MCQ_EDEVICE, "hipGetDeviceCount", hipGetErrorString(e));
+    return n;
+}
+
+void mcq_destroy(mcq_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    DevBuf *db[] = {&c->d_q, &c->d_res, &c->d_prefix, &c->d_prefix_dev, &c->d_draws, &c->d_off,
+                    &c->d_hands, &c->d_win, &c->d_wt, &c->d_keys};
+    for (DevBuf *b : db) b->release();
+    PinBuf *pb[] = {&c->h_q, &c->h_res, &c->h_draws, &c->h_off, &c->h_misc};
+    for (PinBuf *b : pb) b->release();
+    if (c->d_luts) (void)hipFree(c->d_luts);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+mcq_ctx *mcq_create(int device, int flags) {
+    if (flags != 0) { fail(MCQ_EINVAL, "mcq_create: flags must be 0"); return nullptr; }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        fail(MCQ_EDEVICE, "mcq_create: no HIP device available (this library has no CPU path)",
+             e != hipSuccess ? hipGetErrorString(e) : nullptr);
+        return nullptr;
+    }
+    if (device < 0 || device >= n) { fail(MCQ_EINVAL, "mcq_create: device ordinal out of range"); return nullptr; }
+    mcq_ctx *c = new (std::nothrow) mcq_ctx();
+    if (!c) { fail(MCQ_ENOMEM, "mcq_create: out of host memory"); return nullptr; }
+    c->device = device;
+    hipDeviceProp_t prop;
+    McqLuts luts;
+    mcq_fill_luts(&luts);
+#define CREATE_TRY(expr)                                                      \
+    do {                                                                      \
+        hipError_t e2_ = (expr);                                              \
+        if (e2_ != hipSuccess) {                                              \
+            fail(MCQ_EDEVICE, #expr, hipGetErrorString(e2_));                 \
+            mcq_destroy(c);                                                   \
+            return nullptr;                                                   \
+        }                                                                     \
+    } while (0)
+    CREATE_TRY(hipSetDevice(device));
+    CREATE_TRY(hipGetDeviceProperties(&prop, device));
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipEventCreate(&c->ev0));
+    CREATE_TRY(hipEventCreate(&c->ev1));
+    CREATE_TRY(hipMalloc((void **)&c->d_luts, sizeof(McqLuts)));
+    CREATE_TRY(hipMemcpy(c->d_luts, &luts, sizeof(McqLuts), hipMemcpyHostToDevice));
+    for (int mode = 0; mode < 2; mode++) {
+        int occ = 0;
+        CREATE_TRY(mcq_eval_occupancy(mode, 256, &occ));
+        c->occ256[mode] = occ < 1 ? 1 : (occ > 8 ? 8 : occ);
+    }
+#undef CREATE_TRY
+    return c;
+}
+
+float mcq_last_kernel_ms(mcq_ctx *c) { return c ? c->last_ms : 0.f; }
+
+int mcq_eval_batch_device(mcq_ctx *c, const void *d_queries, size_t n, uint64_t seed, uint64_t first_query_id,
+                          void *d_results, void *hip_stream) {
+    if (!c) return fail(MCQ_EINVAL, "mcq_eval_batch_device: null context");
+    if (n == 0) return MCQ_OK;
+    if (!d_queries || !d_results) return fail(MCQ_EINVAL, "mcq_eval_batch_device: null buffer");
+    if (n > 0x7fffffffu) return fail(MCQ_EINVAL, "mcq_eval_batch_device: n too large");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    /* the prefix buffer must already be large enough when the call is being captured into a graph */
+    return run_slice(c, MCQ_MODE_PHILOX, (const mcq_query *)d_queries, (uint32_t)n, (mcq_result *)d_results, seed,
+                     first_query_id, 0, nullptr, nullptr, s, false);
+}
+
+int mcq_eval_batch(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed, uint64_t first_query_id, int mode,
+                   mcq_result *out) {
+    if (!c) return fail(MCQ_EINVAL, "mcq_eval_batch: null context");
+    if (mode != MCQ_MODE_PHILOX && mode != MCQ_MODE_REPLAY_MT19937) return fail(MCQ_EINVAL, "mcq_eval_batch: bad mode");
+    if (n == 0) return MCQ_OK;
+    if (!q || !out) return fail(MCQ_EINVAL, "mcq_eval_batch: null buffer");
+    if (n > 0x7fffffffu) return fail(MCQ_EINVAL, "mcq_eval_batch: n too large");
+    int rc = validate(q, n);
+    if (rc) return rc;
+    uint64_t total_tasks = 0;
+    for (size_t i = 0; i < n; i++) total_tasks += tasks_of(q[i]);
+    if (total_tasks > 0xfffffff0ull) return fail(MCQ_EINVAL, "mcq_eval_batch: too many iterations in one call");
+
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(c->h_q.reserve(n * sizeof(mcq_query)));
+    HIP_TRY(c->h_res.reserve(n * sizeof(mcq_result)));
+    HIP_TRY(c->d_q.reserve(n * sizeof(mcq_query)));
+    HIP_TRY(c->d_res.reserve(n * sizeof(mcq_result)));
+    memcpy(c->h_q.p, q, n * sizeof(mcq_query));
+    HIP_TRY(hipMemcpyAsync(c->d_q.p, c->h_q.p, n * sizeof(mcq_query), hipMemcpyHostToDevice, c->stream));
+    c->last_ms = 0.f;
+
+    if (mode == MCQ_MODE_PHILOX) {
+        rc = run_slice(c, mode, (const mcq_query *)c->d_q.p, (uint32_t)n, (mcq_result *)c->d_res.p, seed,
+                       first_query_id, total_tasks, nullptr, nullptr, c->stream, true);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(c->h_res.p, c->d_res.p, n * sizeof(mcq_result), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+        memcpy(out, c->h_res.p, n * sizeof(mcq_result));
+        return MCQ_OK;
+    }
+
+    /* parity mode: chunks of queries whose draw bytes fit the staging budget */
+    std::vector<uint64_t> passes(n, 0);
+    size_t a = 0;
+    while (a < n) {
+        size_t b = a;
+        uint64_t bytes = 0, tasks = 0;
+        HIP_TRY(c->h_off.reserve((n - a < 65536 ? n - a : 65536) * sizeof(uint64_t)));
+        uint64_t *off = (uint64_t *)c->h_off.p;
+        while (b < n && b - a < 65536) {
+            uint64_t stride = ((uint64_t)q[b].runs + 63u) & ~63ull;
+            uint64_t need = stride * mcq_draws_per_iteration(q[b]);
+            if (b > a && bytes + need > kReplayChunkBytes) break;
+            off[b - a] = bytes;
+            bytes += need;
+            tasks += tasks_of(q[b]);
+            b++;
+        }
+        const size_t m = b - a;
+        HIP_TRY(c->h_draws.reserve(bytes + 64));
+        HIP_TRY(c->d_draws.reserve(bytes + 64));
+        HIP_TRY(c->d_off.reserve(m * sizeof(uint64_t)));
+        uint8_t *hd = (uint8_t *)c->h_draws.p;
+        {
+            std::atomic<size_t> next(0);
+            unsigned hw = std::thread::hardware_concurrency();
+            size_t nt = hw ? hw : 4;
+            if (nt > 32) nt = 32;
+            if (nt > m) nt = m;
+            auto work = [&]() {
+                for (size_t i = next.fetch_add(1); i < m; i = next.fetch_add(1)) {
+                    const mcq_query &qq = q[a + i];
+                    uint64_t stride = ((uint64_t)qq.runs + 63u) & ~63ull;
+                    passes[a + i] = mcq_replay_parse(qq, (uint32_t)(seed + first_query_id + a + i), hd + off[i], stride);
+                }
+            };
+            std::vector<std::thread> th;
+            for (size_t t = 1; t < nt; t++) th.emplace_back(work);
+            work();
+            for (auto &t : th) t.join();
+        }
+        HIP_TRY(hipMemcpyAsync(c->d_draws.p, hd, bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_off.p, off, m * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+        rc = run_slice(c, mode, (const mcq_query *)c->d_q.p + a, (uint32_t)m, (mcq_result *)c->d_res.p + a, seed,
+                       first_query_id + a, tasks, (const uint8_t *)c->d_draws.p, (const uint64_t *)c->d_off.p,
+                       c->stream, true);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(c->stream)); /* staging buffers are reused by the next chunk */
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        c->last_ms += ms;
+        a = b;
+    }
+    HIP_TRY(hipMemcpyAsync(c->h_res.p, c->d_res.p, n * sizeof(mcq_result), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(out, c->h_res.p, n * sizeof(mcq_result));
+    for (size_t i = 0; i < n; i++) out[i].passes = passes[i];
+    return MCQ_OK;
+}
+
+int mcq_eval_one(mcq_ctx *c, const mcq_query *q, uint64_t seed, int mode, mcq_result *out) {
+    return mcq_eval_batch(c, q, 1, seed, 0, mode, out);
+}
+
+int mcq_showdown(mcq_ctx *c, const uint8_t *hands, size_t n_tables, int n_players, uint8_t *winner,
+                 uint8_t *winner_type, uint32_t *keys) {
+    if (!c) return fail(MCQ_EINVAL, "mcq_showdown: null context");
+    if (n_tables == 0) return MCQ_OK;
+    if (!hands || !winner || !winner_type) return fail(MCQ_EINVAL, "mcq_showdown: null buffer");
+    if (n_players < 1 || n_players > 10) return fail(MCQ_EINVAL, "mcq_showdown: n_players must be in [1,10]");
+    if (n_tables > 0x7fffffffu / 70u) return fail(MCQ_EINVAL, "mcq_showdown: n_tables too large");
+    const size_t nh = n_tables * (size_t)n_players;
+    for (size_t h = 0; h < nh; h++) {
+        uint64_t seen = 0;
+        for (int k = 0; k < 7; k++) {
+            uint8_t cd = hands[h * 7 + k];
+            if (cd >= 52 || (seen >> cd) & 1)
+                return fail(MCQ_EINVAL, "mcq_showdown: a hand needs 7 distinct card ids < 52");
+            seen |= 1ull << cd;
+        }
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(c->d_hands.reserve(nh * 7));
+    HIP_TRY(c->d_win.reserve(n_tables));
+    HIP_TRY(c->d_wt.reserve(n_tables));
+    HIP_TRY(c->d_keys.reserve(nh * sizeof(uint32_t)));
+    HIP_TRY(c->h_misc.reserve(nh * 7 + 2 * n_tables + nh * sizeof(uint32_t)));
+    uint8_t *hp = (uint8_t *)c->h_misc.p;
+    memcpy(hp, hands, nh * 7);
+    HIP_TRY(hipMemcpyAsync(c->d_hands.p, hp, nh * 7, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(mcq_launch_showdown((const uint8_t *)c->d_hands.p, (uint32_t)n_tables, (uint32_t)n_players, c->d_luts,
+                                (uint8_t *)c->d_win.p, (uint8_t *)c->d_wt.p, (uint32_t *)c->d_keys.p, c->stream));
+    uint8_t *hw = hp + nh * 7, *ht = hw + n_tables;
+    HIP_TRY(hipMemcpyAsync(hw, c->d_win.p, n_tables, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(ht, c->d_wt.p, n_tables, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(winner, hw, n_tables);
+    memcpy(winner_type, ht, n_tables);
+    if (keys) HIP_TRY(hipMemcpy(keys, c->d_keys.p, nh * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return MCQ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,91 @@
+// mcq_replay.hpp -- host half of MCQ_MODE_REPLAY_MT19937.
+//
+// The reference draws every random index from numpy's legacy global RandomState: one serial MT19937 stream
+// whose consumption is data dependent (masked rejection inside randint, re-draw when r1 == r2).  To make the
+// GPU tallies bit-exact against tools/montecarlo_python.py under np.random.seed(s), the host walks that stream
+// once per query and hands the kernel the ACCEPTED draw values (one byte each, draw-major); the deal ->
+// evaluate -> tally work stays on the GPU.  Rejected pairs only show up in `passes`, which is counted here.
+//
+//   numpy 1.26.4 legacy seeding      init_genrand(s)                 -> McqMt19937::seed
+//   numpy legacy randint(0, n)       masked rejection, 1 word/trial  -> mcq_np_randint
+//   montecarlo_python.py:165-176     opponent pair loop              -> mcq_replay_parse
+//   montecarlo_python.py:185-189     table draws randint(0, len-1)   -> mcq_replay_parse
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/mcq.h"
+
+struct McqMt19937 {
+    uint32_t mt[624];
+    uint32_t pos;
+
+    void seed(uint32_t s) {
+        mt[0] = s;
+        for (uint32_t i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + i;
+        pos = 624;
+    }
+    static uint32_t twist(uint32_t u, uint32_t v) {
+        uint32_t y = (u & 0x80000000u) | (v & 0x7fffffffu);
+        return (y >> 1) ^ ((0u - (v & 1u)) & 0x9908b0dfu);
+    }
+    void regenerate() {
+        uint32_t k = 0;
+        for (; k < 624 - 397; k++) mt[k] = mt[k + 397] ^ twist(mt[k], mt[k + 1]);
+        for (; k < 623; k++) mt[k] = mt[k + 397 - 624] ^ twist(mt[k], mt[k + 1]);
+        mt[623] = mt[396] ^ twist(mt[623], mt[0]);
+        pos = 0;
+    }
+    uint32_t next() {
+        if (pos >= 624) regenerate();
+        uint32_t y = mt[pos++];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        return y ^ (y >> 18);
+    }
+};
+
+static inline uint32_t mcq_np_randint(McqMt19937 &g, uint32_t n) { /* value in [0, n-1] */
+    uint32_t rng = n - 1;
+    if (rng == 0) return 0;
+    uint32_t mask = 0xFFFFFFFFu >> __builtin_clz(rng);
+    uint32_t v;
+    do v = g.next() & mask;
+    while (v > rng);
+    return v;
+}
+
+static inline uint32_t mcq_draws_per_iteration(const mcq_query &q) {
+    return 2u * (q.n_players - 1u) + (5u - q.n_board);
+}
+
+// Fills draws[d * stride + it] for it < q.runs, d < mcq_draws_per_iteration(q); returns `passes`.
+static inline uint64_t mcq_replay_parse(const mcq_query &q, uint32_t seed32, uint8_t *draws, size_t stride) {
+    McqMt19937 g;
+    g.seed(seed32);
+    const uint32_t n_opp = q.n_players - 1u, n_deal = 5u - q.n_board;
+    uint64_t passes = 0;
+    for (uint32_t it = 0; it < q.runs; it++) {
+        uint32_t L = 50u - q.n_board;
+        uint8_t *p = draws + it;
+        for (uint32_t o = 0; o < n_opp; o++) {
+            uint32_t r1, r2;
+            do {
+                passes++;
+                r1 = mcq_np_randint(g, L);
+                r2 = mcq_np_randint(g, L - 1);
+            } while (r1 == r2);
+            p[0] = (uint8_t)r1;
+            p[stride] = (uint8_t)r2;
+            p += 2 * stride;
+            L -= 2;
+        }
+        for (uint32_t k = 0; k < n_deal; k++) {
+            p[0] = (uint8_t)mcq_np_randint(g, L - 1);
+            p += stride;
+            L -= 1;
+        }
+    }
+    return passes;
+}

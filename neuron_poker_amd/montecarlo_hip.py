@@ -1,0 +1,148 @@
+"""Drop-in for tools/montecarlo_python.py of neuron_poker, computed on an MI355X.
+
+Same call surface, same meaning of the arguments, same attributes afterwards
+(reference: tools/montecarlo_python.py:191-252 and :401-406):
+
+    get_equity(player_cards, table_cards, players, runs) -> float
+    MonteCarlo().run_montecarlo(original_player_card_list, original_table_card_list, player_amount, ui,
+                                maxRuns, timeout, ghost_cards, opponent_range=1) -> (equity, winTypesDict)
+        then .equity .winnerCardTypeList .winTypesDict .runs .passes
+
+so `HoldemTable.get_equity = montecarlo_hip.get_equity` (gym_env/env.py:75-81) is the whole integration.
+New and additive: get_equity_batch() evaluates many states in one launch.
+
+Deliberate differences:
+  * exactly `runs` iterations are executed; the reference's 1 s wall-clock cut-off (montecarlo_python.py:235,
+    :405) is not reproduced, `timeout` and `ui` are accepted and ignored;
+  * the library never touches numpy's global random state.  seed(s) makes results reproducible; in
+    mode 'replay' a call after seed(s) returns exactly what the reference returns after np.random.seed(s);
+  * a hero card that is also on the table is rejected with ValueError (the reference silently swallows it,
+    montecarlo_python.py:154-161);
+  * opponent ranges, hero ranges, ghost cards and several known hands are not on this path yet
+    (SURVEY.md 8f-2): they raise NotImplementedError instead of returning something else.
+"""
+import os
+import threading
+from collections import Counter
+
+import numpy as np
+
+from . import _lib
+from .cards import TYPES, card_id
+
+__all__ = ["get_equity", "get_equity_batch", "MonteCarlo", "seed", "configure"]
+
+_state = {"seed": int.from_bytes(os.urandom(8), "little"), "counter": 0,
+          "mode": _lib.MODE_REPLAY_MT19937 if os.environ.get("MCQ_MODE", "philox").lower() == "replay"
+          else _lib.MODE_PHILOX}
+_lock = threading.Lock()
+_MODES = {"philox": _lib.MODE_PHILOX, "replay": _lib.MODE_REPLAY_MT19937,
+          _lib.MODE_PHILOX: _lib.MODE_PHILOX, _lib.MODE_REPLAY_MT19937: _lib.MODE_REPLAY_MT19937}
+
+
+def seed(s):
+    """Counterpart of np.random.seed(s) for this module: the next call uses stream `s`."""
+    with _lock:
+        _state["seed"] = int(s) & (2 ** 64 - 1)
+        _state["counter"] = 0
+
+
+def configure(mode=None):
+    """mode: 'philox' (default, production) or 'replay' (bit-exact MT19937 replay of the reference)."""
+    if mode is not None:
+        if mode not in _MODES:
+            raise ValueError("mode must be 'philox' or 'replay'")
+        _state["mode"] = _MODES[mode]
+
+
+def _take_ids(n):
+    with _lock:
+        first = _state["counter"]
+        _state["counter"] += n
+        return _state["seed"], first
+
+
+def _query(player_cards, table_cards, players, runs):
+    hole = [card_id(c) for c in player_cards]
+    board = [card_id(c) for c in table_cards]
+    if len(hole) != 2:
+        raise ValueError("player_cards must hold exactly two cards")
+    if len(board) > 5:
+        raise ValueError("table_cards holds more than five cards")
+    players = int(players)
+    runs = int(runs)
+    if runs < 1:
+        raise ValueError("runs must be >= 1")
+    return _lib.pack_queries([hole], [board + [255] * (5 - len(board))], players, runs)
+
+
+class MonteCarlo(object):
+    """Mirror of tools/montecarlo_python.py:22 MonteCarlo for the path gym_env/env.py uses."""
+
+    def __init__(self, engine=None):
+        self._engine = engine
+        self.equity = None
+        self.winnerCardTypeList = Counter()
+        self.winTypesDict = self.winnerCardTypeList.items()
+        self.runs = 0
+        self.passes = 0
+        self.result = None
+
+    def run_montecarlo(self, original_player_card_list, original_table_card_list, player_amount, ui, maxRuns,
+                       timeout, ghost_cards, opponent_range=1, *, mode=None, seed=None):
+        if ghost_cards != '' and ghost_cards is not None:
+            raise NotImplementedError("ghost_cards are not on the HIP path yet (SURVEY.md 8f-2)")
+        if not (isinstance(opponent_range, (int, float)) and float(opponent_range) >= 1.0):
+            raise NotImplementedError("opponent_range < 1 / explicit ranges are not on the HIP path yet "
+                                      "(SURVEY.md 8f-2)")
+        if len(original_player_card_list) != 1 or isinstance(original_player_card_list[0], (set, frozenset)):
+            raise NotImplementedError("only one known hand given as two cards is on the HIP path "
+                                      "(hero ranges / collusion hands: SURVEY.md 8f-2)")
+        q = _query(list(original_player_card_list[0]), list(original_table_card_list), player_amount, maxRuns)
+        eng = self._engine or _lib.default_engine()
+        m = _state["mode"] if mode is None else _MODES[mode]
+        if seed is None:
+            s, first = _take_ids(1)
+        else:
+            s, first = int(seed), 0
+        res = eng.eval_batch(q, s, first_query_id=first, mode=m)[0]
+        runs = int(res["runs"])
+        wins = int(res["win"]) + int(res["tie"])
+        self.result = res
+        self.equity = wins / runs                                   # montecarlo_python.py:243
+        self.winnerCardTypeList = Counter({TYPES[t]: int(c) / runs   # :244-246
+                                           for t, c in enumerate(res["by_type"]) if c})
+        self.winTypesDict = self.winnerCardTypeList.items()          # :248
+        self.runs = runs                                             # :249
+        self.passes = int(res["passes"])                             # :250
+        return self.equity, self.winTypesDict
+
+
+def get_equity(player_cards, table_cards, players, runs):
+    """Get equity from a Monte-Carlo run -- tools/montecarlo_python.py:401-406, on the GPU."""
+    simulation = MonteCarlo()
+    simulation.run_montecarlo([list(player_cards)], list(table_cards), players, 1, maxRuns=runs, timeout=0,
+                              ghost_cards='', opponent_range=1)
+    return simulation.equity
+
+
+def get_equity_batch(hole, board, n_players, runs, seed=None, first_query_id=0, mode=None, engine=None):
+    """Many states in one launch.
+
+    hole [B,2] u8 card ids, board [B,5] u8 (0xFF = empty), n_players scalar or [B], runs scalar or [B].
+    -> (equity[B] float64, tallies[B,13] uint64) with tally columns runs, passes, win, tie, by_type[9].
+    Query i gets query id first_query_id + i: splitting a batch keeps every per-query tally identical.
+    """
+    q = _lib.pack_queries(hole, board, n_players, runs)
+    eng = engine or _lib.default_engine()
+    m = _state["mode"] if mode is None else _MODES[mode]
+    if seed is None:
+        s, base = _take_ids(len(q))
+        first_query_id = base + first_query_id
+    else:
+        s = int(seed)
+    res = eng.eval_batch(q, s, first_query_id=first_query_id, mode=m)
+    tallies = res.view(np.uint64).reshape(len(q), 13)
+    runs_f = np.maximum(tallies[:, 0], 1).astype(np.float64)
+    equity = (tallies[:, 2] + tallies[:, 3]).astype(np.float64) / runs_f
+    return equity, tallies

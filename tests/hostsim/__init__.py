@@ -1,0 +1,72 @@
+"""Test-only host build of the product's lane arithmetic (see hostsim.cpp)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libmcq_hostsim.so")
+_SRCS = [os.path.join(_HERE, "hostsim.cpp"),
+         os.path.join(_HERE, "..", "..", "neuron_poker_amd", "csrc", "mcq_device.hpp"),
+         os.path.join(_HERE, "..", "..", "neuron_poker_amd", "csrc", "mcq_replay.hpp"),
+         os.path.join(_HERE, "..", "..", "include", "mcq.h")]
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in _SRCS):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-shared", "-fPIC", "-o", _SO, _SRCS[0]])
+        L = C.CDLL(_SO)
+        L.hs_select_pop.restype = C.c_uint32
+        _lib = L
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def eval7(cards):
+    cards = np.ascontiguousarray(cards, np.uint8).reshape(-1, 7)
+    keys = np.zeros(len(cards), np.uint32)
+    lib().hs_eval7(_p(cards, C.c_uint8), C.c_size_t(len(cards)), _p(keys, C.c_uint32))
+    return keys
+
+
+def run_ctr(query16, seed, qid):
+    q = np.ascontiguousarray(query16, np.uint8)
+    out = np.zeros(13, np.uint64)
+    rc = lib().hs_run_ctr(_p(q, C.c_uint8), C.c_uint64(seed), C.c_uint64(qid), _p(out, C.c_uint64))
+    if rc:
+        raise ValueError(rc)
+    return out
+
+
+def run_replay(query16, seed32):
+    q = np.ascontiguousarray(query16, np.uint8)
+    out = np.zeros(13, np.uint64)
+    rc = lib().hs_run_replay(_p(q, C.c_uint8), C.c_uint32(seed32), _p(out, C.c_uint64))
+    if rc:
+        raise ValueError(rc)
+    return out
+
+
+def select_pop(dlo, dhi, k):
+    a, b = C.c_uint32(dlo), C.c_uint32(dhi)
+    pos = lib().hs_select_pop(C.byref(a), C.byref(b), C.c_uint32(k))
+    return pos, a.value, b.value
+
+
+def mt_words(seed, n):
+    out = np.zeros(n, np.uint32)
+    lib().hs_mt_words(C.c_uint32(seed), C.c_uint32(n), _p(out, C.c_uint32))
+    return out
+
+
+def philox(ctr, key):
+    c, k, o = np.array(ctr, np.uint32), np.array(key, np.uint32), np.zeros(4, np.uint32)
+    lib().hs_philox(_p(c, C.c_uint32), _p(k, C.c_uint32), _p(o, C.c_uint32))
+    return o

@@ -1,0 +1,109 @@
+// hostsim.cpp -- TEST HARNESS ONLY (built and loaded by tests/, never by the product).
+//
+// Compiles the product's per-lane arithmetic (neuron_poker_amd/csrc/mcq_device.hpp, mcq_replay.hpp) for the
+// HOST compiler and walks the kernels' task/lane decomposition sequentially, so that the lane code can be
+// checked against the oracle and the golden fixtures in a container that has no GPU.  It is not a CPU
+// backend: libmcq_hip.so contains none of this and fails loudly without a GPU.
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../neuron_poker_amd/csrc/mcq_device.hpp"
+#include "../../neuron_poker_amd/csrc/mcq_replay.hpp"
+
+namespace {
+struct ArrayStore {
+    uint32_t lo[MCQ_MAX_OPP], hi[MCQ_MAX_OPP];
+    void put(uint32_t p, uint32_t l, uint32_t h) { lo[p] = l; hi[p] = h; }
+    void get(uint32_t p, uint32_t &l, uint32_t &h) { l = lo[p]; h = hi[p]; }
+};
+McqLuts g_luts;
+bool g_init = false;
+const McqLuts &luts() {
+    if (!g_init) { mcq_fill_luts(&g_luts); g_init = true; }
+    return g_luts;
+}
+void fold(const McqLaneAcc &a, mcq_result *r) {
+    uint64_t wins = 0;
+    for (int t = 0; t < 9; t++) {
+        uint64_t v = (a.types >> (6 * t)) & 63;
+        r->by_type[t] += v;
+        wins += v;
+    }
+    r->tie += a.tie;
+    r->win += wins - a.tie;
+    r->passes += a.passes;
+}
+}  // namespace
+
+extern "C" {
+
+int hs_query_valid(const mcq_query *q) { return mcq_query_valid(mcq_query_words(*q)) ? 1 : 0; }
+
+void hs_eval7(const uint8_t *cards, size_t n, uint32_t *keys) {
+    const McqLuts &t = luts();
+    for (size_t i = 0; i < n; i++) {
+        uint32_t lo = 0, hi = 0;
+        for (int k = 0; k < 7; k++) { lo |= t.suit_lo[cards[7 * i + k]]; hi |= t.suit_hi[cards[7 * i + k]]; }
+        keys[i] = mcq_eval7(lo, hi);
+    }
+}
+
+uint32_t hs_select_pop(uint32_t *dlo, uint32_t *dhi, uint32_t k) { return mcq_select_pop(*dlo, *dhi, k, luts().sel8); }
+
+void hs_philox(const uint32_t *ctr, const uint32_t *key, uint32_t *out) {
+    mcq_philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
+}
+
+// production mode, lane/stream decomposition exactly as the kernel: lane <-> stream of 16 iterations
+int hs_run_ctr(const mcq_query *q, uint64_t seed, uint64_t qid, mcq_result *out) {
+    if (!mcq_query_valid(mcq_query_words(*q))) return MCQ_EINVAL;
+    const McqLuts &t = luts();
+    McqQueryCtx qc;
+    mcq_query_ctx(mcq_query_words(*q), t.suit_lo, t.suit_hi, qc);
+    memset(out, 0, sizeof(*out));
+    out->runs = q->runs;
+    uint32_t n_streams = (q->runs + MCQ_STREAM_ITERS - 1) / MCQ_STREAM_ITERS;
+    for (uint32_t s = 0; s < n_streams; s++) {
+        McqCtrDraws dr;
+        dr.rng.seed(seed, qid, s);
+        McqLaneAcc acc = {0, 0, 0};
+        ArrayStore st;
+        for (uint32_t j = 0; j < MCQ_STREAM_ITERS; j++) {
+            if ((uint64_t)s * MCQ_STREAM_ITERS + j >= q->runs) break;
+            mcq_iteration(qc, dr, t.sel8, t.suit_lo, t.suit_hi, st, acc);
+        }
+        fold(acc, out);
+    }
+    return MCQ_OK;
+}
+
+// parity mode: host parse of the MT19937 stream + the same lane arithmetic
+int hs_run_replay(const mcq_query *q, uint32_t seed32, mcq_result *out) {
+    if (!mcq_query_valid(mcq_query_words(*q))) return MCQ_EINVAL;
+    const McqLuts &t = luts();
+    McqQueryCtx qc;
+    mcq_query_ctx(mcq_query_words(*q), t.suit_lo, t.suit_hi, qc);
+    memset(out, 0, sizeof(*out));
+    out->runs = q->runs;
+    size_t stride = q->runs ? q->runs : 1;
+    std::vector<uint8_t> draws((size_t)mcq_draws_per_iteration(*q) * stride + 1);
+    out->passes = mcq_replay_parse(*q, seed32, draws.data(), stride);
+    for (uint32_t it = 0; it < q->runs; it++) {
+        McqReplayDraws dr = {draws.data() + it, stride};
+        McqLaneAcc acc = {0, 0, 0};
+        ArrayStore st;
+        mcq_iteration(qc, dr, t.sel8, t.suit_lo, t.suit_hi, st, acc);
+        acc.passes = 0;
+        fold(acc, out);
+    }
+    return MCQ_OK;
+}
+
+void hs_mt_words(uint32_t seed, uint32_t n, uint32_t *out) {
+    McqMt19937 g;
+    g.seed(seed);
+    for (uint32_t i = 0; i < n; i++) out[i] = g.next();
+}
+}

@@ -1,0 +1,63 @@
+"""The C-ABI shared library loads and exports every symbol include/mcq.h declares; record layouts match the
+header.  No compute calls here (no GPU needed)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import neuron_poker_amd as npa
+from neuron_poker_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header():
+    with open(os.path.join(ROOT, "include", "mcq.h")) as f:
+        return f.read()
+
+
+def test_library_exports_every_declared_symbol():
+    from neuron_poker_amd import build
+    build.build()
+    L = npa.load_library()
+    names = re.findall(r"MCQ_API\s+[\w\s\*]+?\b(mcq_\w+)\s*\(", header())
+    assert set(names) >= {"mcq_create", "mcq_destroy", "mcq_eval_batch", "mcq_eval_one", "mcq_eval_batch_device",
+                          "mcq_showdown", "mcq_last_error", "mcq_version", "mcq_device_count", "mcq_last_kernel_ms"}
+    for n in names:
+        assert hasattr(L, n), n
+
+
+def test_version_matches_header():
+    L = npa.load_library()
+    a, b, c = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+    L.mcq_version(C.byref(a), C.byref(b), C.byref(c))
+    h = header()
+    exp = tuple(int(re.search(r"#define MCQ_VERSION_%s (\d+)" % k, h).group(1)) for k in ("MAJOR", "MINOR", "PATCH"))
+    assert (a.value, b.value, c.value) == exp
+
+
+def test_record_layouts():
+    assert _lib.QUERY_DTYPE.itemsize == 16 and _lib.RESULT_DTYPE.itemsize == 104
+    assert _lib.QUERY_DTYPE.fields["runs"][1] == 12 and _lib.QUERY_DTYPE.fields["n_players"][1] == 8
+    q = npa.pack_queries([[50, 46]], [[255, 3, 255, 9, 255]], 6, 1000)
+    assert q["n_board"][0] == 2 and list(q["board"][0]) == [3, 9, 0, 0, 0] and q["runs"][0] == 1000
+    assert list(q.view(np.uint8)[:9]) == [50, 46, 3, 9, 0, 0, 0, 2, 6]
+
+
+def test_no_cpu_fallback_without_gpu():
+    L = npa.load_library()
+    if L.mcq_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(npa.McqError):
+        npa.Engine(0)
+    assert b"no HIP device" in L.mcq_last_error()
+
+
+def test_card_notation():
+    assert npa.card_id("2C") == 0 and npa.card_id("AS") == 51 and npa.card_id("AH") == 50 and npa.card_id("KH") == 46
+    assert [npa.card_str(i) for i in (0, 1, 2, 3, 4, 51)] == ["2C", "2D", "2H", "2S", "3C", "AS"]
+    for bad in ("ah", "1H", "AHH", "", 5):
+        with pytest.raises(ValueError):
+            npa.card_id(bad)

@@ -1,0 +1,265 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the oracle and the golden fixtures.
+
+Bar (integer work): bit-exact.  The only floating-point number on the path is wins / runs.
+  * parity mode (MT19937 replay)  == the reference's own tallies under np.random.seed (tests/golden/tallies.json)
+  * production mode (MCQ-CTR v1)  == the oracle's CTR mode, query by query
+  * evaluator                     == the reference's _calc_score ordering on the golden hands / showdowns
+  * full-size configs             -> size-independent properties (sum of types, shard invariance, exact
+                                     expectation from exhaustive enumeration)
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import neuron_poker_amd as npa
+from neuron_poker_amd import montecarlo_hip as mh
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = npa.Engine(0)
+    yield e
+    e.close()
+
+
+def jload(name):
+    with open(os.path.join(G, name)) as f:
+        return json.load(f)
+
+
+def mkq(hero, board, n, runs):
+    b = [npa.card_id(c) for c in board] + [255] * (5 - len(board))
+    return npa.pack_queries([[npa.card_id(hero[0]), npa.card_id(hero[1])]], [b], n, runs)
+
+
+def u64(res):
+    return res.view(np.uint64).reshape(-1, 13)
+
+
+# ------------------------------------------------------------------------------------------ evaluator
+def test_keys_reproduce_reference_categories_and_order(eng):
+    z = np.load(os.path.join(G, "evaluator_hands.npz"))
+    cards, cat, nr, ranks = z["cards"], z["category"], z["n_ranks"], z["card_ranks"]
+    _, _, keys = eng.showdown(cards.reshape(-1, 1, 7), want_keys=True)
+    keys = keys.reshape(-1)
+    assert np.array_equal(keys >> 28, cat)
+    tup = [(int(cat[i]), tuple(int(x) for x in ranks[i, :nr[i]])) for i in range(len(cards))]
+    order = np.argsort(keys, kind="stable")
+    for a, b in zip(order[:-1], order[1:]):
+        assert (tup[a] == tup[b]) if keys[a] == keys[b] else (tup[a] < tup[b]), (cards[a], cards[b])
+
+
+def test_showdown_winners_match_reference(eng):
+    z = np.load(os.path.join(G, "showdowns.npz"))
+    hands, n, win, wt = z["hands"], z["n_players"], z["winner"], z["winner_type"]
+    for p in range(2, 11):
+        sel = np.nonzero(n == p)[0]
+        if len(sel) == 0:
+            continue
+        w, t = eng.showdown(hands[sel, :p])
+        assert np.array_equal(w, win[sel]) and np.array_equal(t, wt[sel]), p
+
+
+def test_reference_evaluator_cases(eng):
+    for c in jload("evaluator_cases.json"):
+        ids = [[npa.card_id(x) for x in h] for h in c["hands"]]
+        if any(len(set(h)) != 7 for h in ids):
+            with pytest.raises(ValueError):  # duplicate cards (tests/test_evaluator.py:27,63): outside the domain
+                eng.showdown(np.array([ids], np.uint8))
+            continue
+        w, t = eng.showdown(np.array([ids], np.uint8))
+        assert w[0] == c["winner"] and npa.TYPES[t[0]] == c["winner_type"], c
+
+
+# ------------------------------------------------------------------------------------------ parity mode
+def test_replay_reproduces_reference_tallies_bit_exact(eng):
+    rows = jload("tallies.json")
+    for t in rows:
+        r = eng.eval_batch(mkq(t["hero"], t["board"], t["n_players"], t["runs"]), seed=t["seed"],
+                           mode=npa.MODE_REPLAY_MT19937)[0]
+        assert int(r["runs"]) == t["runs"]
+        assert int(r["win"] + r["tie"]) == t["wins"], t
+        assert int(r["passes"]) == t["passes"], t
+        assert [int(x) for x in r["by_type"]] == t["by_type"], t
+
+
+def test_replay_batch_equals_oracle_mt_per_query(eng):
+    g = np.random.default_rng(11)
+    B = 96
+    hole, board, npl, runs = [], [], [], []
+    for i in range(B):
+        nb = [0, 3, 4, 5][i % 4]
+        cards = g.choice(52, 2 + nb, replace=False)
+        hole.append(cards[:2])
+        board.append(list(cards[2:]) + [255] * (5 - nb))
+        npl.append(1 + i % 10)
+        runs.append(int(g.integers(1, 3000)))
+    q = npa.pack_queries(hole, board, npl, runs)
+    got = u64(eng.eval_batch(q, seed=1234, first_query_id=7, mode=npa.MODE_REPLAY_MT19937))
+    exp = O.run_batch(O.MODE_MT, q.view(np.uint8).reshape(-1, 16), 1234, 7, threads=4)
+    assert np.array_equal(got, exp)
+
+
+# ------------------------------------------------------------------------------------------ production mode
+def test_philox_equals_oracle_ctr_bit_exact(eng):
+    g = np.random.default_rng(5)
+    B = 200
+    hole, board, npl, runs = [], [], [], []
+    for i in range(B):
+        nb = [0, 3, 4, 5][i % 4]
+        cards = g.choice(52, 2 + nb, replace=False)
+        hole.append(cards[:2])
+        board.append(list(cards[2:]) + [255] * (5 - nb))
+        npl.append(1 + (i * 7) % 10)
+        runs.append(int(g.choice([1, 15, 16, 17, 1000, 1023, 1024, 1025, 4097])))
+    q = npa.pack_queries(hole, board, npl, runs)
+    for seed, first in [(0, 0), (0xDEADBEEF12345678, 2 ** 33 + 5)]:
+        got = u64(eng.eval_batch(q, seed=seed, first_query_id=first, mode=npa.MODE_PHILOX))
+        exp = O.run_batch(O.MODE_CTR, q.view(np.uint8).reshape(-1, 16), seed, first, threads=4)
+        assert np.array_equal(got, exp)
+
+
+def test_config2_single_query_100k(eng):
+    """BASELINE configs[1]: AhKh, empty board, 1 opponent, 100k iterations."""
+    q = mkq(["AH", "KH"], [], 2, 100000)
+    for seed, wins, passes in [(0, 65807, 102091), (1, 65985, 102097)]:  # reference, SURVEY.md 8c F3
+        r = eng.eval_batch(q, seed=seed, mode=npa.MODE_REPLAY_MT19937)[0]
+        assert (int(r["win"] + r["tie"]), int(r["passes"])) == (wins, passes)
+    got = u64(eng.eval_batch(q, seed=3, mode=npa.MODE_PHILOX))
+    exp = O.run_batch(O.MODE_CTR, q.view(np.uint8).reshape(-1, 16), 3, 0)
+    assert np.array_equal(got, exp)
+    # production front end vs the reference's seeded equities: both estimate the same expectation
+    eq = (got[0, 2] + got[0, 3]) / 1e5
+    assert abs(eq - 0.65807) < 6e-3 and abs(eq - 0.65985) < 6e-3  # 4 sigma of the difference at 100k
+
+
+def test_shard_invariance_and_device_entry(eng):
+    """Splitting a batch (other ranks / other calls) never changes a per-query tally."""
+    g = np.random.default_rng(4096)
+    B = 512
+    hole = np.array([g.choice(52, 2, replace=False) for _ in range(B)], np.uint8)
+    q = npa.pack_queries(hole, np.full((B, 5), 255, np.uint8), 3, 5000)
+    whole = u64(eng.eval_batch(q, seed=1, first_query_id=0))
+    parts = [u64(eng.eval_batch(q[a:a + 128], seed=1, first_query_id=a)) for a in range(0, B, 128)]
+    assert np.array_equal(whole, np.concatenate(parts))
+    torch = pytest.importorskip("torch")
+    dq = torch.from_numpy(q.view(np.uint8).reshape(B, 16).copy()).cuda()
+    dres = torch.empty((B, 13), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    eng.eval_batch_device(dq.data_ptr(), B, 1, dres.data_ptr(), first_query_id=0,
+                          stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(dres.cpu().numpy().view(np.uint64), whole)
+
+
+def test_config3_full_size_properties(eng):
+    """BASELINE configs[2]: 4096 random preflop states, 2 opponents, 50k iterations each."""
+    g = np.random.default_rng(4096)
+    hole = np.array([g.choice(52, 2, replace=False) for _ in range(4096)], np.uint8)
+    q = npa.pack_queries(hole, np.full((4096, 5), 255, np.uint8), 3, 50000)
+    t = u64(eng.eval_batch(q, seed=1))
+    assert (t[:, 0] == 50000).all()
+    assert np.array_equal(t[:, 2] + t[:, 3], t[:, 4:].sum(1))          # reference: sum(types) == equity
+    assert (t[:, 1] >= 2 * 50000).all() and (t[:, 1] < 2.2 * 50000).all()  # passes ~ runs * opponents * (1 + 1/L)
+    eq = (t[:, 2] + t[:, 3]) / 50000.0
+    # 64 of the queries checked bit-for-bit against the oracle
+    idx = np.arange(0, 4096, 64)
+    exp = np.stack([O.run_batch(O.MODE_CTR, q[i:i + 1].view(np.uint8).reshape(-1, 16), 1, int(i))[0] for i in idx])
+    assert np.array_equal(t[idx], exp)
+    # suit isomorphism: states with the same ranks / suitedness have the same expectation (6 sigma)
+    cls = {}
+    for i in range(4096):
+        a, b = sorted((int(hole[i, 0]) >> 2, int(hole[i, 1]) >> 2))
+        cls.setdefault((a, b, (hole[i, 0] & 3) == (hole[i, 1] & 3)), []).append(eq[i])
+    # the reference's dealing is order-biased, so classes agree only to ~1 point; this guards gross errors
+    assert max(max(v) - min(v) for v in cls.values()) < 0.05
+
+
+def test_philox_converges_to_exact_expectation(eng):
+    """The production RNG front end follows the REFERENCE'S dealing law: at 4e8 iterations the estimate sits
+    within 5 sigma (~1.2e-4) of the exact expectation obtained by exhaustive enumeration of that law."""
+    for hero, board, n in [(["TC", "TH"], ["4D", "QD", "KC", "2S"], 2), (["3S", "QH"], ["2C", "5H", "7C"], 2),
+                           (["JD", "JS"], ["8C", "TC", "JC", "5H", "QC"], 3)]:
+        w, t, _ = O.exact(hero, board, n)
+        p = w + t
+        B, runs = 100, 4000000
+        q = np.repeat(mkq(hero, board, n, runs), B)
+        r = u64(eng.eval_batch(q, seed=99))
+        total = float(r[:, 0].sum())
+        est = float((r[:, 2] + r[:, 3]).sum()) / total
+        est_tie = float(r[:, 3].sum()) / total
+        assert abs(est - p) < 5 * (p * (1 - p) / total) ** 0.5 + 1e-9, (hero, est, p)
+        assert abs(est_tie - t) < 5 * (max(t, 1e-9) / total) ** 0.5 + 1e-9, (hero, est_tie, t)
+        assert abs(est - p) <= 1e-4
+
+
+def test_statistical_expectations_of_reference_tests(eng):
+    rows = jload("stat_expectations.json")
+    hole = [[npa.card_id(c) for c in r["hero"]] for r in rows]
+    board = [[npa.card_id(c) for c in r["board"]] + [255] * (5 - len(r["board"])) for r in rows]
+    eq, _ = mh.get_equity_batch(hole, board, [r["n_players"] for r in rows], 200000, seed=7, engine=eng)
+    for r, e in zip(rows, eq):
+        assert abs(100 * e - r["expected_pct"]) < r["tol_pct"], (r, e)
+
+
+# ------------------------------------------------------------------------------------------ edges and errors
+def test_single_player_zero_board_and_small_runs(eng):
+    r = eng.eval_batch(mkq(["7H", "2C"], [], 1, 3000), seed=9, mode=npa.MODE_REPLAY_MT19937)[0]
+    assert (int(r["win"]), int(r["tie"]), int(r["passes"])) == (3000, 0, 0)
+    for runs in (1, 2, 63, 64, 65):
+        q = mkq(["AS", "AC"], ["2C", "2D", "2H"], 10, runs)
+        got = u64(eng.eval_batch(q, seed=5))
+        assert np.array_equal(got, O.run_batch(O.MODE_CTR, q.view(np.uint8).reshape(-1, 16), 5, 0))
+    assert len(eng.eval_batch(npa.pack_queries(np.zeros((0, 2)), np.zeros((0, 5)), 2, 10), seed=0)) == 0
+
+
+def test_invalid_queries_raise_value_error(eng):
+    good = mkq(["AH", "KH"], [], 2, 100)
+    for bad in [mkq(["AH", "KH"], ["AH", "2C", "3C"], 2, 100),   # hero card on the table
+                mkq(["AH", "KH"], ["2C", "2C", "3C"], 2, 100),   # duplicate table card
+                mkq(["AH", "KH"], [], 11, 100), mkq(["AH", "KH"], [], 0, 100)]:
+        with pytest.raises(ValueError):
+            eng.eval_batch(np.concatenate([good, bad]), seed=0)
+    q = good.copy()
+    q["hole"][0, 0] = 52
+    with pytest.raises(ValueError):
+        eng.eval_batch(q, seed=0)
+    with pytest.raises(ValueError):
+        eng.eval_batch(good, seed=0, mode=7)
+
+
+# ------------------------------------------------------------------------------------------ drop-in surface
+def test_dropin_module_matches_reference_call_surface(eng):
+    mh.configure(mode="replay")
+    try:
+        mh.seed(0)
+        sim = mh.MonteCarlo(eng)
+        eq, types = sim.run_montecarlo([["AH", "KH"]], [], 2, 1, maxRuns=10000, timeout=0, ghost_cards="",
+                                       opponent_range=1)
+        # reference after np.random.seed(0): 6629 wins, 10213 passes (tests/golden/tallies.json row 0)
+        row = jload("tallies.json")[0]
+        assert (eq, sim.runs, sim.passes) == (row["wins"] / row["runs"], row["runs"], row["passes"])
+        assert dict(types) == {npa.TYPES[i]: c / row["runs"] for i, c in enumerate(row["by_type"]) if c}
+        assert abs(sum(sim.winnerCardTypeList.values()) - sim.equity) < 1e-4  # tests/test_montecarlo_python.py:32
+        mh.seed(1)
+        assert mh.get_equity({"AH", "KH"}, set(), np.int64(2), 10000) == 0.6529
+    finally:
+        mh.configure(mode="philox")
+    mh.seed(42)
+    a = mh.get_equity({"AS", "KS"}, set(), 2, 100000)
+    mh.seed(42)
+    assert mh.get_equity({"KS", "AS"}, set(), 2, 100000) == a
+    assert abs(100 * a - 66.0) < 1.0
+    with pytest.raises(ValueError):
+        mh.get_equity({"AS", "KS"}, {"AS", "2C", "3C"}, 2, 100)
+    with pytest.raises(ValueError):
+        mh.get_equity({"AS", "Kx"}, set(), 2, 100)
+    with pytest.raises(NotImplementedError):
+        mh.MonteCarlo(eng).run_montecarlo([["AS", "KS"]], [], 2, 1, maxRuns=10, timeout=0, ghost_cards="",
+                                          opponent_range=0.25)

@@ -1,0 +1,109 @@
+"""Host-compiled build of the product's lane arithmetic (mcq_device.hpp / mcq_replay.hpp) against the oracle
+and the golden fixtures.  This exercises the exact source the gfx950 kernels are built from; the GPU parity
+tests (tests/test_gpu_parity.py) repeat the comparisons through the C ABI on the device."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import hostsim as H
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def q16(hero, board, n, runs):
+    b = [255] * 5
+    for i, c in enumerate(board):
+        b[i] = O.card_id(c)
+    return O.pack_queries([[O.card_id(hero[0]), O.card_id(hero[1])]], [b], n, runs)[0]
+
+
+def test_select_pop_matches_list_pop():
+    g = np.random.default_rng(1)
+    for _ in range(300):
+        deck = sorted(g.choice(52, g.integers(2, 53), replace=False).tolist())
+        m = sum(1 << c for c in deck)
+        dlo, dhi = m & 0xffffffff, m >> 32
+        for _ in range(min(len(deck) - 1, 25)):
+            k = int(g.integers(0, len(deck)))
+            pos, dlo, dhi = H.select_pop(dlo, dhi, k)
+            assert pos == deck.pop(k)
+            assert dlo | dhi << 32 == sum(1 << c for c in deck)
+
+
+def test_key_category_matches_reference_fixture():
+    z = np.load(os.path.join(G, "evaluator_hands.npz"))
+    keys = H.eval7(z["cards"])
+    assert np.array_equal(keys >> 28, z["category"])
+
+
+def test_key_order_matches_reference_tuple_order():
+    # the 32-bit key must order hands exactly like Python orders _calc_score tuples
+    z = np.load(os.path.join(G, "evaluator_hands.npz"))
+    cards, cat, nr, ranks = z["cards"], z["category"], z["n_ranks"], z["card_ranks"]
+    keys = H.eval7(cards)
+    tup = [(int(cat[i]), tuple(int(x) for x in ranks[i, :nr[i]])) for i in range(len(cards))]
+    # category order == score order (hand_evaluator.py:83-115), so (category, card_ranks) is the reference order
+    g = np.random.default_rng(2)
+    order = np.argsort(keys, kind="stable")
+    for a, b in zip(order[:-1], order[1:]):  # adjacent in key order -> strongest test of the total order
+        if keys[a] == keys[b]:
+            assert tup[a] == tup[b], (cards[a], cards[b])
+        else:
+            assert tup[a] < tup[b], (cards[a], cards[b], tup[a], tup[b])
+    for _ in range(20000):
+        a, b = g.integers(0, len(cards), 2)
+        ka, kb = int(keys[a]), int(keys[b])
+        assert (ka > kb) - (ka < kb) == (tup[a] > tup[b]) - (tup[a] < tup[b])
+
+
+def test_showdowns_fixture_with_keys():
+    z = np.load(os.path.join(G, "showdowns.npz"))
+    hands, n, win, wt = z["hands"], z["n_players"], z["winner"], z["winner_type"]
+    for i in range(len(hands)):
+        k = H.eval7(hands[i, :n[i]])
+        w = int(np.argmax(k))  # first of the maxima
+        assert (w, k[w] >> 28) == (win[i], wt[i]), i
+
+
+def test_reference_evaluator_cases_without_duplicates():
+    with open(os.path.join(G, "evaluator_cases.json")) as f:
+        cases = json.load(f)
+    for c in cases:
+        ids = [[O.card_id(x) for x in h] for h in c["hands"]]
+        if any(len(set(h)) != 7 for h in ids):
+            continue  # duplicate cards (tests/test_evaluator.py:27,63) are outside the kernel's domain
+        k = H.eval7(ids)
+        w = int(np.argmax(k))
+        assert w == c["winner"] and O.TYPES[k[w] >> 28] == c["winner_type"], c
+
+
+def test_mt_and_philox_restated_identically():
+    assert np.array_equal(H.mt_words(12345, 3000), O.mt_words(12345, 3000))
+    assert list(H.philox([1, 2, 3, 4], [5, 6])) == list(O.philox4x32_10([1, 2, 3, 4], [5, 6]))
+
+
+def test_replay_mode_equals_reference_tallies():
+    with open(os.path.join(G, "tallies.json")) as f:
+        rows = json.load(f)
+    for t in rows:
+        if t["runs"] > 20000:
+            continue
+        r = H.run_replay(q16(t["hero"], t["board"], t["n_players"], t["runs"]), t["seed"] & 0xffffffff)
+        assert int(r[0]) == t["runs"] and int(r[1]) == t["passes"]
+        assert int(r[2] + r[3]) == t["wins"], t
+        assert [int(x) for x in r[4:]] == t["by_type"], t
+
+
+@pytest.mark.parametrize("hero,board,n,runs", [
+    (["AH", "KH"], [], 2, 5000), (["AH", "KH"], [], 6, 3001), (["2C", "7D"], ["AS", "KS", "QS"], 6, 2000),
+    (["TC", "TH"], ["4D", "QD", "KC", "2S"], 3, 4097), (["3H", "3S"], ["8S", "4S", "QH", "8C", "4H"], 10, 1000),
+    (["7H", "2C"], [], 1, 777), (["AS", "AC"], [], 10, 1500), (["9D", "9C"], ["9H"] * 0, 4, 15)])
+def test_ctr_mode_equals_oracle_ctr(hero, board, n, runs):
+    q = q16(hero, board, n, runs)
+    for seed, qid in [(0, 0), (0xDEADBEEFCAFE, 7), (2 ** 64 - 1, 2 ** 40 + 3)]:
+        got = H.run_ctr(q, seed, qid)
+        exp = O.run(O.MODE_CTR, hero, board, n, runs, seed, qid=qid)["tallies"]
+        assert np.array_equal(got, exp), (seed, qid, got, exp)
