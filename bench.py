@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X equity engine.
+
+Metric (BASELINE.json): Monte-Carlo 7-card hand evaluations per second @100k iterations, 6-max preflop.
+A "step" = one pass of the hot path (deal -> evaluate -> tally) over one batch of synthetic equity queries:
+4 096 random preflop states PER GPU (the batch size and state generator of BASELINE configs[2]), 6 players,
+no table cards, 100 000 iterations each = 2.4576e9 hand evaluations per GPU per step.  Queries and tallies
+are resident in HBM (torch tensors, device-pointer C-ABI entry mcq_eval_batch_device); with N > 1 ranks each
+rank evaluates its own shard and one RCCL all-reduce of the integer tally matrix closes the step (weak
+scaling: per-GPU work is fixed).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
+  roofline      VALU integer issue roofline of the evaluation kernel (this path is integer/branch work, neither
+                HBM- nor MFMA-bound: 120 B of HBM traffic per QUERY, none per iteration); `achieved` =
+                algorithmic int32 lane-ops per launch / mean kernel time from HIP events recorded on the
+                launch stream inside the timed region
+  cpu_baseline  the oracle (a C port of tools/montecarlo_python.py, bit-exact to it) timed on this host
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_VALU_TOPS = 256 * 4 * 2.4e9 * 32 / 1e12  # 256 CU x 4 SIMD-32 x 2.4 GHz full-rate int32 lane-ops
+HBM_PEAK_GBPS = 8000.0
+
+
+def alg_ops_per_iteration(n_players, n_board):
+    """SURVEY.md 8(d) canonical cost model: A(N, b) = 48 D + 30 + 82 N int32 lane-ops, D = 2(N-1) + (5-b)."""
+    d = 2 * (n_players - 1) + (5 - n_board)
+    return 48 * d + 30 + 82 * n_players
+
+
+def make_states(n_states, rank):
+    g = np.random.default_rng(4096 + rank)  # rank 0 == the generator of BASELINE configs[2]
+    hole = np.array([g.choice(52, 2, replace=False) for _ in range(n_states)], np.uint8)
+    board = np.full((n_states, 5), 255, np.uint8)
+    return hole, board
+
+
+def cpu_baseline(n_players, runs, seconds=12.0):
+    """Time the oracle (kind 'port') on this host's cores on a bounded sample of the same workload."""
+    from oracle import oracle as O
+    cores = max(1, len(os.sched_getaffinity(0)))
+    threads = min(cores, 64)
+    hole, board = make_states(threads, 0)
+    probe = O.pack_queries(hole, board, n_players, 20000)
+    t0 = time.perf_counter()
+    O.run_batch(O.MODE_MT, probe, 1, 0, threads=threads)
+    rate = threads * 20000 * n_players / max(time.perf_counter() - t0, 1e-3)  # evals/s estimate
+    iters = runs
+    n_states = int(min(4096, max(threads, threads * round(rate * seconds / (runs * n_players * threads)))))
+    hole, board = make_states(n_states, 0)
+    q = O.pack_queries(hole, board, n_players, iters)
+    t0 = time.perf_counter()
+    O.run_batch(O.MODE_MT, q, 1, 0, threads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": len(hole) * iters * n_players / dt, "unit": "hand-evals/s", "cores": threads, "kind": "port",
+            "sample": "%d of the workload's preflop states x %d iterations x %d players, oracle MT19937 mode "
+                      "(bit-exact to tools/montecarlo_python.py), %d threads, %.1f s" %
+                      (len(hole), iters, n_players, threads, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--states", type=int, default=4096, help="states per GPU")
+    ap.add_argument("--iters", type=int, default=100000)
+    ap.add_argument("--players", type=int, default=6)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import neuron_poker_amd as npa
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                             "--master-addr 127.0.0.1 bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        raise SystemExit("--gpus (%d) != WORLD_SIZE (%d)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    eng = npa.Engine(local_rank)
+    B, N, runs = args.states, args.players, args.iters
+    hole, board = make_states(B, rank)
+    q = npa.pack_queries(hole, board, N, runs)
+    d_q = torch.from_numpy(q.view(np.uint8).reshape(B, 16).copy()).to(dev)
+    tallies = torch.zeros((world * B, 13), dtype=torch.int64, device=dev)  # mcq_result rows of the whole job
+    mine = tallies[rank * B:(rank + 1) * B]
+    stream = torch.cuda.current_stream()
+    seed = 20261004
+
+    def step(i):
+        if world > 1:
+            tallies.zero_()
+        eng.eval_batch_device(d_q.data_ptr(), B, seed + i, mine.data_ptr(), first_query_id=rank * B,
+                              stream=stream.cuda_stream)
+        if world > 1:
+            dist.all_reduce(tallies, op=dist.ReduceOp.SUM)  # the path's one collective: integer tallies over xGMI
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    # sanity on the last step's tallies (cheap; outside the timed region)
+    t = tallies.cpu().numpy().view(np.uint64)
+    assert (t[:, 0] == runs).all(), "runs column wrong"
+    assert np.array_equal(t[:, 2] + t[:, 3], t[:, 4:].sum(1)), "sum(by_type) != win + tie"
+
+    kt = eng.kernel_times(min(args.steps, 64))  # HIP events on the launch stream, recorded inside the timed region
+    kernel_ms = float(np.mean(kt)) if len(kt) else float("nan")
+    evals_per_step = float(world) * B * runs * N
+    value = evals_per_step * args.steps / elapsed
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ops_per_launch = float(B) * runs * alg_ops_per_iteration(N, 0)
+    achieved = ops_per_launch / (kernel_ms * 1e-3) / 1e12
+    traffic = None
+    tp = os.path.join(ROOT, "profiles", "traffic.json")  # HBM bytes per launch from rocprofv3 --pmc passes
+    if os.path.exists(tp):
+        try:
+            with open(tp) as f:
+                tj = json.load(f)
+            if tj.get("states") == B and tj.get("iters") == runs and tj.get("players") == N:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except (OSError, ValueError):
+            traffic = None
+    out = {
+        "metric": "Monte Carlo hand evals/sec @100k iters, 6-max preflop", "value": value, "unit": "hand-evals/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": "%d random preflop states per GPU (default_rng(4096+rank), as BASELINE configs[2]) x "
+                               "%d players x %d iterations, production RNG (Philox-keyed xoshiro128++), queries and "
+                               "tallies resident in HBM%s" %
+                               (B, N, runs, ", one RCCL all-reduce of the [%d,13] int64 tally matrix per step" %
+                                (world * B) if world > 1 else ""),
+                   "states_per_gpu": B, "n_players": N, "iterations": runs, "n_board": 0,
+                   "hand_evals_per_step": evals_per_step},
+        "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_VALU_TOPS, "unit": "Tops/s (int32 lane-ops)",
+                     "frac": achieved / PEAK_VALU_TOPS, "traffic": traffic,
+                     "kernel": "mcq_eval_kernel<PHILOX>", "kernel_ms": kernel_ms,
+                     "alg_ops_per_iteration": alg_ops_per_iteration(N, 0),
+                     "hbm": {"algorithmic_bytes_per_launch": B * 120,
+                             "achieved_GBps": B * 120 / (kernel_ms * 1e-3) / 1e9, "peak_GBps": HBM_PEAK_GBPS}},
+    }
+    if not args.no_extras:
+        extras = {}
+        # BASELINE configs[1]: single query AhKh heads-up 100k iterations (latency-bound: 98 wave tasks)
+        q1 = npa.pack_queries([[npa.card_id("AH"), npa.card_id("KH")]], [[255] * 5], 2, 100000)
+        for _ in range(3):
+            eng.eval_batch(q1, seed=1)
+        t1 = time.perf_counter()
+        for i in range(20):
+            eng.eval_batch(q1, seed=i)
+        dt = (time.perf_counter() - t1) / 20
+        extras["configs[1]_single_query_100k"] = {"call_ms_host_buffers": 1e3 * dt, "kernel_ms": eng.last_kernel_ms,
+                                                 "hand_evals_per_s": 2e5 / dt}
+        # BASELINE configs[2]: 4096 preflop states x 3 players x 50k iterations, host buffers (PCIe-inclusive)
+        q3 = npa.pack_queries(hole[:4096], board[:4096], 3, 50000) if B >= 4096 else None
+        if q3 is not None:
+            eng.eval_batch(q3, seed=1)
+            t1 = time.perf_counter()
+            for i in range(5):
+                eng.eval_batch(q3, seed=i)
+            dt = (time.perf_counter() - t1) / 5
+            extras["configs[2]_4096x3x50k"] = {"call_ms_host_buffers": 1e3 * dt, "kernel_ms": eng.last_kernel_ms,
+                                               "hand_evals_per_s": 4096 * 3 * 50000 / dt}
+        out["other_configs"] = extras
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(N, runs)
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

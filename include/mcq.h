@@ -92,10 +92,11 @@ MCQ_API int mcq_eval_batch(mcq_ctx *ctx, const mcq_query *q, size_t n, uint64_t 
 MCQ_API int mcq_eval_one(mcq_ctx *ctx, const mcq_query *q, uint64_t seed, int mode, mcq_result *out);
 
 /* Same computation with queries and results RESIDENT IN HBM: d_queries -> mcq_query[n], d_results ->
- * mcq_result[n] (overwritten), both device pointers on this context's device; hip_stream is a hipStream_t
- * (NULL = the context's own stream).  Asynchronous: returns after enqueueing; no host synchronisation, so it
- * can be captured into a hipGraph.  MCQ_MODE_PHILOX only.  Invalid queries cannot be rejected up front here:
- * their result has runs = 0 and passes = UINT64_MAX. */
+ * mcq_result[n] (overwritten), both device pointers on this context's device; hip_stream is the hipStream_t
+ * to launch on (NULL = HIP's null stream, as everywhere in HIP).  Asynchronous: returns after enqueueing,
+ * no host synchronisation once the context's scratch is large enough (first call / larger n allocate).
+ * MCQ_MODE_PHILOX only.  Invalid queries cannot be rejected up front here: their result has runs = 0 and
+ * passes = UINT64_MAX. */
 MCQ_API int mcq_eval_batch_device(mcq_ctx *ctx, const void *d_queries, size_t n, uint64_t seed, uint64_t first_query_id,
                           void *d_results, void *hip_stream);
 
@@ -105,8 +106,12 @@ MCQ_API int mcq_eval_batch_device(mcq_ctx *ctx, const void *d_queries, size_t n,
 MCQ_API int mcq_showdown(mcq_ctx *ctx, const uint8_t *hands, size_t n_tables, int n_players, uint8_t *winner,
                  uint8_t *winner_type, uint32_t *keys);
 
-/* Duration in milliseconds of the most recent evaluation kernel launched through this context's host entry
- * points, measured with HIP events on the context's stream (0 if none). */
+/* Every evaluation-kernel launch is bracketed by a pair of HIP events on the stream it is launched on (a ring
+ * of the 64 most recent launches).  mcq_kernel_times writes the durations in milliseconds of the latest
+ * min(max_n, 64, launches so far) launches, oldest first, and returns how many; the launches must have
+ * completed (synchronise the stream first).  mcq_last_kernel_ms: the most recent host-entry call's total
+ * (all chunks), else the latest launch. */
+MCQ_API int mcq_kernel_times(mcq_ctx *ctx, float *ms, int max_n);
 MCQ_API float mcq_last_kernel_ms(mcq_ctx *ctx);
 
 MCQ_API const char *mcq_last_error(void);

@@ -4,7 +4,9 @@ The library is built in-tree by `python -m neuron_poker_amd.build` (or __graft_e
 missing, or no HIP device can be opened, this module raises -- it never falls back to a CPU implementation.
 """
 import ctypes as C
+import importlib.util
 import os
+import sys
 import threading
 
 import numpy as np
@@ -32,6 +34,25 @@ def library_path():
     return os.environ.get("MCQ_LIBRARY", os.path.join(_HERE, "libmcq_hip.so"))
 
 
+def _share_hip_runtime_with_torch():
+    """One process must hold ONE HIP/HSA runtime.  PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME
+    libamdhip64.so.7, the same as /opt/rocm's); if libmcq_hip.so bound the system copy and torch were imported
+    afterwards, the second runtime would find no GPU.  So when a torch wheel with a bundled runtime is
+    installed, that copy is mapped first and libmcq_hip.so resolves to it by SONAME.  MCQ_HIP_RUNTIME=system
+    opts out (processes that never import torch)."""
+    if os.environ.get("MCQ_HIP_RUNTIME", "auto") == "system" or "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load_library():
     """Load libmcq_hip.so and declare the prototypes of include/mcq.h.  Loud failure if it is not built."""
     global _lib
@@ -42,6 +63,7 @@ def load_library():
         if not os.path.exists(path):
             raise ImportError("%s not found: build it with `python -m neuron_poker_amd.build` (hipcc, gfx950). "
                               "neuron_poker_amd has no CPU fallback." % path)
+        _share_hip_runtime_with_torch()
         L = C.CDLL(path)
         vp, u64, sz = C.c_void_p, C.c_uint64, C.c_size_t
         L.mcq_device_count.argtypes = []
@@ -58,6 +80,8 @@ def load_library():
         L.mcq_eval_batch_device.restype = C.c_int
         L.mcq_showdown.argtypes = [vp, vp, sz, C.c_int, vp, vp, vp]
         L.mcq_showdown.restype = C.c_int
+        L.mcq_kernel_times.argtypes = [vp, vp, C.c_int]
+        L.mcq_kernel_times.restype = C.c_int
         L.mcq_last_kernel_ms.argtypes = [vp]
         L.mcq_last_kernel_ms.restype = C.c_float
         L.mcq_last_error.argtypes = []
@@ -156,6 +180,14 @@ class Engine:
         if rc:
             _raise(rc)
         return (win, wt, keys) if want_keys else (win, wt)
+
+    def kernel_times(self, max_n=64):
+        """Durations (ms, HIP events on the launch stream) of the most recent evaluation-kernel launches."""
+        ms = np.zeros(max(int(max_n), 1), np.float32)
+        n = self._lib.mcq_kernel_times(self._ctx, ms.ctypes.data, int(max_n))
+        if n < 0:
+            _raise(n)
+        return ms[:n]
 
     @property
     def last_kernel_ms(self):

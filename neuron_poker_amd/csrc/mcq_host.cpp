@@ -86,10 +86,12 @@ struct mcq_ctx {
     int n_cu = 0;
     int occ256[2] = {1, 1}; /* resident 256-thread blocks per CU of the two eval kernels */
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    static constexpr int kRing = 64; /* event pairs around the most recent evaluation-kernel launches */
+    hipEvent_t ev0[kRing] = {}, ev1[kRing] = {};
+    uint64_t n_timed = 0;
     float last_ms = 0.f;
     McqLuts *d_luts = nullptr;
-    DevBuf d_q, d_res, d_prefix, d_prefix_dev, d_draws, d_off, d_hands, d_win, d_wt, d_keys;
+    DevBuf d_q, d_res, d_prefix, d_draws, d_off, d_hands, d_win, d_wt, d_keys;
     PinBuf h_q, h_res, h_draws, h_off, h_misc;
 };
 
@@ -118,10 +120,14 @@ int run_slice(mcq_ctx *c, int mode, const mcq_query *d_q, uint32_t n, mcq_result
     HIP_TRY(mcq_launch_prep(d_q, n, d_res, (uint32_t *)c->d_prefix.p, s));
     uint32_t grid, block;
     pick_geometry(c, mode, total_tasks, &grid, &block);
-    if (timed) HIP_TRY(hipEventRecord(c->ev0, s));
+    const int slot = (int)(c->n_timed % mcq_ctx::kRing);
+    if (timed) HIP_TRY(hipEventRecord(c->ev0[slot], s));
     HIP_TRY(mcq_launch_eval(mode, d_q, n, (const uint32_t *)c->d_prefix.p, d_res, seed, first_qid, c->d_luts, d_draws,
                             d_off, grid, block, s));
-    if (timed) HIP_TRY(hipEventRecord(c->ev1, s));
+    if (timed) {
+        HIP_TRY(hipEventRecord(c->ev1[slot], s));
+        c->n_timed++;
+    }
     return MCQ_OK;
 }
 
@@ -159,14 +165,16 @@ void mcq_destroy(mcq_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf *db[] = {&c->d_q, &c->d_res, &c->d_prefix, &c->d_prefix_dev, &c->d_draws, &c->d_off,
-                    &c->d_hands, &c->d_win, &c->d_wt, &c->d_keys};
+    DevBuf *db[] = {&c->d_q, &c->d_res, &c->d_prefix, &c->d_draws, &c->d_off, &c->d_hands, &c->d_win, &c->d_wt,
+                    &c->d_keys};
     for (DevBuf *b : db) b->release();
     PinBuf *pb[] = {&c->h_q, &c->h_res, &c->h_draws, &c->h_off, &c->h_misc};
     for (PinBuf *b : pb) b->release();
     if (c->d_luts) (void)hipFree(c->d_luts);
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (int i = 0; i < mcq_ctx::kRing; i++) {
+        if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]);
+        if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]);
+    }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -200,8 +208,10 @@ mcq_ctx *mcq_create(int device, int flags) {
     CREATE_TRY(hipGetDeviceProperties(&prop, device));
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    CREATE_TRY(hipEventCreate(&c->ev0));
-    CREATE_TRY(hipEventCreate(&c->ev1));
+    for (int i = 0; i < mcq_ctx::kRing; i++) {
+        CREATE_TRY(hipEventCreate(&c->ev0[i]));
+        CREATE_TRY(hipEventCreate(&c->ev1[i]));
+    }
     CREATE_TRY(hipMalloc((void **)&c->d_luts, sizeof(McqLuts)));
     CREATE_TRY(hipMemcpy(c->d_luts, &luts, sizeof(McqLuts), hipMemcpyHostToDevice));
     for (int mode = 0; mode < 2; mode++) {
@@ -213,7 +223,24 @@ mcq_ctx *mcq_create(int device, int flags) {
     return c;
 }
 
-float mcq_last_kernel_ms(mcq_ctx *c) { return c ? c->last_ms : 0.f; }
+int mcq_kernel_times(mcq_ctx *c, float *ms, int max_n) {
+    if (!c || !ms || max_n < 0) return fail(MCQ_EINVAL, "mcq_kernel_times: bad argument");
+    uint64_t have = c->n_timed < (uint64_t)mcq_ctx::kRing ? c->n_timed : (uint64_t)mcq_ctx::kRing;
+    int n = (int)(have < (uint64_t)max_n ? have : (uint64_t)max_n);
+    HIP_TRY(hipSetDevice(c->device));
+    for (int i = 0; i < n; i++) {
+        int slot = (int)((c->n_timed - (uint64_t)n + (uint64_t)i) % mcq_ctx::kRing);
+        HIP_TRY(hipEventElapsedTime(&ms[i], c->ev0[slot], c->ev1[slot]));
+    }
+    return n;
+}
+
+float mcq_last_kernel_ms(mcq_ctx *c) {
+    float ms = 0.f;
+    if (!c) return 0.f;
+    if (c->last_ms > 0.f) return c->last_ms;
+    return mcq_kernel_times(c, &ms, 1) == 1 ? ms : 0.f;
+}
 
 int mcq_eval_batch_device(mcq_ctx *c, const void *d_queries, size_t n, uint64_t seed, uint64_t first_query_id,
                           void *d_results, void *hip_stream) {
@@ -222,10 +249,11 @@ int mcq_eval_batch_device(mcq_ctx *c, const void *d_queries, size_t n, uint64_t 
     if (!d_queries || !d_results) return fail(MCQ_EINVAL, "mcq_eval_batch_device: null buffer");
     if (n > 0x7fffffffu) return fail(MCQ_EINVAL, "mcq_eval_batch_device: n too large");
     HIP_TRY(hipSetDevice(c->device));
-    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    hipStream_t s = (hipStream_t)hip_stream; /* NULL = the HIP null stream */
     /* the prefix buffer must already be large enough when the call is being captured into a graph */
+    c->last_ms = 0.f;
     return run_slice(c, MCQ_MODE_PHILOX, (const mcq_query *)d_queries, (uint32_t)n, (mcq_result *)d_results, seed,
-                     first_query_id, 0, nullptr, nullptr, s, false);
+                     first_query_id, 0, nullptr, nullptr, s, true);
 }
 
 int mcq_eval_batch(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed, uint64_t first_query_id, int mode,
@@ -256,13 +284,14 @@ int mcq_eval_batch(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed, uint
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(c->h_res.p, c->d_res.p, n * sizeof(mcq_result), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        HIP_TRY(hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+        if (mcq_kernel_times(c, &c->last_ms, 1) != 1) c->last_ms = 0.f;
         memcpy(out, c->h_res.p, n * sizeof(mcq_result));
         return MCQ_OK;
     }
 
     /* parity mode: chunks of queries whose draw bytes fit the staging budget */
     std::vector<uint64_t> passes(n, 0);
+    float replay_ms = 0.f;
     size_t a = 0;
     while (a < n) {
         size_t b = a;
@@ -309,14 +338,14 @@ int mcq_eval_batch(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed, uint
         if (rc) return rc;
         HIP_TRY(hipStreamSynchronize(c->stream)); /* staging buffers are reused by the next chunk */
         float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-        c->last_ms += ms;
+        if (mcq_kernel_times(c, &ms, 1) == 1) replay_ms += ms;
         a = b;
     }
     HIP_TRY(hipMemcpyAsync(c->h_res.p, c->d_res.p, n * sizeof(mcq_result), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     memcpy(out, c->h_res.p, n * sizeof(mcq_result));
     for (size_t i = 0; i < n; i++) out[i].passes = passes[i];
+    c->last_ms = replay_ms;
     return MCQ_OK;
 }
 
