@@ -1,0 +1,83 @@
+"""The N > 1 path on CPU: world_size-2 gloo process group, queries block-sharded, one integer all-reduce.
+The per-rank evaluator here is the ORACLE (tests may use it as the checker's stand-in; the product's GPU
+evaluator is exercised with the same sharding in tests/test_gpu_parity.py::test_shard_invariance...)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.distributed as dist  # noqa: E402
+import torch.multiprocessing as mp  # noqa: E402
+
+from neuron_poker_amd import sharding  # noqa: E402
+from neuron_poker_amd._lib import pack_queries  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+def _batch():
+    g = np.random.default_rng(65536)  # BASELINE configs[3] generator, scaled down
+    B = 37
+    hole, board = [], []
+    for i in range(B):
+        b = 3 if i % 2 == 0 else 4
+        cards = g.choice(52, 2 + b, replace=False)
+        hole.append(cards[:2])
+        board.append(list(cards[2:]) + [255] * (5 - b))
+    return pack_queries(hole, board, 6, 700)
+
+
+def _oracle_eval(mode):
+    def f(q, seed, first):
+        return O.run_batch(mode, np.ascontiguousarray(q).view(np.uint8).reshape(-1, 16), seed, first)
+    return f
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        q = _batch()
+        for mode in (O.MODE_CTR, O.MODE_MT):
+            t = sharding.eval_batch_sharded(q, 77, _oracle_eval(mode), first_query_id=1000)
+            np.save(os.path.join(out_dir, "t_%d_%d.npy" % (mode, rank)), t)
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_shard_bounds_cover_everything():
+    for n in (0, 1, 7, 4096, 65536):
+        for w in (1, 2, 3, 8):
+            b = [sharding.shard_bounds(n, r, w) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            assert max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b) <= 1
+    with pytest.raises(ValueError):
+        sharding.shard_bounds(4, 2, 2)
+
+
+def test_two_rank_gloo_allreduce_equals_single_rank(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    q = _batch()
+    for mode in (O.MODE_CTR, O.MODE_MT):
+        exp = _oracle_eval(mode)(q, 77, 1000)
+        for r in range(world):
+            got = np.load(os.path.join(str(tmp_path), "t_%d_%d.npy" % (mode, r)))
+            assert np.array_equal(got, exp), (mode, r)
+
+
+def test_single_process_without_group():
+    q = _batch()[:5]
+    t = sharding.eval_batch_sharded(q, 3, _oracle_eval(O.MODE_CTR))
+    assert np.array_equal(t, _oracle_eval(O.MODE_CTR)(q, 3, 0))
