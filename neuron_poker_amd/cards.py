@@ -24,3 +24,10 @@ def card_str(cid):
     if not 0 <= cid < 52:
         raise ValueError("card id out of range: %r" % (cid,))
     return RANKS[cid >> 2] + SUITS[cid & 3]
+
+
+def key_type(keys):
+    """by_type index of the 32-bit ranking keys returned by Engine.showdown (MCQ_KEY_TYPE in include/mcq.h)."""
+    import numpy as np
+    code = np.asarray(keys, dtype=np.uint32) >> 27
+    return (code - (code >= 6)).astype(np.uint32)

@@ -1,14 +1,20 @@
-// mcq_device.hpp -- per-lane arithmetic of the equity kernels: RNG front ends, k-th-card selection on the
-// 52-bit deck mask, the branch-light 7-card ranking key, and one Monte-Carlo iteration.
+// mcq_device.hpp -- per-lane arithmetic of the equity kernels: RNG front ends, search-free dealing from the
+// ordered deck, the branch-free 7-card ranking key, and one Monte-Carlo iteration.
 //
-// Everything here is written against three tiny primitives (popcount, count-leading-zeros, 32x32 high
-// multiply) so that the very same source is compiled for gfx950 by hipcc (the product) and, by
+// Everything here is written against a few tiny primitives (popcount, count-leading-zeros, 32x32 high
+// multiply, byte splat) so that the very same source is compiled for gfx950 by hipcc (the product) and, by
 // tests/hostsim only, for the host compiler to unit-test the lane arithmetic where no GPU exists.
 //
 // What it reproduces (reference paths relative to /root/reference):
 //   tools/montecarlo_python.py:121-189  dealing order and index semantics (see mcq_iteration)
-//   tools/hand_evaluator.py:27-119      _calc_score ordering incl. its quirks (see mcq_eval7)
+//   tools/hand_evaluator.py:27-119      _calc_score ordering incl. its quirks (see mcq_eval_key)
 //   tools/hand_evaluator.py:20-24       ties go to the first hand = hero
+//
+// Instruction selection follows the gfx950 issue costs measured with tools/ubench (profiles/r01_ubench.txt):
+// add/sub/and/or/xor/not/lshr/ashr issue in ~2.3 cycles per wave, while lshl, cmp, cndmask, bcnt, ffbh, bfe,
+// min/max, every multiply and every 3-operand form take ~4.3, and a random LDS lookup ~8.5 cycles of the
+// (otherwise idle) LDS pipe.  Hence: no compare/select chains, arithmetic masks instead; small LDS tables for
+// straights, flushes and top-two-bits; masks kept pre-shifted where they index a table.
 #pragma once
 #include <stdint.h>
 
@@ -36,11 +42,11 @@ MCQ_HD uint32_t mcq_popc(uint32_t x) {
     return (uint32_t)__builtin_popcount(x);
 #endif
 }
-MCQ_HD uint32_t mcq_clz(uint32_t x) { /* x != 0 */
+MCQ_HD uint32_t mcq_clz(uint32_t x) { /* x != 0 for a meaningful result */
 #if defined(__HIP_DEVICE_COMPILE__)
     return (uint32_t)__clz((int)x);
 #else
-    return (uint32_t)__builtin_clz(x);
+    return x ? (uint32_t)__builtin_clz(x) : 32u;
 #endif
 }
 MCQ_HD uint32_t mcq_mulhi(uint32_t a, uint32_t b) {
@@ -51,30 +57,77 @@ MCQ_HD uint32_t mcq_mulhi(uint32_t a, uint32_t b) {
 #endif
 }
 MCQ_HD uint32_t mcq_rotl(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
-MCQ_HD uint32_t mcq_topbit(uint32_t m) { return 0x80000000u >> mcq_clz(m); } /* m != 0 */
+MCQ_HD uint32_t mcq_topbit(uint32_t m) { return 0x80000000u >> (mcq_clz(m) & 31u); } /* garbage for m == 0 */
 MCQ_HD uint32_t mcq_droplow(uint32_t m) { return m & (m - 1); }
+MCQ_HD uint32_t mcq_nz_mask(uint32_t x) { /* x < 2^31: all ones if x != 0 else 0, without compare/select */
+    return (uint32_t)((int32_t)(0u - x) >> 31);
+}
+MCQ_HD uint32_t mcq_splat_byte(uint32_t x) { /* x < 256 -> x in all four bytes */
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(0u, x, 0u); /* v_perm_b32: every selector byte 0 = byte 0 of x */
+#else
+    return x * 0x01010101u;
+#endif
+}
 
-// ------------------------------------------------------------------------------------------ lookup tables
-// Staged in LDS by the kernels.  sel8[v]: positions of the set bits of byte v, 3 bits each (j-th set bit at
-// bits 3j..3j+2).  suit[c]: the bit of card c in the suit-major hand layout (lo = clubs | diamonds << 16,
-// hi = hearts | spades << 16, bit r of each half-word = rank r).
-struct McqLuts {
+// ------------------------------------------------------------------------------------------ ranking keys
+// Internal key = code << 27 | field, unsigned order == Python's order of _calc_score's (score, card_ranks).
+// Codes leave a gap at 5 (history: lets a 16-bit flush table add 3 * flag); by_type index = code - (code >= 6).
+#define MCQ_KEY_SHIFT 27
+enum { MCQ_C_HIGH = 0, MCQ_C_PAIR = 1, MCQ_C_TWOPAIR = 2, MCQ_C_TRIPS = 3, MCQ_C_STRAIGHT = 4, MCQ_C_FLUSH = 6,
+       MCQ_C_FULL = 7, MCQ_C_QUADS = 8, MCQ_C_SF = 9, MCQ_N_CODES = 10 };
+MCQ_HD uint32_t mcq_code_to_type(uint32_t code) { return code - (code >= 6u ? 1u : 0u); } /* by_type index */
+MCQ_HD uint32_t mcq_key_type(uint32_t key) { return mcq_code_to_type(key >> MCQ_KEY_SHIFT); }
+
+// bit i of the result set <=> ranks i-1 .. i+3 all present (rank -1 = ace playing low)
+MCQ_HD uint32_t mcq_straight_runs(uint32_t m) {
+    uint32_t m2 = (m << 1) | (m >> 12);
+    uint32_t r1 = m2 & (m2 >> 1);
+    uint32_t r2 = r1 & (r1 >> 2);
+    return r2 & (m2 >> 4);
+}
+
+// ------------------------------------------------------------------------------------------ lookup tables (LDS)
+// sel8: only for laying out the per-query base deck (once per wave task).
+// str[m]  (m = 13-bit rank mask): 0 if m holds no straight, else 0x80 | (top position 1..10); key = str << 22.
+// top2[m]: the two highest set bits of m (0 if m has fewer than two).
+// tf[m]:   the complete key of the suit mask m: StraightFlush (all ranks of the suit plus the -1 slot when it
+//          holds the ace, hand_evaluator.py:71-80,93), Flush (top five, :98-100), or 0 when popcount(m) < 5.
+struct McqTables {
+    uint32_t tf[8192];
+    uint16_t top2[8192];
+    uint8_t str[8192];
     uint32_t sel8[256];
-    uint32_t suit_lo[64];
-    uint32_t suit_hi[64];
 };
 
-static inline void mcq_fill_luts(McqLuts *t) {
+static inline void mcq_fill_tables(McqTables *t) {
     for (uint32_t v = 0; v < 256; v++) {
         uint32_t e = 0, j = 0;
         for (uint32_t b = 0; b < 8; b++)
             if (v >> b & 1) e |= b << (3 * j++);
         t->sel8[v] = e;
     }
-    for (uint32_t c = 0; c < 64; c++) {
-        uint32_t pos = ((c & 3) << 4) | (c >> 2);
-        t->suit_lo[c] = (c < 52 && pos < 32) ? 1u << pos : 0;
-        t->suit_hi[c] = (c < 52 && pos >= 32) ? 1u << (pos - 32) : 0;
+    for (uint32_t m = 0; m < 8192; m++) {
+        uint32_t runs = mcq_straight_runs(m);
+        t->str[m] = runs ? (uint8_t)(0x80u | (32u - (uint32_t)__builtin_clz(runs))) : 0;
+        uint32_t n = (uint32_t)__builtin_popcount(m);
+        uint32_t hi2 = 0;
+        if (n >= 2) {
+            uint32_t a = 0x80000000u >> __builtin_clz(m);
+            hi2 = a | (0x80000000u >> __builtin_clz(m ^ a));
+        }
+        t->top2[m] = (uint16_t)hi2;
+        uint32_t key = 0;
+        if (n >= 5) {
+            if (runs) {
+                key = ((uint32_t)MCQ_C_SF << MCQ_KEY_SHIFT) | (m << 1) | (m >> 12);
+            } else {
+                uint32_t f = m;
+                for (uint32_t k = n; k > 5; k--) f &= f - 1;
+                key = ((uint32_t)MCQ_C_FLUSH << MCQ_KEY_SHIFT) | f;
+            }
+        }
+        t->tf[m] = key;
     }
 }
 
@@ -103,6 +156,10 @@ struct McqXoshiro { /* xoshiro128++ (Blackman & Vigna) */
         if ((s0 | s1 | s2 | s3) == 0) s0 = 1;
     }
     MCQ_HDM uint32_t next() {
+#ifdef MCQ_ABLATE_RNG /* diagnostic timing build: wrong results */
+        s0 += 0x9E3779B9u;
+        return s0;
+#endif
         uint32_t result = mcq_rotl(s0 + s3, 7) + s0;
         uint32_t t = s1 << 9;
         s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3;
@@ -144,9 +201,9 @@ struct McqReplayDraws {
     }
 };
 
-// ------------------------------------------------------------------------------------------ deck
-// The deck is a 52-bit mask in card-id order (= the reference's list order); list.pop(k) of the ordered
-// remaining deck is "find the k-th set bit, clear it".  Returns the card id.
+// ------------------------------------------------------------------------------------------ base deck
+// k-th set bit of the 52-bit deck mask (card-id order = the reference's list order), cleared afterwards.
+// Only used to lay out the per-query base deck once per wave task; the per-draw work is search-free (below).
 MCQ_HD uint32_t mcq_select_pop(uint32_t &dlo, uint32_t &dhi, uint32_t k, const uint32_t *sel8) {
     uint32_t c = mcq_popc(dlo);
     bool up = k >= c;
@@ -164,82 +221,131 @@ MCQ_HD uint32_t mcq_select_pop(uint32_t &dlo, uint32_t &dhi, uint32_t k, const u
     k = u ? k - c : k;
     base += u ? 8u : 0u;
     uint32_t e = sel8[w & 0xFFu];
-    uint32_t pos = base + ((e >> (3 * k)) & 7u);
+    uint32_t pos = base + ((e >> (3 * (k & 7u))) & 7u);
     uint32_t bit = 1u << (pos & 31u);
     dlo &= up ? 0xFFFFFFFFu : ~bit;
     dhi &= up ? ~bit : 0xFFFFFFFFu;
     return pos;
 }
 
-// ------------------------------------------------------------------------------------------ evaluator
-// bit i of the result set <=> ranks i-1 .. i+3 all present (rank -1 = ace playing low)
-MCQ_HD uint32_t mcq_straight_runs(uint32_t m) {
-    uint32_t m2 = (m << 1) | (m >> 12);
-    uint32_t r1 = m2 & (m2 >> 1);
-    uint32_t r2 = r1 & (r1 >> 2);
-    return r2 & (m2 >> 4);
+// One card as the evaluator wants it (16 bytes: one ds_read_b128 per dealt card).
+struct __attribute__((aligned(16))) McqCard {
+    uint32_t rb;  /* 1 << rank */
+    uint32_t cnt; /* 1 << 4*suit: packed per-suit counters */
+    uint32_t los; /* suit-major bit, pre-shifted left by 2 (tf[] byte offset): clubs bits 2..14, diamonds 18..30 */
+    uint32_t his; /* hearts bits 2..14, spades bits 18..30 */
+};
+
+MCQ_HD McqCard mcq_card(uint32_t c) { /* c < 52 */
+    const uint32_t rank = c >> 2, suit = c & 3u;
+    McqCard e;
+    e.rb = 1u << rank;
+    e.cnt = 1u << (4u * suit);
+    const uint32_t bit = 4u << (rank + 16u * (suit & 1u));
+    e.los = suit < 2 ? bit : 0u;
+    e.his = suit < 2 ? 0u : bit;
+    return e;
 }
 
-// 32-bit key whose unsigned order equals Python's order of _calc_score's (score, card_ranks) tuples
-// (hand_evaluator.py:27-119) for 7 distinct cards.  key >> 28 = by_type index.  Every card_ranks vector that
-// is a strictly descending sequence is encoded as a rank bit mask (lexicographic order of such sequences,
-// including the shorter-is-smaller rule, equals integer order of the masks); (count-major) prefixes such as
-// the pair or trips rank sit above the kicker mask.
-//   lo = clubs | diamonds << 16, hi = hearts | spades << 16; bit r = rank r (0 = deuce .. 12 = ace).
-MCQ_HD uint32_t mcq_eval7(uint32_t lo, uint32_t hi) {
-    uint32_t X = lo ^ hi, A = lo & hi; /* half-adders of (clubs,hearts) and (diamonds,spades), both halves at once */
-    uint32_t x0 = X & 0xFFFFu, x1 = X >> 16, a0 = A & 0xFFFFu, a1 = A >> 16;
-    uint32_t any = (lo | hi);
-    any = (any | (any >> 16)) & 0xFFFFu;
-    uint32_t ge2 = a0 | a1 | (x0 & x1);
-    uint32_t ge3 = (a0 & (x1 | a1)) | (a1 & x0);
-    uint32_t eq4 = a0 & a1;
-
-    uint32_t s0 = lo & 0xFFFFu, s1 = lo >> 16, s2 = hi & 0xFFFFu, s3 = hi >> 16;
-    uint32_t fl = mcq_popc(s0) >= 5 ? s0 : mcq_popc(s1) >= 5 ? s1 : mcq_popc(s2) >= 5 ? s2 : mcq_popc(s3) >= 5 ? s3 : 0u;
-
-    uint32_t n2 = mcq_popc(ge2);
-    uint32_t key;
-    if (fl != 0 && mcq_straight_runs(fl) != 0) {
-        /* StraightFlush: ALL ranks of the suit, plus the -1 slot when it holds the ace (l.71-80, l.93) */
-        key = (8u << 28) | (fl << 1) | (fl >> 12);
-    } else if (eq4 != 0) {
-        /* FoufOfAKind: the two highest distinct ranks of all seven cards (l.43-46) */
-        uint32_t t = mcq_topbit(any);
-        key = (7u << 28) | t | mcq_topbit(any ^ t);
-    } else if (ge3 != 0 && n2 >= 2) {
-        /* FullHouse: (trips, best remaining pair or second trips) (l.36-38) */
-        uint32_t t = mcq_topbit(ge3);
-        key = (6u << 28) | (t << 13) | mcq_topbit(ge2 ^ t);
-    } else if (fl != 0) {
-        /* Flush: top five ranks of the suit (l.98-100) */
-        uint32_t n = mcq_popc(fl), f = fl;
-        f = n > 5 ? mcq_droplow(f) : f;
-        f = n > 6 ? mcq_droplow(f) : f;
-        key = (5u << 28) | f;
-    } else {
-        uint32_t runs = mcq_straight_runs(any);
-        if (runs != 0) {
-            /* Straight: decided by its top rank (l.52-58); wheel = lowest */
-            key = (4u << 28) | (32u - mcq_clz(runs));
-        } else if (ge3 != 0) {
-            /* ThreeOfAKind: trips, two kickers (l.104-106) */
-            uint32_t s = mcq_droplow(mcq_droplow(any ^ ge3));
-            key = (3u << 28) | (ge3 << 13) | s;
-        } else if (n2 >= 2) {
-            /* TwoPair: two best pairs, kicker = best of everything else incl. a third pair (l.39-42, l.107-109) */
-            uint32_t P = n2 == 3 ? mcq_droplow(ge2) : ge2;
-            key = (2u << 28) | (P << 13) | mcq_topbit(any ^ P);
-        } else if (ge2 != 0) {
-            /* Pair: pair, three kickers (l.110-112) */
-            uint32_t s = mcq_droplow(mcq_droplow(any ^ ge2));
-            key = (1u << 28) | (ge2 << 13) | s;
-        } else {
-            /* HighCard: top five (l.113-115) */
-            key = mcq_droplow(mcq_droplow(any));
-        }
+// ------------------------------------------------------------------------------------------ evaluator
+// A hand is (table cards) + (two hole cards).  The table part is accumulated once per iteration:
+//   any/ge2/ge3/eq4: ranks present at least once / twice / three times / four times; cnt: packed suit counters;
+//   los/his: suit-major masks (pre-shifted).  Adding a card with rank bit r: eq4 |= ge3 & r; ge3 |= ge2 & r; ...
+struct McqBoard {
+    uint32_t any, ge2, ge3, eq4, cnt, los, his;
+    MCQ_HDM void clear() { any = ge2 = ge3 = eq4 = cnt = los = his = 0; }
+    MCQ_HDM void add(const McqCard &c) {
+        eq4 |= ge3 & c.rb;
+        ge3 |= ge2 & c.rb;
+        ge2 |= any & c.rb;
+        any |= c.rb;
+        cnt += c.cnt;
+        los |= c.los;
+        his |= c.his;
     }
-    return key;
+};
+
+struct McqHole { /* two hole cards: B = r1 | r2, P = r1 & r2 (pocket pair) */
+    uint32_t B, P, los, his;
+    MCQ_HDM void set(const McqCard &a, const McqCard &b) {
+        B = a.rb | b.rb;
+        P = a.rb & b.rb;
+        los = a.los | b.los;
+        his = a.his | b.his;
+    }
+};
+
+// Only a suit with at least three table cards can make a flush, and five table cards hold at most one such
+// suit: mlo/mhi select that suit's half-word of the (los, his) pairs, bfl4 is the table's mask in it (<< 2).
+struct McqFlushSel {
+    uint32_t mlo, mhi, bfl4;
+    MCQ_HDM void from_board(const McqBoard &b) {
+        const uint32_t f = (b.cnt + 0x5555u) & 0x8888u; /* bit 4s+3 <=> suit s has >= 3 table cards */
+        const uint32_t mc = 0u - ((f >> 3) & 1u), md = 0u - ((f >> 7) & 1u);
+        const uint32_t mh = 0u - ((f >> 11) & 1u), ms = 0u - ((f >> 15) & 1u);
+        mlo = (mc & 0x0000FFFFu) | (md & 0xFFFF0000u);
+        mhi = (mh & 0x0000FFFFu) | (ms & 0xFFFF0000u);
+        const uint32_t x = (b.los & mlo) | (b.his & mhi);
+        bfl4 = (x | (x >> 16)) & 0xFFFFu;
+    }
+};
+
+// Table lookups by BYTE offset (masks are doubled / pre-shifted by the caller, never shifted left here).
+MCQ_HD uint32_t mcq_ld_u16(const uint16_t *t, uint32_t byte_off) {
+    return *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(t) + byte_off);
+}
+MCQ_HD uint32_t mcq_ld_u32(const uint32_t *t, uint32_t byte_off) {
+    return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(t) + byte_off);
+}
+
+// Key of table + hole.  Branch-free: every family of hand types yields a candidate key that is 0 when the
+// family does not apply or carries a lower code than the true type; the key is their maximum.
+//   F1  HighCard / Pair / ThreeOfAKind: (pair or trips rank) then the kickers = all other ranks minus the two
+//       lowest (hand_evaluator.py:104-106, 110-115)
+//   F2  TwoPair (two best pairs, kicker = best of the rest incl. a third pair, :39-42, 107-109) and
+//       FullHouse (trips, best remaining pair or second trips, :36-38)
+//   straight (top rank decides, wheel lowest, :52-58), flush / straight flush (table tf), and
+//   FoufOfAKind = the two highest distinct ranks of all seven cards (:43-46).
+MCQ_HD uint32_t mcq_eval_key(const McqBoard &b, const McqFlushSel &fs, const McqHole &h, const uint32_t *tf,
+                             const uint16_t *top2, const uint8_t *str) {
+#ifdef MCQ_ABLATE_EVAL /* diagnostic timing build: wrong results */
+    return (b.any ^ h.B ^ (h.los >> 3)) | (1u << MCQ_KEY_SHIFT);
+#endif
+    const uint32_t any = b.any | h.B;
+    const uint32_t ge2 = b.ge2 | (b.any & h.B) | h.P;
+    const uint32_t ge3 = b.ge3 | (b.ge2 & h.B) | (b.any & h.P);
+    const uint32_t eq4 = b.eq4 | (b.ge3 & h.B) | (b.ge2 & h.P);
+
+    /* straight */
+    const uint32_t key_s = (uint32_t)str[any] << 22;
+
+    /* flush / straight flush */
+    uint32_t x = (h.los & fs.mlo) | (h.his & fs.mhi);
+    x = (x | (x >> 16)) & 0xFFFFu;
+    const uint32_t key_f = mcq_ld_u32(tf, fs.bfl4 | x);
+
+    /* F1 */
+    const uint32_t kick1 = mcq_droplow(mcq_droplow(any ^ ge2));
+    const uint32_t key1 = (ge2 << 13) | kick1 | ((0u - ge2) & (1u << MCQ_KEY_SHIFT)) | ((0u - ge3) & (2u << MCQ_KEY_SHIFT));
+
+    /* F2 */
+    const uint32_t h2 = mcq_ld_u16(top2, ge2 + ge2);
+    const uint32_t t = mcq_topbit(ge3);
+    const uint32_t m3 = mcq_nz_mask(ge3);
+    const uint32_t H = h2 ^ ((h2 ^ t) & m3);
+    const uint32_t R = (any ^ ((any ^ ge2) & m3)) ^ H;
+    const uint32_t mv = (uint32_t)((int32_t)((0u - H) & (0u - R)) >> 31);
+    const uint32_t c2 = ((uint32_t)MCQ_C_TWOPAIR << MCQ_KEY_SHIFT) +
+                        (m3 & ((uint32_t)(MCQ_C_FULL - MCQ_C_TWOPAIR) << MCQ_KEY_SHIFT));
+    const uint32_t key2 = ((H << 13) | mcq_topbit(R) | c2) & mv;
+
+    /* quads */
+    const uint32_t key4 = (mcq_ld_u16(top2, any + any) | ((uint32_t)MCQ_C_QUADS << MCQ_KEY_SHIFT)) & mcq_nz_mask(eq4);
+
+    uint32_t k = key1 > key2 ? key1 : key2;
+    uint32_t k2 = key_s > key_f ? key_s : key_f;
+    k2 = k2 > key4 ? k2 : key4;
+    return k > k2 ? k : k2;
 }
 
 // ------------------------------------------------------------------------------------------ one query, one lane
@@ -248,9 +354,9 @@ struct McqQueryCtx { /* wave-uniform */
     uint32_t L0;               /* its length: 50 - n_board */
     uint32_t n_opp;            /* n_players - 1 */
     uint32_t n_deal;           /* 5 - n_board table cards still to come */
-    uint32_t hero_lo, hero_hi; /* hero's two cards, suit-major */
-    uint32_t board_lo, board_hi;
     uint32_t runs;
+    McqHole hero;
+    McqBoard board; /* the known table cards */
 };
 
 // The 16-byte query record as four little-endian words (kept in SGPRs by the kernels): bytes 0-1 hole,
@@ -280,20 +386,18 @@ MCQ_HD bool mcq_query_valid(const McqQueryWords &q) {
     return ok;
 }
 
-MCQ_HD void mcq_query_ctx(const McqQueryWords &q, const uint32_t *suit_lo, const uint32_t *suit_hi, McqQueryCtx &c) {
+MCQ_HD void mcq_query_ctx(const McqQueryWords &q, McqQueryCtx &c) {
     uint64_t deck = (1ull << 52) - 1;
-    c.board_lo = c.board_hi = c.hero_lo = c.hero_hi = 0;
-    for (uint32_t i = 0; i < 2u + q.n_board(); i++) {
-        uint32_t cd = q.card(i);
+    c.board.clear();
+    for (uint32_t i = 0; i < q.n_board(); i++) {
+        const uint32_t cd = q.card(2u + i);
         deck &= ~(1ull << cd);
-        if (i < 2) {
-            c.hero_lo |= suit_lo[cd];
-            c.hero_hi |= suit_hi[cd];
-        } else {
-            c.board_lo |= suit_lo[cd];
-            c.board_hi |= suit_hi[cd];
-        }
+        c.board.add(mcq_card(cd));
     }
+    const uint32_t h0 = q.card(0), h1 = q.card(1);
+    deck &= ~(1ull << h0);
+    deck &= ~(1ull << h1);
+    c.hero.set(mcq_card(h0), mcq_card(h1));
     c.deck_lo = (uint32_t)deck;
     c.deck_hi = (uint32_t)(deck >> 32);
     c.L0 = 50u - q.n_board();
@@ -308,42 +412,116 @@ static inline McqQueryWords mcq_query_words(const mcq_query &q) { /* host side *
     return w;
 }
 
+// entry l of the base deck = the l-th card of the ordered remaining deck (device: lane l computes entry l)
+MCQ_HD McqCard mcq_base_entry(const McqQueryCtx &qc, uint32_t l, const uint32_t *sel8) {
+    uint32_t dlo = qc.deck_lo, dhi = qc.deck_hi;
+    uint32_t c = mcq_select_pop(dlo, dhi, l, sel8);
+    return mcq_card(c < 52u ? c : 0u); /* lanes beyond the deck length write an entry nobody reads */
+}
+
 struct McqLaneAcc {
-    uint64_t types; /* 9 fields of 6 bits: hero's winning hand types (<= 16 per lane per task) */
+    uint64_t types; /* MCQ_N_CODES fields of 6 bits: hero's winning hand codes (<= 16 per lane per task) */
     uint32_t tie;
     uint32_t passes;
 };
 
-// One Monte-Carlo iteration of one lane.  Store keeps each opponent's two cards (suit-major) until the table
-// is complete: the reference deals ALL opponents before any table card (montecarlo_python.py:215-217).
-template <class Draws, class Store>
-MCQ_HD void mcq_iteration(const McqQueryCtx &qc, Draws &dr, const uint32_t *sel8, const uint32_t *suit_lo,
-                          const uint32_t *suit_hi, Store &st, McqLaneAcc &acc) {
-    uint32_t dlo = qc.deck_lo, dhi = qc.deck_hi, L = qc.L0;
-    for (uint32_t p = 0; p < qc.n_opp; p++) {
-        uint32_t r1, r2;
-        dr.pair(L, r1, r2, acc.passes);                   /* r1 in [0,L-1], r2 in [0,L-2], r1 != r2 (l.167-176) */
-        uint32_t c1 = mcq_select_pop(dlo, dhi, r1, sel8); /* deck.pop(r1) (l.178) */
-        uint32_t c2 = mcq_select_pop(dlo, dhi, r2, sel8); /* deck.pop(r2) on the shrunk list (l.179) */
-        st.put(p, suit_lo[c1] | suit_lo[c2], suit_hi[c1] | suit_hi[c2]);
-        L -= 2;
+// ------------------------------------------------------------------------------------------ dealing without search
+// list.pop(r) on the ordered remaining deck, reformulated so that no k-th-set-bit search is needed:
+// the base deck (query's deck minus table cards and hero, wave-uniform) is a table base[0..L0) in LDS; every card
+// already dealt in this iteration is a HOLE, remembered by its coordinate t in the CURRENT (shrunk) list, i.e.
+// the number of not-yet-dealt cards below it.  Then for a draw r on the current list
+//     base position s = r + #{holes with t <= r};   afterwards every hole with t > r moves down by one and the
+//     new hole has t = r.
+// Holes are independent of each other (no ordering to maintain), so four of them are handled per register with
+// byte-SWAR arithmetic: with rb = 0x80808080 | r * 0x01010101, bit 7 of each byte of (rb - h) says t <= r.
+// Unused byte slots hold the sentinel 0x7F and are decremented along (23 draws at most: always > 49 >= r).
+// This is an exact restatement of montecarlo_python.py:178-179,188 (checked against list.pop in the tests).
+#define MCQ_HOLE_SENTINEL 0x7F7F7F7Fu
+
+MCQ_HD void mcq_hole_reg(uint32_t rb, uint32_t &h, uint32_t &k) {
+#ifdef MCQ_ABLATE_HOLES /* diagnostic timing build: wrong results */
+    k += (rb ^ h) & 1u;
+    return;
+#endif
+    uint32_t flags = (rb - h) & 0x80808080u;
+    k += mcq_popc(flags);
+    h -= (flags ^ 0x80808080u) >> 7;
+}
+
+template <int SLOT>
+MCQ_HD void mcq_hole_put(uint32_t &h, uint32_t r) {
+    constexpr uint32_t sh = 8u * (SLOT & 3);
+    h = (h & ~(0xFFu << sh)) | (r << sh);
+}
+
+// opponent draw number J (0-based; J holes precede it, all in H[0 .. (J+3)/4))
+template <int J>
+MCQ_HD uint32_t mcq_draw_opp(uint32_t r, uint32_t (&H)[5]) {
+    uint32_t k = r;
+    if (J > 0) {
+        const uint32_t rb = mcq_splat_byte(r | 0x80u);
+#pragma unroll
+        for (int i = 0; i < (J + 3) / 4; i++) mcq_hole_reg(rb, H[i], k);
     }
-    uint32_t blo = qc.board_lo, bhi = qc.board_hi;
-    for (uint32_t k = 0; k < qc.n_deal; k++) {
-        uint32_t c = mcq_select_pop(dlo, dhi, dr.single(L - 1), sel8); /* randint(0, len-1): never the last card (l.188) */
-        blo |= suit_lo[c];
-        bhi |= suit_hi[c];
-        L -= 1;
+    mcq_hole_put<J>(H[J / 4], r);
+    return k;
+}
+
+// table draw number K (0..4): scans the opponents' holes (n_regs registers, wave-uniform) and the K earlier table holes
+template <int K>
+MCQ_HD uint32_t mcq_draw_table(uint32_t r, uint32_t (&H)[5], uint32_t &hb, uint32_t n_regs) {
+    uint32_t k = r;
+    const uint32_t rb = mcq_splat_byte(r | 0x80u);
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+        if ((uint32_t)i < n_regs) mcq_hole_reg(rb, H[i], k);
+    if (K > 0) mcq_hole_reg(rb, hb, k);
+    if (K < 4) mcq_hole_put<K>(hb, r); /* the hole of a fifth table card is never looked at */
+    return k;
+}
+
+// One Monte-Carlo iteration of one lane.  The opponents' hole cards stay in registers (statically indexed:
+// everything below is unrolled over the opponent number) until the table is complete: the reference deals
+// ALL opponents before any table card (montecarlo_python.py:215-217).
+template <class Draws>
+MCQ_HD void mcq_iteration(const McqQueryCtx &qc, Draws &dr, const McqCard *base, const uint32_t *tf,
+                          const uint16_t *top2, const uint8_t *str, McqLaneAcc &acc) {
+    uint32_t H[5] = {MCQ_HOLE_SENTINEL, MCQ_HOLE_SENTINEL, MCQ_HOLE_SENTINEL, MCQ_HOLE_SENTINEL, MCQ_HOLE_SENTINEL};
+    uint32_t hb = MCQ_HOLE_SENTINEL;
+    uint32_t L = qc.L0;
+    McqHole opp[MCQ_MAX_OPP];
+#define MCQ_OPP(P)                                                                                             \
+    if (P < qc.n_opp) {                                                                                        \
+        uint32_t r1, r2;                                                                                       \
+        dr.pair(L, r1, r2, acc.passes); /* r1 in [0,L-1], r2 in [0,L-2], r1 != r2 (l.167-176) */               \
+        const McqCard c1 = base[mcq_draw_opp<2 * P>(r1, H)];     /* deck.pop(r1) (l.178) */                    \
+        const McqCard c2 = base[mcq_draw_opp<2 * P + 1>(r2, H)]; /* deck.pop(r2) on the shrunk list (l.179) */ \
+        opp[P].set(c1, c2);                                                                                    \
+        L -= 2;                                                                                                \
     }
-    uint32_t hk = mcq_eval7(qc.hero_lo | blo, qc.hero_hi | bhi);
+    MCQ_OPP(0) MCQ_OPP(1) MCQ_OPP(2) MCQ_OPP(3) MCQ_OPP(4) MCQ_OPP(5) MCQ_OPP(6) MCQ_OPP(7) MCQ_OPP(8)
+#undef MCQ_OPP
+    const uint32_t n_regs = (2u * qc.n_opp + 3u) / 4u;
+    McqBoard b = qc.board;
+#define MCQ_TABLE(K)                                                                                           \
+    if (K < qc.n_deal) {                                                                                       \
+        b.add(base[mcq_draw_table<K>(dr.single(L - 1), H, hb, n_regs)]); /* never the last card (l.188) */     \
+        L -= 1;                                                                                                \
+    }
+    MCQ_TABLE(0) MCQ_TABLE(1) MCQ_TABLE(2) MCQ_TABLE(3) MCQ_TABLE(4)
+#undef MCQ_TABLE
+    McqFlushSel fs;
+    fs.from_board(b);
+    const uint32_t hk = mcq_eval_key(b, fs, qc.hero, tf, top2, str);
     uint32_t best = 0;
-    for (uint32_t p = 0; p < qc.n_opp; p++) {
-        uint32_t lo, hi;
-        st.get(p, lo, hi);
-        uint32_t k = mcq_eval7(lo | blo, hi | bhi);
-        best = k > best ? k : best;
+#define MCQ_EVAL(P)                                                        \
+    if (P < qc.n_opp) {                                                    \
+        const uint32_t k = mcq_eval_key(b, fs, opp[P], tf, top2, str);     \
+        best = k > best ? k : best;                                        \
     }
+    MCQ_EVAL(0) MCQ_EVAL(1) MCQ_EVAL(2) MCQ_EVAL(3) MCQ_EVAL(4) MCQ_EVAL(5) MCQ_EVAL(6) MCQ_EVAL(7) MCQ_EVAL(8)
+#undef MCQ_EVAL
     uint64_t won = hk >= best ? 1u : 0u; /* ties go to hero (hand_evaluator.py:23) */
-    acc.types += won << (6u * (hk >> 28));
+    acc.types += won << (6u * (hk >> MCQ_KEY_SHIFT));
     acc.tie += hk == best ? 1u : 0u;
 }

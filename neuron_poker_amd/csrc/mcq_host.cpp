@@ -78,19 +78,20 @@ struct PinBuf {
 };
 
 constexpr size_t kReplayChunkBytes = 256u << 20; /* draw bytes staged per launch in parity mode */
+constexpr uint32_t kBlock = 512;                 /* threads per block of the evaluation kernels */
 
 }  // namespace
 
 struct mcq_ctx {
     int device = 0;
     int n_cu = 0;
-    int occ256[2] = {1, 1}; /* resident 256-thread blocks per CU of the two eval kernels */
+    int occ[2] = {1, 1}; /* resident kBlock-thread blocks per CU of the two eval kernels */
     hipStream_t stream = nullptr;
     static constexpr int kRing = 64; /* event pairs around the most recent evaluation-kernel launches */
     hipEvent_t ev0[kRing] = {}, ev1[kRing] = {};
     uint64_t n_timed = 0;
     float last_ms = 0.f;
-    McqLuts *d_luts = nullptr;
+    McqTables *d_luts = nullptr;
     DevBuf d_q, d_res, d_prefix, d_draws, d_off, d_hands, d_win, d_wt, d_keys;
     PinBuf h_q, h_res, h_draws, h_off, h_misc;
 };
@@ -101,15 +102,16 @@ uint32_t tasks_of(const mcq_query &q) { return (q.runs + MCQ_TASK_ITERS - 1) / M
 
 /* grid/block for a launch whose total task count is known (host entry) or unknown (0) */
 void pick_geometry(const mcq_ctx *c, int mode, uint64_t total_tasks, uint32_t *grid, uint32_t *block) {
-    const uint32_t full = (uint32_t)c->n_cu * (uint32_t)c->occ256[mode];
-    if (total_tasks == 0) { *block = 256; *grid = full; return; }
+    const uint32_t full = (uint32_t)c->n_cu * (uint32_t)c->occ[mode];
+    if (total_tasks == 0) { *block = kBlock; *grid = full; return; }
     if (total_tasks <= (uint64_t)c->n_cu * 4) { /* few tasks (single query): one wave per block spreads over CUs */
         *block = 64;
         *grid = (uint32_t)total_tasks;
         return;
     }
-    uint64_t blocks = (total_tasks + 3) / 4;
-    *block = 256;
+    const uint64_t wpb = kBlock / 64;
+    uint64_t blocks = (total_tasks + wpb - 1) / wpb;
+    *block = kBlock;
     *grid = (uint32_t)(blocks < full ? blocks : full);
 }
 
@@ -193,14 +195,16 @@ mcq_ctx *mcq_create(int device, int flags) {
     if (!c) { fail(MCQ_ENOMEM, "mcq_create: out of host memory"); return nullptr; }
     c->device = device;
     hipDeviceProp_t prop;
-    McqLuts luts;
-    mcq_fill_luts(&luts);
+    McqTables *tabs = new (std::nothrow) McqTables();
+    if (!tabs) { fail(MCQ_ENOMEM, "mcq_create: out of host memory"); delete c; return nullptr; }
+    mcq_fill_tables(tabs);
 #define CREATE_TRY(expr)                                                      \
     do {                                                                      \
         hipError_t e2_ = (expr);                                              \
         if (e2_ != hipSuccess) {                                              \
             fail(MCQ_EDEVICE, #expr, hipGetErrorString(e2_));                 \
             mcq_destroy(c);                                                   \
+            delete tabs;                                                      \
             return nullptr;                                                   \
         }                                                                     \
     } while (0)
@@ -212,14 +216,15 @@ mcq_ctx *mcq_create(int device, int flags) {
         CREATE_TRY(hipEventCreate(&c->ev0[i]));
         CREATE_TRY(hipEventCreate(&c->ev1[i]));
     }
-    CREATE_TRY(hipMalloc((void **)&c->d_luts, sizeof(McqLuts)));
-    CREATE_TRY(hipMemcpy(c->d_luts, &luts, sizeof(McqLuts), hipMemcpyHostToDevice));
+    CREATE_TRY(hipMalloc((void **)&c->d_luts, sizeof(McqTables)));
+    CREATE_TRY(hipMemcpy(c->d_luts, tabs, sizeof(McqTables), hipMemcpyHostToDevice));
     for (int mode = 0; mode < 2; mode++) {
         int occ = 0;
-        CREATE_TRY(mcq_eval_occupancy(mode, 256, &occ));
-        c->occ256[mode] = occ < 1 ? 1 : (occ > 8 ? 8 : occ);
+        CREATE_TRY(mcq_eval_occupancy(mode, (int)kBlock, &occ));
+        c->occ[mode] = occ < 1 ? 1 : (occ > 8 ? 8 : occ);
     }
 #undef CREATE_TRY
+    delete tabs;
     return c;
 }
 

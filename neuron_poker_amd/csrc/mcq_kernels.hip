@@ -15,22 +15,27 @@
 
 namespace {
 
-constexpr int kMaxBlock = 256;
-
-struct LdsStore { /* opponents' cards of this lane, [opponent][lane-in-block] -> conflict-free b64 accesses */
-    uint2 *base;
-    __device__ __forceinline__ void put(uint32_t p, uint32_t lo, uint32_t hi) { base[p * kMaxBlock] = make_uint2(lo, hi); }
-    __device__ __forceinline__ void get(uint32_t p, uint32_t &lo, uint32_t &hi) {
-        uint2 v = base[p * kMaxBlock];
-        lo = v.x;
-        hi = v.y;
-    }
-};
+constexpr int kMaxBlock = 512; /* 8 waves; two blocks per CU share 160 KB of LDS (tables 57 KB + base decks 8 KB each) */
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
+}
+
+struct LdsTables { /* per block */
+    uint32_t tf[8192];
+    uint16_t top2[8192];
+    uint8_t str[8192];
+    uint32_t sel8[256];
+};
+static_assert(sizeof(LdsTables) == sizeof(McqTables), "table image is copied word by word");
+
+__device__ __forceinline__ void load_tables(LdsTables &dst, const McqTables *__restrict__ g) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(g);
+    uint4 *d = reinterpret_cast<uint4 *>(&dst);
+    for (uint32_t i = threadIdx.x; i < sizeof(LdsTables) / 16; i += blockDim.x) d[i] = src[i];
+    __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------- prep
@@ -74,28 +79,22 @@ __global__ __launch_bounds__(1024) void mcq_prep_kernel(const mcq_query *__restr
 
 // ---------------------------------------------------------------------------------------------- eval
 template <int MODE>
-__global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__restrict__ queries, uint32_t n,
-                                                             const uint32_t *__restrict__ prefix,
-                                                             mcq_result *__restrict__ res, uint64_t seed,
-                                                             uint64_t first_qid, const McqLuts *__restrict__ g_luts,
-                                                             const uint8_t *__restrict__ draws,
-                                                             const uint64_t *__restrict__ draw_off) {
-    __shared__ McqLuts luts;
-    __shared__ uint2 opp[MCQ_MAX_OPP * kMaxBlock];
-
-    {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(g_luts);
-        uint32_t *dst = reinterpret_cast<uint32_t *>(&luts);
-        for (uint32_t i = threadIdx.x; i < sizeof(McqLuts) / 4; i += blockDim.x) dst[i] = src[i];
-    }
-    __syncthreads();
+__global__ __launch_bounds__(kMaxBlock, 4) void mcq_eval_kernel(const mcq_query *__restrict__ queries, uint32_t n,
+                                                                const uint32_t *__restrict__ prefix,
+                                                                mcq_result *__restrict__ res, uint64_t seed,
+                                                                uint64_t first_qid, const McqTables *__restrict__ g_tab,
+                                                                const uint8_t *__restrict__ draws,
+                                                                const uint64_t *__restrict__ draw_off) {
+    __shared__ __attribute__((aligned(16))) LdsTables tab;
+    __shared__ McqCard base_tab[kMaxBlock]; /* per wave: the query's ordered remaining deck, 64 entries x 16 B */
+    load_tables(tab, g_tab);
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t waves_per_block = blockDim.x >> 6;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * waves_per_block + (threadIdx.x >> 6));
     const uint32_t n_waves = gridDim.x * waves_per_block;
     const uint32_t total = prefix[n];
-    LdsStore st = {opp + threadIdx.x};
+    McqCard *base = base_tab + (threadIdx.x & ~63u);
 
     for (uint32_t t = wave; t < total; t += n_waves) {
         /* query of task t: last q with prefix[q] <= t (wave-uniform binary search, scalar loads) */
@@ -109,7 +108,11 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
         const uint4 raw = reinterpret_cast<const uint4 *>(queries)[qi];
         const McqQueryWords q = {raw.x, raw.y, raw.z, raw.w};
         McqQueryCtx qc;
-        mcq_query_ctx(q, luts.suit_lo, luts.suit_hi, qc);
+        mcq_query_ctx(q, qc);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); /* the previous task's lookups are done (same wave) */
+        base[lane] = mcq_base_entry(qc, lane, tab.sel8);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 
         McqLaneAcc acc = {0, 0, 0};
         if (MODE == MCQ_MODE_PHILOX) {
@@ -119,17 +122,16 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
                 McqCtrDraws dr;
                 dr.rng.seed(seed, first_qid + qi, stream);
                 const uint32_t cnt = (uint32_t)min((uint64_t)MCQ_STREAM_ITERS, (uint64_t)qc.runs - it0);
-                for (uint32_t j = 0; j < cnt; j++)
-                    mcq_iteration(qc, dr, luts.sel8, luts.suit_lo, luts.suit_hi, st, acc);
+                for (uint32_t j = 0; j < cnt; j++) mcq_iteration(qc, dr, base, tab.tf, tab.top2, tab.str, acc);
             }
         } else {
             const uint64_t stride = (qc.runs + 63u) & ~63ull;
-            const uint8_t *base = draws + draw_off[qi];
+            const uint8_t *dbase = draws + draw_off[qi];
             for (uint32_t j = 0; j < MCQ_STREAM_ITERS; j++) {
                 const uint64_t it = (uint64_t)task * MCQ_TASK_ITERS + j * MCQ_WAVE + lane;
                 if (it < qc.runs) {
-                    McqReplayDraws dr = {base + it, stride};
-                    mcq_iteration(qc, dr, luts.sel8, luts.suit_lo, luts.suit_hi, st, acc);
+                    McqReplayDraws dr = {dbase + it, stride};
+                    mcq_iteration(qc, dr, base, tab.tf, tab.top2, tab.str, acc);
                 }
             }
             acc.passes = 0; /* counted by the host while parsing the MT19937 stream */
@@ -139,10 +141,11 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
         uint32_t wins = 0;
         uint64_t mine = 0;
 #pragma unroll
-        for (int ty = 0; ty < 9; ty++) {
-            uint32_t v = wave_sum((uint32_t)(acc.types >> (6 * ty)) & 63u);
+        for (uint32_t code = 0; code < MCQ_N_CODES; code++) {
+            if (code == 5) continue;
+            uint32_t v = wave_sum((uint32_t)(acc.types >> (6 * code)) & 63u);
             wins += v;
-            if (lane == 3u + ty) mine = v;
+            if (lane == 3u + mcq_code_to_type(code)) mine = v;
         }
         const uint32_t ties = wave_sum(acc.tie);
         const uint32_t passes = wave_sum(acc.passes);
@@ -156,33 +159,29 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
 
 // ---------------------------------------------------------------------------------------------- showdown
 __global__ __launch_bounds__(256) void mcq_showdown_kernel(const uint8_t *__restrict__ hands, uint32_t n_tables,
-                                                           uint32_t n_players, const McqLuts *__restrict__ g_luts,
+                                                           uint32_t n_players, const McqTables *__restrict__ g_tab,
                                                            uint8_t *__restrict__ winner, uint8_t *__restrict__ wtype,
                                                            uint32_t *__restrict__ keys) {
-    __shared__ McqLuts luts;
-    {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(g_luts);
-        uint32_t *dst = reinterpret_cast<uint32_t *>(&luts);
-        for (uint32_t i = threadIdx.x; i < sizeof(McqLuts) / 4; i += blockDim.x) dst[i] = src[i];
-    }
-    __syncthreads();
+    __shared__ __attribute__((aligned(16))) LdsTables tab;
+    load_tables(tab, g_tab);
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_tables; t += gridDim.x * blockDim.x) {
         uint32_t best = 0, w = 0;
         for (uint32_t p = 0; p < n_players; p++) {
             const uint8_t *h = hands + ((size_t)t * n_players + p) * 7;
-            uint32_t lo = 0, hi = 0;
+            McqBoard b;
+            b.clear();
 #pragma unroll
-            for (int k = 0; k < 7; k++) {
-                uint32_t c = h[k] & 63u;
-                lo |= luts.suit_lo[c];
-                hi |= luts.suit_hi[c];
-            }
-            uint32_t key = mcq_eval7(lo, hi);
+            for (int k = 2; k < 7; k++) b.add(mcq_card(h[k] < 52 ? h[k] : 0));
+            McqHole hole;
+            hole.set(mcq_card(h[0] < 52 ? h[0] : 0), mcq_card(h[1] < 52 ? h[1] : 0));
+            McqFlushSel fs;
+            fs.from_board(b);
+            const uint32_t key = mcq_eval_key(b, fs, hole, tab.tf, tab.top2, tab.str);
             if (keys) keys[(size_t)t * n_players + p] = key;
             if (key > best) { best = key; w = p; } /* strict: the first of equal hands stays (hand_evaluator.py:23) */
         }
         winner[t] = (uint8_t)w;
-        wtype[t] = (uint8_t)(best >> 28);
+        wtype[t] = (uint8_t)mcq_key_type(best);
     }
 }
 
@@ -195,7 +194,7 @@ hipError_t mcq_launch_prep(const mcq_query *d_q, uint32_t n, mcq_result *d_res, 
 }
 
 hipError_t mcq_launch_eval(int mode, const mcq_query *d_q, uint32_t n, const uint32_t *d_prefix, mcq_result *d_res,
-                           uint64_t seed, uint64_t first_qid, const McqLuts *d_luts, const uint8_t *d_draws,
+                           uint64_t seed, uint64_t first_qid, const McqTables *d_luts, const uint8_t *d_draws,
                            const uint64_t *d_draw_off, uint32_t grid, uint32_t block, hipStream_t s) {
     if (mode == MCQ_MODE_PHILOX)
         hipLaunchKernelGGL(mcq_eval_kernel<MCQ_MODE_PHILOX>, dim3(grid), dim3(block), 0, s, d_q, n, d_prefix, d_res,
@@ -206,7 +205,7 @@ hipError_t mcq_launch_eval(int mode, const mcq_query *d_q, uint32_t n, const uin
     return hipGetLastError();
 }
 
-hipError_t mcq_launch_showdown(const uint8_t *d_hands, uint32_t n_tables, uint32_t n_players, const McqLuts *d_luts,
+hipError_t mcq_launch_showdown(const uint8_t *d_hands, uint32_t n_tables, uint32_t n_players, const McqTables *d_luts,
                                uint8_t *d_winner, uint8_t *d_wtype, uint32_t *d_keys, hipStream_t s) {
     uint32_t grid = (n_tables + 255) / 256;
     if (grid > 4096) grid = 4096;

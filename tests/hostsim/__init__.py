@@ -36,6 +36,12 @@ def eval7(cards):
     return keys
 
 
+def key_type(keys):
+    """by_type index of internal ranking keys (bits 27.. hold a code with a gap at 5)."""
+    code = np.asarray(keys, np.uint32) >> 27
+    return (code - (code >= 6)).astype(np.uint32)
+
+
 def run_ctr(query16, seed, qid):
     q = np.ascontiguousarray(query16, np.uint8)
     out = np.zeros(13, np.uint64)

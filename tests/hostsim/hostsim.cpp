@@ -13,22 +13,21 @@
 #include "../../neuron_poker_amd/csrc/mcq_replay.hpp"
 
 namespace {
-struct ArrayStore {
-    uint32_t lo[MCQ_MAX_OPP], hi[MCQ_MAX_OPP];
-    void put(uint32_t p, uint32_t l, uint32_t h) { lo[p] = l; hi[p] = h; }
-    void get(uint32_t p, uint32_t &l, uint32_t &h) { l = lo[p]; h = hi[p]; }
-};
-McqLuts g_luts;
+McqTables g_tab;
 bool g_init = false;
-const McqLuts &luts() {
-    if (!g_init) { mcq_fill_luts(&g_luts); g_init = true; }
-    return g_luts;
+const McqTables &luts() {
+    if (!g_init) { mcq_fill_tables(&g_tab); g_init = true; }
+    return g_tab;
+}
+void make_base(const McqQueryCtx &qc, const McqTables &t, McqCard *base) {
+    for (uint32_t l = 0; l < 64; l++) base[l] = mcq_base_entry(qc, l, t.sel8);
 }
 void fold(const McqLaneAcc &a, mcq_result *r) {
     uint64_t wins = 0;
-    for (int t = 0; t < 9; t++) {
-        uint64_t v = (a.types >> (6 * t)) & 63;
-        r->by_type[t] += v;
+    for (uint32_t c = 0; c < MCQ_N_CODES; c++) {
+        if (c == 5) continue;
+        uint64_t v = (a.types >> (6 * c)) & 63;
+        r->by_type[mcq_code_to_type(c)] += v;
         wins += v;
     }
     r->tie += a.tie;
@@ -41,14 +40,21 @@ extern "C" {
 
 int hs_query_valid(const mcq_query *q) { return mcq_query_valid(mcq_query_words(*q)) ? 1 : 0; }
 
+// keys of 7-card hands: cards 0,1 = hole, 2..6 = table (the split does not matter for the key)
 void hs_eval7(const uint8_t *cards, size_t n, uint32_t *keys) {
-    const McqLuts &t = luts();
+    const McqTables &t = luts();
     for (size_t i = 0; i < n; i++) {
-        uint32_t lo = 0, hi = 0;
-        for (int k = 0; k < 7; k++) { lo |= t.suit_lo[cards[7 * i + k]]; hi |= t.suit_hi[cards[7 * i + k]]; }
-        keys[i] = mcq_eval7(lo, hi);
+        McqBoard b;
+        b.clear();
+        for (int k = 2; k < 7; k++) b.add(mcq_card(cards[7 * i + k]));
+        McqHole h;
+        h.set(mcq_card(cards[7 * i]), mcq_card(cards[7 * i + 1]));
+        McqFlushSel fs;
+        fs.from_board(b);
+        keys[i] = mcq_eval_key(b, fs, h, t.tf, t.top2, t.str);
     }
 }
+uint32_t hs_key_type(uint32_t key) { return mcq_key_type(key); }
 
 uint32_t hs_select_pop(uint32_t *dlo, uint32_t *dhi, uint32_t k) { return mcq_select_pop(*dlo, *dhi, k, luts().sel8); }
 
@@ -59,9 +65,11 @@ void hs_philox(const uint32_t *ctr, const uint32_t *key, uint32_t *out) {
 // production mode, lane/stream decomposition exactly as the kernel: lane <-> stream of 16 iterations
 int hs_run_ctr(const mcq_query *q, uint64_t seed, uint64_t qid, mcq_result *out) {
     if (!mcq_query_valid(mcq_query_words(*q))) return MCQ_EINVAL;
-    const McqLuts &t = luts();
+    const McqTables &t = luts();
     McqQueryCtx qc;
-    mcq_query_ctx(mcq_query_words(*q), t.suit_lo, t.suit_hi, qc);
+    mcq_query_ctx(mcq_query_words(*q), qc);
+    McqCard base[64];
+    make_base(qc, t, base);
     memset(out, 0, sizeof(*out));
     out->runs = q->runs;
     uint32_t n_streams = (q->runs + MCQ_STREAM_ITERS - 1) / MCQ_STREAM_ITERS;
@@ -69,10 +77,9 @@ int hs_run_ctr(const mcq_query *q, uint64_t seed, uint64_t qid, mcq_result *out)
         McqCtrDraws dr;
         dr.rng.seed(seed, qid, s);
         McqLaneAcc acc = {0, 0, 0};
-        ArrayStore st;
         for (uint32_t j = 0; j < MCQ_STREAM_ITERS; j++) {
             if ((uint64_t)s * MCQ_STREAM_ITERS + j >= q->runs) break;
-            mcq_iteration(qc, dr, t.sel8, t.suit_lo, t.suit_hi, st, acc);
+            mcq_iteration(qc, dr, base, t.tf, t.top2, t.str, acc);
         }
         fold(acc, out);
     }
@@ -82,9 +89,11 @@ int hs_run_ctr(const mcq_query *q, uint64_t seed, uint64_t qid, mcq_result *out)
 // parity mode: host parse of the MT19937 stream + the same lane arithmetic
 int hs_run_replay(const mcq_query *q, uint32_t seed32, mcq_result *out) {
     if (!mcq_query_valid(mcq_query_words(*q))) return MCQ_EINVAL;
-    const McqLuts &t = luts();
+    const McqTables &t = luts();
     McqQueryCtx qc;
-    mcq_query_ctx(mcq_query_words(*q), t.suit_lo, t.suit_hi, qc);
+    mcq_query_ctx(mcq_query_words(*q), qc);
+    McqCard base[64];
+    make_base(qc, t, base);
     memset(out, 0, sizeof(*out));
     out->runs = q->runs;
     size_t stride = q->runs ? q->runs : 1;
@@ -93,8 +102,7 @@ int hs_run_replay(const mcq_query *q, uint32_t seed32, mcq_result *out) {
     for (uint32_t it = 0; it < q->runs; it++) {
         McqReplayDraws dr = {draws.data() + it, stride};
         McqLaneAcc acc = {0, 0, 0};
-        ArrayStore st;
-        mcq_iteration(qc, dr, t.sel8, t.suit_lo, t.suit_hi, st, acc);
+        mcq_iteration(qc, dr, base, t.tf, t.top2, t.str, acc);
         acc.passes = 0;
         fold(acc, out);
     }

@@ -48,7 +48,7 @@ def test_keys_reproduce_reference_categories_and_order(eng):
     cards, cat, nr, ranks = z["cards"], z["category"], z["n_ranks"], z["card_ranks"]
     _, _, keys = eng.showdown(cards.reshape(-1, 1, 7), want_keys=True)
     keys = keys.reshape(-1)
-    assert np.array_equal(keys >> 28, cat)
+    assert np.array_equal(npa.key_type(keys), cat)
     tup = [(int(cat[i]), tuple(int(x) for x in ranks[i, :nr[i]])) for i in range(len(cards))]
     order = np.argsort(keys, kind="stable")
     for a, b in zip(order[:-1], order[1:]):

@@ -36,7 +36,7 @@ def test_select_pop_matches_list_pop():
 def test_key_category_matches_reference_fixture():
     z = np.load(os.path.join(G, "evaluator_hands.npz"))
     keys = H.eval7(z["cards"])
-    assert np.array_equal(keys >> 28, z["category"])
+    assert np.array_equal(H.key_type(keys), z["category"])
 
 
 def test_key_order_matches_reference_tuple_order():
@@ -65,7 +65,7 @@ def test_showdowns_fixture_with_keys():
     for i in range(len(hands)):
         k = H.eval7(hands[i, :n[i]])
         w = int(np.argmax(k))  # first of the maxima
-        assert (w, k[w] >> 28) == (win[i], wt[i]), i
+        assert (w, H.key_type(k[w])) == (win[i], wt[i]), i
 
 
 def test_reference_evaluator_cases_without_duplicates():
@@ -77,7 +77,7 @@ def test_reference_evaluator_cases_without_duplicates():
             continue  # duplicate cards (tests/test_evaluator.py:27,63) are outside the kernel's domain
         k = H.eval7(ids)
         w = int(np.argmax(k))
-        assert w == c["winner"] and O.TYPES[k[w] >> 28] == c["winner_type"], c
+        assert w == c["winner"] and O.TYPES[H.key_type(k[w])] == c["winner_type"], c
 
 
 def test_mt_and_philox_restated_identically():
