@@ -98,6 +98,7 @@ struct McqTables {
     uint16_t top2[8192];
     uint8_t str[8192];
     uint32_t sel8[256];
+    uint32_t inv[64]; /* inv[d] = 2^20 / d + 1 (d >= 1) */
 };
 
 static inline void mcq_fill_tables(McqTables *t) {
@@ -107,6 +108,8 @@ static inline void mcq_fill_tables(McqTables *t) {
             if (v >> b & 1) e |= b << (3 * j++);
         t->sel8[v] = e;
     }
+    t->inv[0] = 0;
+    for (uint32_t d = 1; d < 64; d++) t->inv[d] = (1u << 20) / d + 1u;
     for (uint32_t m = 0; m < 8192; m++) {
         uint32_t runs = mcq_straight_runs(m);
         t->str[m] = runs ? (uint8_t)(0x80u | (32u - (uint32_t)__builtin_clz(runs))) : 0;
@@ -169,18 +172,36 @@ struct McqXoshiro { /* xoshiro128++ (Blackman & Vigna) */
     }
 };
 
-// Draw policy of the production mode: same procedure as montecarlo_python.py:165-176 / :188 with
-// mulhi32(word, n) in place of numpy's masked rejection.
+// Draw policy of the production mode, "MCQ-CTR v2": the reference's dealing law without its re-draw loop.
+//   Opponent pair on a deck of length L from ONE word u: x = mulhi32(u, (L-1)^2), a = x / (L-1), c = x % (L-1);
+//   (r1, r2) = (a, c) if a != c else (L-1, a).  That is a bijection from [0, (L-1)^2) onto the pairs the
+//   reference accepts (r1 in [0,L), r2 in [0,L-1), r1 != r2; montecarlo_python.py:167-176), so every accepted
+//   pair is as likely as after the reference's rejection loop, with no divergent loop on the GPU.  No attempt
+//   is ever rejected, hence `passes` = one per opponent per iteration (added by the caller).
+//   Table cards, two per word: even draw: u = next(), idx = mulhi32(u, n), w = u * n; odd draw: idx = mulhi32(w, n)
+//   (n = deck length - 1: never the last card, montecarlo_python.py:188).  Bias of either <= 2401 / 2^32.
+// inv[d] = 2^20 / d + 1 makes (x * inv[d]) >> 20 == x / d exactly for x < d * d <= 2601 (checked in the tests).
 struct McqCtrDraws {
     McqXoshiro rng;
-    MCQ_HDM void pair(uint32_t L, uint32_t &r1, uint32_t &r2, uint32_t &passes) {
-        do {
-            passes++;
-            r1 = mcq_mulhi(rng.next(), L);
-            r2 = mcq_mulhi(rng.next(), L - 1);
-        } while (r1 == r2);
+    uint32_t w;
+    MCQ_HDM void pair(uint32_t L, const uint32_t *inv, uint32_t &r1, uint32_t &r2) {
+        const uint32_t dd = L - 1u;
+        const uint32_t x = mcq_mulhi(rng.next(), dd * dd);
+        const uint32_t a = (x * inv[dd]) >> 20;
+        const uint32_t c = x - a * dd;
+        const uint32_t eq = (uint32_t)((int32_t)((a ^ c) - 1u) >> 31); /* all ones iff a == c */
+        r1 = a ^ ((a ^ dd) & eq);
+        r2 = c;
     }
-    MCQ_HDM uint32_t single(uint32_t n) { return mcq_mulhi(rng.next(), n); }
+    template <int K>
+    MCQ_HDM uint32_t table(uint32_t n) {
+        if ((K & 1) == 0) {
+            const uint32_t u = rng.next();
+            w = u * n;
+            return mcq_mulhi(u, n);
+        }
+        return mcq_mulhi(w, n);
+    }
 };
 
 // Draw policy of the parity mode: the host has already turned the MT19937 stream into the accepted draw
@@ -189,12 +210,13 @@ struct McqCtrDraws {
 struct McqReplayDraws {
     const uint8_t *p; /* &draws[iteration] */
     uint64_t stride;
-    MCQ_HDM void pair(uint32_t, uint32_t &r1, uint32_t &r2, uint32_t &) {
+    MCQ_HDM void pair(uint32_t, const uint32_t *, uint32_t &r1, uint32_t &r2) {
         r1 = p[0];
         r2 = p[stride];
         p += 2 * stride;
     }
-    MCQ_HDM uint32_t single(uint32_t) {
+    template <int K>
+    MCQ_HDM uint32_t table(uint32_t) {
         uint32_t v = p[0];
         p += stride;
         return v;
@@ -485,7 +507,7 @@ MCQ_HD uint32_t mcq_draw_table(uint32_t r, uint32_t (&H)[5], uint32_t &hb, uint3
 // ALL opponents before any table card (montecarlo_python.py:215-217).
 template <class Draws>
 MCQ_HD void mcq_iteration(const McqQueryCtx &qc, Draws &dr, const McqCard *base, const uint32_t *tf,
-                          const uint16_t *top2, const uint8_t *str, McqLaneAcc &acc) {
+                          const uint16_t *top2, const uint8_t *str, const uint32_t *inv, McqLaneAcc &acc) {
     uint32_t H[5] = {MCQ_HOLE_SENTINEL, MCQ_HOLE_SENTINEL, MCQ_HOLE_SENTINEL, MCQ_HOLE_SENTINEL, MCQ_HOLE_SENTINEL};
     uint32_t hb = MCQ_HOLE_SENTINEL;
     uint32_t L = qc.L0;
@@ -493,7 +515,7 @@ MCQ_HD void mcq_iteration(const McqQueryCtx &qc, Draws &dr, const McqCard *base,
 #define MCQ_OPP(P)                                                                                             \
     if (P < qc.n_opp) {                                                                                        \
         uint32_t r1, r2;                                                                                       \
-        dr.pair(L, r1, r2, acc.passes); /* r1 in [0,L-1], r2 in [0,L-2], r1 != r2 (l.167-176) */               \
+        dr.pair(L, inv, r1, r2); /* r1 in [0,L-1], r2 in [0,L-2], r1 != r2 (l.167-176) */                      \
         const McqCard c1 = base[mcq_draw_opp<2 * P>(r1, H)];     /* deck.pop(r1) (l.178) */                    \
         const McqCard c2 = base[mcq_draw_opp<2 * P + 1>(r2, H)]; /* deck.pop(r2) on the shrunk list (l.179) */ \
         opp[P].set(c1, c2);                                                                                    \
@@ -505,7 +527,7 @@ MCQ_HD void mcq_iteration(const McqQueryCtx &qc, Draws &dr, const McqCard *base,
     McqBoard b = qc.board;
 #define MCQ_TABLE(K)                                                                                           \
     if (K < qc.n_deal) {                                                                                       \
-        b.add(base[mcq_draw_table<K>(dr.single(L - 1), H, hb, n_regs)]); /* never the last card (l.188) */     \
+        b.add(base[mcq_draw_table<K>(dr.template table<K>(L - 1), H, hb, n_regs)]); /* never the last card (l.188) */ \
         L -= 1;                                                                                                \
     }
     MCQ_TABLE(0) MCQ_TABLE(1) MCQ_TABLE(2) MCQ_TABLE(3) MCQ_TABLE(4)

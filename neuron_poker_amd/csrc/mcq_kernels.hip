@@ -28,6 +28,7 @@ struct LdsTables { /* per block */
     uint16_t top2[8192];
     uint8_t str[8192];
     uint32_t sel8[256];
+    uint32_t inv[64];
 };
 static_assert(sizeof(LdsTables) == sizeof(McqTables), "table image is copied word by word");
 
@@ -120,9 +121,12 @@ __global__ __launch_bounds__(kMaxBlock, 4) void mcq_eval_kernel(const mcq_query 
             const uint64_t it0 = (uint64_t)stream * MCQ_STREAM_ITERS;
             if (it0 < qc.runs) {
                 McqCtrDraws dr;
+                dr.w = 0;
                 dr.rng.seed(seed, first_qid + qi, stream);
                 const uint32_t cnt = (uint32_t)min((uint64_t)MCQ_STREAM_ITERS, (uint64_t)qc.runs - it0);
-                for (uint32_t j = 0; j < cnt; j++) mcq_iteration(qc, dr, base, tab.tf, tab.top2, tab.str, acc);
+                for (uint32_t j = 0; j < cnt; j++)
+                    mcq_iteration(qc, dr, base, tab.tf, tab.top2, tab.str, tab.inv, acc);
+                acc.passes = cnt * qc.n_opp; /* MCQ-CTR v2: one attempt per opponent, never re-drawn */
             }
         } else {
             const uint64_t stride = (qc.runs + 63u) & ~63ull;
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(kMaxBlock, 4) void mcq_eval_kernel(const mcq_query 
                 const uint64_t it = (uint64_t)task * MCQ_TASK_ITERS + j * MCQ_WAVE + lane;
                 if (it < qc.runs) {
                     McqReplayDraws dr = {dbase + it, stride};
-                    mcq_iteration(qc, dr, base, tab.tf, tab.top2, tab.str, acc);
+                    mcq_iteration(qc, dr, base, tab.tf, tab.top2, tab.str, tab.inv, acc);
                 }
             }
             acc.passes = 0; /* counted by the host while parsing the MT19937 stream */

@@ -84,9 +84,14 @@ static uint32_t np_randint(mt_t *s, uint32_t n) {
 }
 
 /* ------------------------------------------------------- counter-based front end (product's CTR mode) */
-/* Spec (DESIGN.md "MCQ-CTR v1"): iterations are grouped in streams of 16; stream s of query id q under
- * seed k starts xoshiro128++ from Philox4x32-10(counter = {q_lo, q_hi, s, 'MCQ1'}, key = {k_lo, k_hi});
- * a bounded draw is mulhi32(next(), n). */
+/* Spec (DESIGN.md "MCQ-CTR v2"): iterations are grouped in streams of 16; stream s of query id q under
+ * seed k starts xoshiro128++ from Philox4x32-10(counter = {q_lo, q_hi, s, 'MCQ1'}, key = {k_lo, k_hi}).
+ * Opponent pair on a deck of length L, ONE word u: x = mulhi32(u, (L-1)^2), a = x / (L-1), c = x % (L-1);
+ * (r1, r2) = (a, c) if a != c else (L-1, a) -- a bijection onto the pairs the reference accepts
+ * (r1 in [0,L), r2 in [0,L-1), r1 != r2), so they are equally likely exactly as after its re-draw loop
+ * (montecarlo_python.py:167-176); no re-draw happens, so `passes` counts one attempt per opponent.
+ * Table cards, two per word: even draw K: u = next(), idx = mulhi32(u, n), w = u * n (mod 2^32);
+ * odd draw: idx = mulhi32(w, n)   (n = current deck length - 1, montecarlo_python.py:188). */
 #define STREAM_ITERS 16u
 
 static void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
@@ -335,7 +340,16 @@ static uint32_t deal_iteration(rng_t *rng, const uint8_t hero[2], const uint8_t 
     hole[0][0] = hero[0]; hole[0][1] = hero[1];
     deck_remove(&d, hero[0]); /* l.154-161 */
     deck_remove(&d, hero[1]);
-    for (int p = 1; p < n_players; p++) { /* l.165-181 */
+    for (int p = 1; p < n_players && rng->kind == 1; p++) { /* MCQ-CTR v2 */
+        uint32_t dd = (uint32_t)d.n - 1;
+        uint32_t x = (uint32_t)(((uint64_t)xo_next(rng->xo) * (dd * dd)) >> 32);
+        uint32_t a = x / dd, c = x % dd;
+        uint32_t r1 = a != c ? a : dd, r2 = a != c ? c : a;
+        passes++;
+        hole[p][0] = deck_pop(&d, (int)r1);
+        hole[p][1] = deck_pop(&d, (int)r2);
+    }
+    for (int p = 1; p < n_players && rng->kind == 0; p++) { /* l.165-181 */
         uint32_t r1, r2;
         for (;;) {
             passes++;
@@ -346,7 +360,21 @@ static uint32_t deal_iteration(rng_t *rng, const uint8_t hero[2], const uint8_t 
         hole[p][0] = deck_pop(&d, (int)r1);
         hole[p][1] = deck_pop(&d, (int)r2);
     }
-    for (int k = nb; k < 5; k++) table[k] = deck_pop(&d, (int)draw(rng, (uint32_t)d.n - 1)); /* l.186-188 */
+    if (rng->kind == 0) {
+        for (int k = nb; k < 5; k++) table[k] = deck_pop(&d, (int)draw(rng, (uint32_t)d.n - 1)); /* l.186-188 */
+    } else {
+        uint32_t w = 0;
+        for (int k = nb; k < 5; k++) {
+            uint32_t n = (uint32_t)d.n - 1;
+            if (((k - nb) & 1) == 0) {
+                uint32_t u = xo_next(rng->xo);
+                table[k] = deck_pop(&d, (int)(((uint64_t)u * n) >> 32));
+                w = u * n;
+            } else {
+                table[k] = deck_pop(&d, (int)(((uint64_t)w * n) >> 32));
+            }
+        }
+    }
     for (int p = 0; p < n_players; p++) { /* l.218-220 */
         hands[7 * p] = hole[p][0];
         hands[7 * p + 1] = hole[p][1];

@@ -75,11 +75,13 @@ int hs_run_ctr(const mcq_query *q, uint64_t seed, uint64_t qid, mcq_result *out)
     uint32_t n_streams = (q->runs + MCQ_STREAM_ITERS - 1) / MCQ_STREAM_ITERS;
     for (uint32_t s = 0; s < n_streams; s++) {
         McqCtrDraws dr;
+        dr.w = 0;
         dr.rng.seed(seed, qid, s);
         McqLaneAcc acc = {0, 0, 0};
         for (uint32_t j = 0; j < MCQ_STREAM_ITERS; j++) {
             if ((uint64_t)s * MCQ_STREAM_ITERS + j >= q->runs) break;
-            mcq_iteration(qc, dr, base, t.tf, t.top2, t.str, acc);
+            mcq_iteration(qc, dr, base, t.tf, t.top2, t.str, t.inv, acc);
+            acc.passes += qc.n_opp; /* MCQ-CTR v2: one attempt per opponent, never re-drawn */
         }
         fold(acc, out);
     }
@@ -102,7 +104,7 @@ int hs_run_replay(const mcq_query *q, uint32_t seed32, mcq_result *out) {
     for (uint32_t it = 0; it < q->runs; it++) {
         McqReplayDraws dr = {draws.data() + it, stride};
         McqLaneAcc acc = {0, 0, 0};
-        mcq_iteration(qc, dr, base, t.tf, t.top2, t.str, acc);
+        mcq_iteration(qc, dr, base, t.tf, t.top2, t.str, t.inv, acc);
         acc.passes = 0;
         fold(acc, out);
     }
@@ -114,4 +116,12 @@ void hs_mt_words(uint32_t seed, uint32_t n, uint32_t *out) {
     g.seed(seed);
     for (uint32_t i = 0; i < n; i++) out[i] = g.next();
 }
+}
+
+extern "C" int hs_check_inv(void) { /* (x * inv[d]) >> 20 == x / d for every x < d * d, d in [1, 51] */
+    const McqTables &t = luts();
+    for (uint32_t d = 1; d <= 51; d++)
+        for (uint32_t x = 0; x < d * d; x++)
+            if (((x * t.inv[d]) >> 20) != x / d) return (int)(d * 10000 + x);
+    return 0;
 }
