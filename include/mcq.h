@@ -104,7 +104,7 @@ MCQ_API int mcq_eval_batch_device(mcq_ctx *ctx, const void *d_queries, size_t n,
  * hands = n_tables x n_players x 7 card ids (host); winner[t] = index of the best hand (first of equals),
  * winner_type[t] = its by_type index, keys (optional, n_tables x n_players) = the 32-bit ranking keys: a
  * greater key is a stronger hand, equal keys tie; MCQ_KEY_TYPE(key) is the hand's by_type index. */
-#define MCQ_KEY_TYPE(key) (((key) >> 27) - (((key) >> 27) >= 6u ? 1u : 0u))
+#define MCQ_KEY_TYPE(key) (((key) >> 28) - (((key) >> 28) >= 6u ? 1u : 0u))
 MCQ_API int mcq_showdown(mcq_ctx *ctx, const uint8_t *hands, size_t n_tables, int n_players, uint8_t *winner,
                  uint8_t *winner_type, uint32_t *keys);
 

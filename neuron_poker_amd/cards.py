@@ -29,5 +29,5 @@ def card_str(cid):
 def key_type(keys):
     """by_type index of the 32-bit ranking keys returned by Engine.showdown (MCQ_KEY_TYPE in include/mcq.h)."""
     import numpy as np
-    code = np.asarray(keys, dtype=np.uint32) >> 27
+    code = np.asarray(keys, dtype=np.uint32) >> 28
     return (code - (code >= 6)).astype(np.uint32)

@@ -62,6 +62,15 @@ MCQ_HD uint32_t mcq_droplow(uint32_t m) { return m & (m - 1); }
 MCQ_HD uint32_t mcq_nz_mask(uint32_t x) { /* x < 2^31: all ones if x != 0 else 0, without compare/select */
     return (uint32_t)((int32_t)(0u - x) >> 31);
 }
+// Hide a value from the optimiser (device: pins it in a VGPR).  Used (a) to keep arithmetic masks as AND/XOR
+// instead of v_cmp + v_cndmask (8.6 vs 2.3 cycles) and (b) to keep wave-uniform operands out of SGPRs, which
+// would turn the 2.3-cycle VALU forms into 4.3-cycle ones.
+MCQ_HD uint32_t mcq_opaque(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(x));
+#endif
+    return x;
+}
 MCQ_HD uint32_t mcq_splat_byte(uint32_t x) { /* x < 256 -> x in all four bytes */
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_perm(0u, x, 0u); /* v_perm_b32: every selector byte 0 = byte 0 of x */
@@ -71,9 +80,11 @@ MCQ_HD uint32_t mcq_splat_byte(uint32_t x) { /* x < 256 -> x in all four bytes *
 }
 
 // ------------------------------------------------------------------------------------------ ranking keys
-// Internal key = code << 27 | field, unsigned order == Python's order of _calc_score's (score, card_ranks).
-// Codes leave a gap at 5 (history: lets a 16-bit flush table add 3 * flag); by_type index = code - (code >= 6).
-#define MCQ_KEY_SHIFT 27
+// Internal key = code << 28 | field, unsigned order == Python's order of _calc_score's (score, card_ranks).
+// Codes leave a gap at 5; by_type index = code - (code >= 6).  Rank masks live in the "x4 domain" (bit r+2 =
+// rank r) so that they are byte offsets into 32-bit LDS tables without a (slow) left shift; a field is
+// [13-bit mask << 15][13-bit mask << 2].
+#define MCQ_KEY_SHIFT 28
 enum { MCQ_C_HIGH = 0, MCQ_C_PAIR = 1, MCQ_C_TWOPAIR = 2, MCQ_C_TRIPS = 3, MCQ_C_STRAIGHT = 4, MCQ_C_FLUSH = 6,
        MCQ_C_FULL = 7, MCQ_C_QUADS = 8, MCQ_C_SF = 9, MCQ_N_CODES = 10 };
 MCQ_HD uint32_t mcq_code_to_type(uint32_t code) { return code - (code >= 6u ? 1u : 0u); } /* by_type index */
@@ -89,16 +100,19 @@ MCQ_HD uint32_t mcq_straight_runs(uint32_t m) {
 
 // ------------------------------------------------------------------------------------------ lookup tables (LDS)
 // sel8: only for laying out the per-query base deck (once per wave task).
-// str[m]  (m = 13-bit rank mask): 0 if m holds no straight, else 0x80 | (top position 1..10); key = str << 22.
-// top2[m]: the two highest set bits of m (0 if m has fewer than two).
-// tf[m]:   the complete key of the suit mask m: StraightFlush (all ranks of the suit plus the -1 slot when it
-//          holds the ace, hand_evaluator.py:71-80,93), Flush (top five, :98-100), or 0 when popcount(m) < 5.
+// All mask-indexed tables are addressed with x4-domain masks (m4 = m << 2):
+//   tops[m] (u32, byte offset m4):       top two set bits of m (x4 domain, 0 if fewer than two) | top bit << 16
+//   str[m]  (u8,  byte offset m4 >> 2):  0 if m holds no straight, else 0x80 | (top position 1..10); key = str << 23
+//   tf[m]   (u32, byte offset m4):       complete key of the SUIT mask m: StraightFlush (all ranks of the suit
+//           plus the -1 slot when it holds the ace, hand_evaluator.py:71-80,93), Flush (top five, :98-100), or 0
+//           when popcount(m) < 5
+//   inv[d]: 2^20 / d + 1, so that (x * inv[d]) >> 20 == x / d for x < d * d
 struct McqTables {
     uint32_t tf[8192];
-    uint16_t top2[8192];
+    uint32_t tops[8192];
     uint8_t str[8192];
     uint32_t sel8[256];
-    uint32_t inv[64]; /* inv[d] = 2^20 / d + 1 (d >= 1) */
+    uint32_t inv[64];
 };
 
 static inline void mcq_fill_tables(McqTables *t) {
@@ -114,12 +128,9 @@ static inline void mcq_fill_tables(McqTables *t) {
         uint32_t runs = mcq_straight_runs(m);
         t->str[m] = runs ? (uint8_t)(0x80u | (32u - (uint32_t)__builtin_clz(runs))) : 0;
         uint32_t n = (uint32_t)__builtin_popcount(m);
-        uint32_t hi2 = 0;
-        if (n >= 2) {
-            uint32_t a = 0x80000000u >> __builtin_clz(m);
-            hi2 = a | (0x80000000u >> __builtin_clz(m ^ a));
-        }
-        t->top2[m] = (uint16_t)hi2;
+        uint32_t hi1 = m ? 0x80000000u >> __builtin_clz(m) : 0, hi2 = 0;
+        if (n >= 2) hi2 = hi1 | (0x80000000u >> __builtin_clz(m ^ hi1));
+        t->tops[m] = (hi2 << 2) | (hi1 << 18);
         uint32_t key = 0;
         if (n >= 5) {
             if (runs) {
@@ -252,7 +263,7 @@ MCQ_HD uint32_t mcq_select_pop(uint32_t &dlo, uint32_t &dhi, uint32_t k, const u
 
 // One card as the evaluator wants it (16 bytes: one ds_read_b128 per dealt card).
 struct __attribute__((aligned(16))) McqCard {
-    uint32_t rb;  /* 1 << rank */
+    uint32_t rb;  /* 4 << rank (x4 domain) */
     uint32_t cnt; /* 1 << 4*suit: packed per-suit counters */
     uint32_t los; /* suit-major bit, pre-shifted left by 2 (tf[] byte offset): clubs bits 2..14, diamonds 18..30 */
     uint32_t his; /* hearts bits 2..14, spades bits 18..30 */
@@ -261,7 +272,7 @@ struct __attribute__((aligned(16))) McqCard {
 MCQ_HD McqCard mcq_card(uint32_t c) { /* c < 52 */
     const uint32_t rank = c >> 2, suit = c & 3u;
     McqCard e;
-    e.rb = 1u << rank;
+    e.rb = 4u << rank;
     e.cnt = 1u << (4u * suit);
     const uint32_t bit = 4u << (rank + 16u * (suit & 1u));
     e.los = suit < 2 ? bit : 0u;
@@ -312,10 +323,7 @@ struct McqFlushSel {
     }
 };
 
-// Table lookups by BYTE offset (masks are doubled / pre-shifted by the caller, never shifted left here).
-MCQ_HD uint32_t mcq_ld_u16(const uint16_t *t, uint32_t byte_off) {
-    return *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(t) + byte_off);
-}
+// Table lookups by BYTE offset (x4-domain masks; never shifted left here).
 MCQ_HD uint32_t mcq_ld_u32(const uint32_t *t, uint32_t byte_off) {
     return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(t) + byte_off);
 }
@@ -328,8 +336,9 @@ MCQ_HD uint32_t mcq_ld_u32(const uint32_t *t, uint32_t byte_off) {
 //       FullHouse (trips, best remaining pair or second trips, :36-38)
 //   straight (top rank decides, wheel lowest, :52-58), flush / straight flush (table tf), and
 //   FoufOfAKind = the two highest distinct ranks of all seven cards (:43-46).
+// All masks below are x4-domain.
 MCQ_HD uint32_t mcq_eval_key(const McqBoard &b, const McqFlushSel &fs, const McqHole &h, const uint32_t *tf,
-                             const uint16_t *top2, const uint8_t *str) {
+                             const uint32_t *tops, const uint8_t *str) {
 #ifdef MCQ_ABLATE_EVAL /* diagnostic timing build: wrong results */
     return (b.any ^ h.B ^ (h.los >> 3)) | (1u << MCQ_KEY_SHIFT);
 #endif
@@ -338,10 +347,11 @@ MCQ_HD uint32_t mcq_eval_key(const McqBoard &b, const McqFlushSel &fs, const Mcq
     const uint32_t ge3 = b.ge3 | (b.ge2 & h.B) | (b.any & h.P);
     const uint32_t eq4 = b.eq4 | (b.ge3 & h.B) | (b.ge2 & h.P);
 
-    /* straight */
-    const uint32_t key_s = (uint32_t)str[any] << 22;
-
-    /* flush / straight flush */
+    /* lookups first: their latency overlaps the arithmetic below */
+    const uint32_t e_any = mcq_ld_u32(tops, any);
+    const uint32_t e_ge2 = mcq_ld_u32(tops, ge2);
+    const uint32_t e_ge3 = mcq_ld_u32(tops, ge3);
+    const uint32_t s_any = str[any >> 2];
     uint32_t x = (h.los & fs.mlo) | (h.his & fs.mhi);
     x = (x | (x >> 16)) & 0xFFFFu;
     const uint32_t key_f = mcq_ld_u32(tf, fs.bfl4 | x);
@@ -351,18 +361,20 @@ MCQ_HD uint32_t mcq_eval_key(const McqBoard &b, const McqFlushSel &fs, const Mcq
     const uint32_t key1 = (ge2 << 13) | kick1 | ((0u - ge2) & (1u << MCQ_KEY_SHIFT)) | ((0u - ge3) & (2u << MCQ_KEY_SHIFT));
 
     /* F2 */
-    const uint32_t h2 = mcq_ld_u16(top2, ge2 + ge2);
-    const uint32_t t = mcq_topbit(ge3);
-    const uint32_t m3 = mcq_nz_mask(ge3);
+    const uint32_t m3 = mcq_opaque(mcq_nz_mask(ge3));
+    const uint32_t h2 = e_ge2 & 0xFFFFu, t = e_ge3 >> 16;
     const uint32_t H = h2 ^ ((h2 ^ t) & m3);
     const uint32_t R = (any ^ ((any ^ ge2) & m3)) ^ H;
-    const uint32_t mv = (uint32_t)((int32_t)((0u - H) & (0u - R)) >> 31);
+    const uint32_t kick2 = mcq_ld_u32(tops, R) >> 16;
+    const uint32_t mv = mcq_opaque((uint32_t)((int32_t)((0u - H) & (0u - R)) >> 31));
     const uint32_t c2 = ((uint32_t)MCQ_C_TWOPAIR << MCQ_KEY_SHIFT) +
                         (m3 & ((uint32_t)(MCQ_C_FULL - MCQ_C_TWOPAIR) << MCQ_KEY_SHIFT));
-    const uint32_t key2 = ((H << 13) | mcq_topbit(R) | c2) & mv;
+    const uint32_t key2 = ((H << 13) | kick2 | c2) & mv;
 
-    /* quads */
-    const uint32_t key4 = (mcq_ld_u16(top2, any + any) | ((uint32_t)MCQ_C_QUADS << MCQ_KEY_SHIFT)) & mcq_nz_mask(eq4);
+    /* quads, straight */
+    const uint32_t m4 = mcq_opaque(mcq_nz_mask(eq4));
+    const uint32_t key4 = ((e_any & 0xFFFFu) | ((uint32_t)MCQ_C_QUADS << MCQ_KEY_SHIFT)) & m4;
+    const uint32_t key_s = s_any << 23;
 
     uint32_t k = key1 > key2 ? key1 : key2;
     uint32_t k2 = key_s > key_f ? key_s : key_f;
@@ -507,7 +519,7 @@ MCQ_HD uint32_t mcq_draw_table(uint32_t r, uint32_t (&H)[5], uint32_t &hb, uint3
 // ALL opponents before any table card (montecarlo_python.py:215-217).
 template <class Draws>
 MCQ_HD void mcq_iteration(const McqQueryCtx &qc, Draws &dr, const McqCard *base, const uint32_t *tf,
-                          const uint16_t *top2, const uint8_t *str, const uint32_t *inv, McqLaneAcc &acc) {
+                          const uint32_t *tops, const uint8_t *str, const uint32_t *inv, McqLaneAcc &acc) {
     uint32_t H[5] = {MCQ_HOLE_SENTINEL, MCQ_HOLE_SENTINEL, MCQ_HOLE_SENTINEL, MCQ_HOLE_SENTINEL, MCQ_HOLE_SENTINEL};
     uint32_t hb = MCQ_HOLE_SENTINEL;
     uint32_t L = qc.L0;
@@ -534,11 +546,11 @@ MCQ_HD void mcq_iteration(const McqQueryCtx &qc, Draws &dr, const McqCard *base,
 #undef MCQ_TABLE
     McqFlushSel fs;
     fs.from_board(b);
-    const uint32_t hk = mcq_eval_key(b, fs, qc.hero, tf, top2, str);
+    const uint32_t hk = mcq_eval_key(b, fs, qc.hero, tf, tops, str);
     uint32_t best = 0;
 #define MCQ_EVAL(P)                                                        \
     if (P < qc.n_opp) {                                                    \
-        const uint32_t k = mcq_eval_key(b, fs, opp[P], tf, top2, str);     \
+        const uint32_t k = mcq_eval_key(b, fs, opp[P], tf, tops, str);     \
         best = k > best ? k : best;                                        \
     }
     MCQ_EVAL(0) MCQ_EVAL(1) MCQ_EVAL(2) MCQ_EVAL(3) MCQ_EVAL(4) MCQ_EVAL(5) MCQ_EVAL(6) MCQ_EVAL(7) MCQ_EVAL(8)

@@ -78,7 +78,7 @@ struct PinBuf {
 };
 
 constexpr size_t kReplayChunkBytes = 256u << 20; /* draw bytes staged per launch in parity mode */
-constexpr uint32_t kBlock = 512;                 /* threads per block of the evaluation kernels */
+constexpr uint32_t kBlock = 1024;                /* threads per block of the evaluation kernels */
 
 }  // namespace
 

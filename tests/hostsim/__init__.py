@@ -37,8 +37,8 @@ def eval7(cards):
 
 
 def key_type(keys):
-    """by_type index of internal ranking keys (bits 27.. hold a code with a gap at 5)."""
-    code = np.asarray(keys, np.uint32) >> 27
+    """by_type index of internal ranking keys (bits 28.. hold a code with a gap at 5)."""
+    code = np.asarray(keys, np.uint32) >> 28
     return (code - (code >= 6)).astype(np.uint32)
 
 
