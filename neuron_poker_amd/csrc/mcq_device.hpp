@@ -10,11 +10,13 @@
 //   tools/hand_evaluator.py:27-119      _calc_score ordering incl. its quirks (see mcq_eval_key)
 //   tools/hand_evaluator.py:20-24       ties go to the first hand = hero
 //
-// Instruction selection follows the gfx950 issue costs measured with tools/ubench (profiles/r01_ubench.txt):
-// add/sub/and/or/xor/not/lshr/ashr issue in ~2.3 cycles per wave, while lshl, cmp, cndmask, bcnt, ffbh, bfe,
-// min/max, every multiply and every 3-operand form take ~4.3, and a random LDS lookup ~8.5 cycles of the
-// (otherwise idle) LDS pipe.  Hence: no compare/select chains, arithmetic masks instead; small LDS tables for
-// straights, flushes and top-two-bits; masks kept pre-shifted where they index a table.
+// Cost model, measured on gfx950 with tools/ubench (profiles/r01_ubench*.txt): in any instruction stream that
+// contains even one non-trivial VALU op per 64 (shift-left, compare, select, popcount, multiply, any 3-operand
+// form ...) EVERY wave64 VALU instruction issues in ~4.0-4.3 cycles; the 2.3-cycle rate exists only for pure
+// add/and/or/xor/lshr streams.  A random LDS lookup costs ~8.5 cycles of the separate LDS pipe.  So the kernel
+// is tuned for INSTRUCTION COUNT: fused 3-operand forms (and_or, or3, bitop3, lshl_or, add3, max3, sad_u8),
+// selects where they are shorter than mask arithmetic, and LDS tables (indexed by byte offset, masks kept in
+// the pre-shifted "x4 domain") wherever a lookup replaces more than one instruction.
 #pragma once
 #include <stdint.h>
 
@@ -71,6 +73,20 @@ MCQ_HD uint32_t mcq_opaque(uint32_t x) {
 #endif
     return x;
 }
+MCQ_HD uint32_t mcq_bfe(uint32_t x, uint32_t off, uint32_t width) { /* (x >> off) & ((1 << width) - 1), off + width <= 32 */
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ubfe(x, off, width);
+#else
+    return (x >> off) & (width >= 32 ? 0xFFFFFFFFu : ((1u << width) - 1u));
+#endif
+}
+MCQ_HD uint32_t mcq_sad_u8(uint32_t bytes, uint32_t acc) { /* acc + sum of the four bytes */
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sad_u8(bytes, 0u, acc);
+#else
+    return acc + (bytes & 0xFFu) + ((bytes >> 8) & 0xFFu) + ((bytes >> 16) & 0xFFu) + (bytes >> 24);
+#endif
+}
 MCQ_HD uint32_t mcq_splat_byte(uint32_t x) { /* x < 256 -> x in all four bytes */
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_perm(0u, x, 0u); /* v_perm_b32: every selector byte 0 = byte 0 of x */
@@ -101,16 +117,17 @@ MCQ_HD uint32_t mcq_straight_runs(uint32_t m) {
 // ------------------------------------------------------------------------------------------ lookup tables (LDS)
 // sel8: only for laying out the per-query base deck (once per wave task).
 // All mask-indexed tables are addressed with x4-domain masks (m4 = m << 2):
-//   tops[m] (u32, byte offset m4):       top two set bits of m (x4 domain, 0 if fewer than two) | top bit << 16
-//   str[m]  (u8,  byte offset m4 >> 2):  0 if m holds no straight, else 0x80 | (top position 1..10); key = str << 23
-//   tf[m]   (u32, byte offset m4):       complete key of the SUIT mask m: StraightFlush (all ranks of the suit
+//   tops[m] (u32, byte offset m4):  top two set bits of m (x4 domain, 0 if fewer than two) | top bit << 16
+//   sd[m]   (u32, byte offset m4):  (straight ? 0x80 | top position 1..10 : 0) << 23, i.e. the complete
+//           Straight key, | m without its two lowest set bits (x4 domain; the kickers of HighCard/Pair/Trips)
+//   tf[m]   (u32, byte offset m4):  complete key of the SUIT mask m: StraightFlush (all ranks of the suit
 //           plus the -1 slot when it holds the ace, hand_evaluator.py:71-80,93), Flush (top five, :98-100), or 0
 //           when popcount(m) < 5
 //   inv[d]: 2^20 / d + 1, so that (x * inv[d]) >> 20 == x / d for x < d * d
 struct McqTables {
     uint32_t tf[8192];
     uint32_t tops[8192];
-    uint8_t str[8192];
+    uint32_t sd[8192];
     uint32_t sel8[256];
     uint32_t inv[64];
 };
@@ -126,8 +143,11 @@ static inline void mcq_fill_tables(McqTables *t) {
     for (uint32_t d = 1; d < 64; d++) t->inv[d] = (1u << 20) / d + 1u;
     for (uint32_t m = 0; m < 8192; m++) {
         uint32_t runs = mcq_straight_runs(m);
-        t->str[m] = runs ? (uint8_t)(0x80u | (32u - (uint32_t)__builtin_clz(runs))) : 0;
+        uint32_t st = runs ? (0x80u | (32u - (uint32_t)__builtin_clz(runs))) : 0;
         uint32_t n = (uint32_t)__builtin_popcount(m);
+        uint32_t d2 = m & (m - 1);
+        d2 &= d2 - 1; /* m == 0 stays 0 */
+        t->sd[m] = (st << 23) | (d2 << 2);
         uint32_t hi1 = m ? 0x80000000u >> __builtin_clz(m) : 0, hi2 = 0;
         if (n >= 2) hi2 = hi1 | (0x80000000u >> __builtin_clz(m ^ hi1));
         t->tops[m] = (hi2 << 2) | (hi1 << 18);
@@ -200,8 +220,7 @@ struct McqCtrDraws {
         const uint32_t x = mcq_mulhi(rng.next(), dd * dd);
         const uint32_t a = (x * inv[dd]) >> 20;
         const uint32_t c = x - a * dd;
-        const uint32_t eq = (uint32_t)((int32_t)((a ^ c) - 1u) >> 31); /* all ones iff a == c */
-        r1 = a ^ ((a ^ dd) & eq);
+        r1 = a == c ? dd : a;
         r2 = c;
     }
     template <int K>
@@ -309,17 +328,16 @@ struct McqHole { /* two hole cards: B = r1 | r2, P = r1 & r2 (pocket pair) */
 };
 
 // Only a suit with at least three table cards can make a flush, and five table cards hold at most one such
-// suit: mlo/mhi select that suit's half-word of the (los, his) pairs, bfl4 is the table's mask in it (<< 2).
+// suit.  use_hi / sh locate that suit's 16-bit field in the (los, his) pairs, bfl4 is the table's mask in it.
+// Without such a suit the fields of clubs are taken: table + hole then hold fewer than five bits and tf[] = 0.
 struct McqFlushSel {
-    uint32_t mlo, mhi, bfl4;
+    bool use_hi;
+    uint32_t sh, bfl4;
     MCQ_HDM void from_board(const McqBoard &b) {
         const uint32_t f = (b.cnt + 0x5555u) & 0x8888u; /* bit 4s+3 <=> suit s has >= 3 table cards */
-        const uint32_t mc = 0u - ((f >> 3) & 1u), md = 0u - ((f >> 7) & 1u);
-        const uint32_t mh = 0u - ((f >> 11) & 1u), ms = 0u - ((f >> 15) & 1u);
-        mlo = (mc & 0x0000FFFFu) | (md & 0xFFFF0000u);
-        mhi = (mh & 0x0000FFFFu) | (ms & 0xFFFF0000u);
-        const uint32_t x = (b.los & mlo) | (b.his & mhi);
-        bfl4 = (x | (x >> 16)) & 0xFFFFu;
+        use_hi = (f & 0x8800u) != 0;                     /* hearts or spades */
+        sh = (f & 0x8080u) != 0 ? 16u : 0u;              /* diamonds or spades: upper half-word */
+        bfl4 = mcq_bfe(use_hi ? b.his : b.los, sh, 16);
     }
 };
 
@@ -338,7 +356,7 @@ MCQ_HD uint32_t mcq_ld_u32(const uint32_t *t, uint32_t byte_off) {
 //   FoufOfAKind = the two highest distinct ranks of all seven cards (:43-46).
 // All masks below are x4-domain.
 MCQ_HD uint32_t mcq_eval_key(const McqBoard &b, const McqFlushSel &fs, const McqHole &h, const uint32_t *tf,
-                             const uint32_t *tops, const uint8_t *str) {
+                             const uint32_t *tops, const uint32_t *sd) {
 #ifdef MCQ_ABLATE_EVAL /* diagnostic timing build: wrong results */
     return (b.any ^ h.B ^ (h.los >> 3)) | (1u << MCQ_KEY_SHIFT);
 #endif
@@ -351,34 +369,27 @@ MCQ_HD uint32_t mcq_eval_key(const McqBoard &b, const McqFlushSel &fs, const Mcq
     const uint32_t e_any = mcq_ld_u32(tops, any);
     const uint32_t e_ge2 = mcq_ld_u32(tops, ge2);
     const uint32_t e_ge3 = mcq_ld_u32(tops, ge3);
-    const uint32_t s_any = str[any >> 2];
-    uint32_t x = (h.los & fs.mlo) | (h.his & fs.mhi);
-    x = (x | (x >> 16)) & 0xFFFFu;
-    const uint32_t key_f = mcq_ld_u32(tf, fs.bfl4 | x);
+    const uint32_t d_any = mcq_ld_u32(sd, any);
+    const uint32_t d_kick = mcq_ld_u32(sd, any ^ ge2);
+    const uint32_t key_f = mcq_ld_u32(tf, fs.bfl4 | mcq_bfe(fs.use_hi ? h.his : h.los, fs.sh, 16));
 
-    /* F1 */
-    const uint32_t kick1 = mcq_droplow(mcq_droplow(any ^ ge2));
-    const uint32_t key1 = (ge2 << 13) | kick1 | ((0u - ge2) & (1u << MCQ_KEY_SHIFT)) | ((0u - ge3) & (2u << MCQ_KEY_SHIFT));
+    const uint32_t key_s = d_any & 0xFF800000u;
+    const uint32_t key1 = (ge2 << 13) | (d_kick & 0x7FFCu) | (ge2 != 0 ? 1u << MCQ_KEY_SHIFT : 0u) |
+                          (ge3 != 0 ? 2u << MCQ_KEY_SHIFT : 0u);
 
-    /* F2 */
-    const uint32_t m3 = mcq_opaque(mcq_nz_mask(ge3));
-    const uint32_t h2 = e_ge2 & 0xFFFFu, t = e_ge3 >> 16;
-    const uint32_t H = h2 ^ ((h2 ^ t) & m3);
-    const uint32_t R = (any ^ ((any ^ ge2) & m3)) ^ H;
+    const bool fh = ge3 != 0;
+    const uint32_t H = fh ? (e_ge3 >> 16) : (e_ge2 & 0xFFFFu);
+    const uint32_t R = (fh ? ge2 : any) ^ H;
     const uint32_t kick2 = mcq_ld_u32(tops, R) >> 16;
-    const uint32_t mv = mcq_opaque((uint32_t)((int32_t)((0u - H) & (0u - R)) >> 31));
-    const uint32_t c2 = ((uint32_t)MCQ_C_TWOPAIR << MCQ_KEY_SHIFT) +
-                        (m3 & ((uint32_t)(MCQ_C_FULL - MCQ_C_TWOPAIR) << MCQ_KEY_SHIFT));
-    const uint32_t key2 = ((H << 13) | kick2 | c2) & mv;
+    uint32_t key2 = (H << 13) | kick2 |
+                    (fh ? (uint32_t)MCQ_C_FULL << MCQ_KEY_SHIFT : (uint32_t)MCQ_C_TWOPAIR << MCQ_KEY_SHIFT);
+    key2 = (H != 0 && R != 0) ? key2 : 0u;
 
-    /* quads, straight */
-    const uint32_t m4 = mcq_opaque(mcq_nz_mask(eq4));
-    const uint32_t key4 = ((e_any & 0xFFFFu) | ((uint32_t)MCQ_C_QUADS << MCQ_KEY_SHIFT)) & m4;
-    const uint32_t key_s = s_any << 23;
+    const uint32_t key4 = eq4 != 0 ? ((e_any & 0xFFFFu) | ((uint32_t)MCQ_C_QUADS << MCQ_KEY_SHIFT)) : 0u;
 
     uint32_t k = key1 > key2 ? key1 : key2;
-    uint32_t k2 = key_s > key_f ? key_s : key_f;
-    k2 = k2 > key4 ? k2 : key4;
+    k = k > key_s ? k : key_s;
+    uint32_t k2 = key_f > key4 ? key_f : key4;
     return k > k2 ? k : k2;
 }
 
@@ -477,9 +488,9 @@ MCQ_HD void mcq_hole_reg(uint32_t rb, uint32_t &h, uint32_t &k) {
     k += (rb ^ h) & 1u;
     return;
 #endif
-    uint32_t flags = (rb - h) & 0x80808080u;
-    k += mcq_popc(flags);
-    h -= (flags ^ 0x80808080u) >> 7;
+    const uint32_t f = ((rb - h) >> 7) & 0x01010101u; /* byte i = 1 iff t_i <= r */
+    k = mcq_sad_u8(f, k);                             /* k += number of such holes */
+    h = h + f - 0x01010101u;                          /* every other hole moves down by one */
 }
 
 template <int SLOT>
@@ -519,7 +530,7 @@ MCQ_HD uint32_t mcq_draw_table(uint32_t r, uint32_t (&H)[5], uint32_t &hb, uint3
 // ALL opponents before any table card (montecarlo_python.py:215-217).
 template <class Draws>
 MCQ_HD void mcq_iteration(const McqQueryCtx &qc, Draws &dr, const McqCard *base, const uint32_t *tf,
-                          const uint32_t *tops, const uint8_t *str, const uint32_t *inv, McqLaneAcc &acc) {
+                          const uint32_t *tops, const uint32_t *sd, const uint32_t *inv, McqLaneAcc &acc) {
     uint32_t H[5] = {MCQ_HOLE_SENTINEL, MCQ_HOLE_SENTINEL, MCQ_HOLE_SENTINEL, MCQ_HOLE_SENTINEL, MCQ_HOLE_SENTINEL};
     uint32_t hb = MCQ_HOLE_SENTINEL;
     uint32_t L = qc.L0;
@@ -546,11 +557,11 @@ MCQ_HD void mcq_iteration(const McqQueryCtx &qc, Draws &dr, const McqCard *base,
 #undef MCQ_TABLE
     McqFlushSel fs;
     fs.from_board(b);
-    const uint32_t hk = mcq_eval_key(b, fs, qc.hero, tf, tops, str);
+    const uint32_t hk = mcq_eval_key(b, fs, qc.hero, tf, tops, sd);
     uint32_t best = 0;
 #define MCQ_EVAL(P)                                                        \
     if (P < qc.n_opp) {                                                    \
-        const uint32_t k = mcq_eval_key(b, fs, opp[P], tf, tops, str);     \
+        const uint32_t k = mcq_eval_key(b, fs, opp[P], tf, tops, sd);     \
         best = k > best ? k : best;                                        \
     }
     MCQ_EVAL(0) MCQ_EVAL(1) MCQ_EVAL(2) MCQ_EVAL(3) MCQ_EVAL(4) MCQ_EVAL(5) MCQ_EVAL(6) MCQ_EVAL(7) MCQ_EVAL(8)

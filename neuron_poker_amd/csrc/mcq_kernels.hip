@@ -15,7 +15,7 @@
 
 namespace {
 
-constexpr int kMaxBlock = 1024; /* 16 waves = 4 per SIMD; one block per CU: tables 73 KB + 16 base decks 16 KB of the 160 KB LDS */
+constexpr int kMaxBlock = 1024; /* 16 waves = 4 per SIMD; one block per CU: tables 97 KB + 16 base decks 16 KB of the 160 KB LDS */
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
@@ -26,7 +26,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 struct LdsTables { /* per block */
     uint32_t tf[8192];
     uint32_t tops[8192];
-    uint8_t str[8192];
+    uint32_t sd[8192];
     uint32_t sel8[256];
     uint32_t inv[64];
 };
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
                 dr.rng.seed(seed, first_qid + qi, stream);
                 const uint32_t cnt = (uint32_t)min((uint64_t)MCQ_STREAM_ITERS, (uint64_t)qc.runs - it0);
                 for (uint32_t j = 0; j < cnt; j++)
-                    mcq_iteration(qc, dr, base, tab.tf, tab.tops, tab.str, tab.inv, acc);
+                    mcq_iteration(qc, dr, base, tab.tf, tab.tops, tab.sd, tab.inv, acc);
                 acc.passes = cnt * qc.n_opp; /* MCQ-CTR v2: one attempt per opponent, never re-drawn */
             }
         } else {
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
                 const uint64_t it = (uint64_t)task * MCQ_TASK_ITERS + j * MCQ_WAVE + lane;
                 if (it < qc.runs) {
                     McqReplayDraws dr = {dbase + it, stride};
-                    mcq_iteration(qc, dr, base, tab.tf, tab.tops, tab.str, tab.inv, acc);
+                    mcq_iteration(qc, dr, base, tab.tf, tab.tops, tab.sd, tab.inv, acc);
                 }
             }
             acc.passes = 0; /* counted by the host while parsing the MT19937 stream */
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void mcq_showdown_kernel(const uint8_t *__rest
             hole.set(mcq_card(h[0] < 52 ? h[0] : 0), mcq_card(h[1] < 52 ? h[1] : 0));
             McqFlushSel fs;
             fs.from_board(b);
-            const uint32_t key = mcq_eval_key(b, fs, hole, tab.tf, tab.tops, tab.str);
+            const uint32_t key = mcq_eval_key(b, fs, hole, tab.tf, tab.tops, tab.sd);
             if (keys) keys[(size_t)t * n_players + p] = key;
             if (key > best) { best = key; w = p; } /* strict: the first of equal hands stays (hand_evaluator.py:23) */
         }

@@ -51,7 +51,7 @@ void hs_eval7(const uint8_t *cards, size_t n, uint32_t *keys) {
         h.set(mcq_card(cards[7 * i]), mcq_card(cards[7 * i + 1]));
         McqFlushSel fs;
         fs.from_board(b);
-        keys[i] = mcq_eval_key(b, fs, h, t.tf, t.tops, t.str);
+        keys[i] = mcq_eval_key(b, fs, h, t.tf, t.tops, t.sd);
     }
 }
 uint32_t hs_key_type(uint32_t key) { return mcq_key_type(key); }
@@ -80,7 +80,7 @@ int hs_run_ctr(const mcq_query *q, uint64_t seed, uint64_t qid, mcq_result *out)
         McqLaneAcc acc = {0, 0, 0};
         for (uint32_t j = 0; j < MCQ_STREAM_ITERS; j++) {
             if ((uint64_t)s * MCQ_STREAM_ITERS + j >= q->runs) break;
-            mcq_iteration(qc, dr, base, t.tf, t.tops, t.str, t.inv, acc);
+            mcq_iteration(qc, dr, base, t.tf, t.tops, t.sd, t.inv, acc);
             acc.passes += qc.n_opp; /* MCQ-CTR v2: one attempt per opponent, never re-drawn */
         }
         fold(acc, out);
@@ -104,7 +104,7 @@ int hs_run_replay(const mcq_query *q, uint32_t seed32, mcq_result *out) {
     for (uint32_t it = 0; it < q->runs; it++) {
         McqReplayDraws dr = {draws.data() + it, stride};
         McqLaneAcc acc = {0, 0, 0};
-        mcq_iteration(qc, dr, base, t.tf, t.tops, t.str, t.inv, acc);
+        mcq_iteration(qc, dr, base, t.tf, t.tops, t.sd, t.inv, acc);
         acc.passes = 0;
         fold(acc, out);
     }

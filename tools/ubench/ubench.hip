@@ -178,6 +178,57 @@ KERNEL32(k_xad, I_XAD, "memory")
 KERNEL32(k_or3, I_OR3, "memory")
 KERNEL32(k_addlshl, I_ADDLSHL, "memory")
 KERNEL32(k_bfi, I_BFI, "memory")
+
+// ---- realistic dependent groups (per group of 6: the hole-register update)
+#define I_HOLEGRP(x) "v_sub_u32 v40, %8, " x "\nv_and_b32 v40, 0x80808080, v40\nv_bcnt_u32_b32 v41, v40, v41\nv_lshrrev_b32 v40, 7, v40\nv_xor_b32 v40, 0x1010101, v40\nv_sub_u32 " x ", " x ", v40\n"
+KERNEL32(k_holegrp, I_HOLEGRP, "v40", "v41")
+// dependent chain of fast ops on ONE register (no ILP inside the wave)
+#define I_DEPCHAIN(x) "v_add_u32 %0, %0, %8\nv_xor_b32 %0, %0, %8\n"
+KERNEL32(k_depchain, I_DEPCHAIN, "memory")
+// fast op with literal
+#define I_XORLIT(x) "v_xor_b32 " x ", 0x1010101, " x "\n"
+KERNEL32(k_xorlit, I_XORLIT, "memory")
+// alternating fast / slow
+#define I_ALT(x) "v_add_u32 " x ", " x ", %8\nv_bcnt_u32_b32 " x ", " x ", %8\n"
+KERNEL32(k_alt, I_ALT, "memory")
+// fast op followed by s_waitcnt lgkmcnt(0) (no LDS outstanding)
+#define I_WAITC(x) "v_add_u32 " x ", " x ", %8\ns_waitcnt lgkmcnt(0)\n"
+KERNEL32(k_waitc, I_WAITC, "memory")
+// s_nop interleave
+#define I_NOP(x) "v_add_u32 " x ", " x ", %8\ns_nop 0\n"
+KERNEL32(k_nop, I_NOP, "memory")
+
+// ---- pairing-rule probes: G8 = one asm group touching %0..%7 (8 instructions unless noted)
+#define KGROUP(name, BODY, ...)                                                                       \
+    __global__ void name(uint32_t *out, int iters) {                                                  \
+        uint32_t a0 = threadIdx.x, a1 = a0 * 3 + 1, a2 = a0 ^ 0x55, a3 = a0 + 77, a4 = a0 * 5, a5 = ~a0, a6 = a0 << 3, \
+                 a7 = a0 + blockIdx.x;                                                                \
+        uint32_t s = (blockIdx.x * 2654435761u) | 1u;                                                 \
+        for (int i = 0; i < iters; i++) {                                                             \
+            asm volatile(".rept 16\n" BODY ".endr\n"                                                \
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) \
+                         : "v"(s), "s"(i) : __VA_ARGS__);                                             \
+        }                                                                                             \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;           \
+    }
+KGROUP(g_mixfast, "v_add_u32 %0,%0,%8\nv_xor_b32 %1,%1,%8\nv_and_b32 %2,%2,%8\nv_or_b32 %3,%3,%8\nv_sub_u32 %4,%4,%8\nv_lshrrev_b32 %5,1,%5\nv_not_b32 %6,%6\nv_add_u32 %7,%7,%8\n", "memory")
+KGROUP(g_deppairs, "v_add_u32 %0,%0,%8\nv_xor_b32 %0,%0,%8\nv_add_u32 %1,%1,%8\nv_xor_b32 %1,%1,%8\nv_add_u32 %2,%2,%8\nv_xor_b32 %2,%2,%8\nv_add_u32 %3,%3,%8\nv_xor_b32 %3,%3,%8\n", "memory")
+KGROUP(g_altfs_indep, "v_add_u32 %0,%0,%8\nv_bcnt_u32_b32 %1,%1,%8\nv_add_u32 %2,%2,%8\nv_bcnt_u32_b32 %3,%3,%8\nv_add_u32 %4,%4,%8\nv_bcnt_u32_b32 %5,%5,%8\nv_add_u32 %6,%6,%8\nv_bcnt_u32_b32 %7,%7,%8\n", "memory")
+KGROUP(g_ffss, "v_add_u32 %0,%0,%8\nv_add_u32 %1,%1,%8\nv_bcnt_u32_b32 %2,%2,%8\nv_bcnt_u32_b32 %3,%3,%8\nv_add_u32 %4,%4,%8\nv_add_u32 %5,%5,%8\nv_bcnt_u32_b32 %6,%6,%8\nv_bcnt_u32_b32 %7,%7,%8\n", "memory")
+KGROUP(g_fffs, "v_add_u32 %0,%0,%8\nv_add_u32 %1,%1,%8\nv_add_u32 %2,%2,%8\nv_bcnt_u32_b32 %3,%3,%8\nv_add_u32 %4,%4,%8\nv_add_u32 %5,%5,%8\nv_add_u32 %6,%6,%8\nv_bcnt_u32_b32 %7,%7,%8\n", "memory")
+KGROUP(g_hole_nolit, "v_sub_u32 %6,%8,%0\nv_and_b32 %6,%7,%6\nv_bcnt_u32_b32 %1,%6,%1\nv_lshrrev_b32 %6,7,%6\nv_xor_b32 %6,%5,%6\nv_sub_u32 %0,%0,%6\n", "memory")
+KGROUP(g_hole_ilp2, "v_sub_u32 %6,%8,%0\nv_sub_u32 %7,%8,%2\nv_and_b32 %6,%4,%6\nv_and_b32 %7,%4,%7\nv_bcnt_u32_b32 %1,%6,%1\nv_bcnt_u32_b32 %3,%7,%3\nv_lshrrev_b32 %6,7,%6\nv_lshrrev_b32 %7,7,%7\nv_xor_b32 %6,%5,%6\nv_xor_b32 %7,%5,%7\nv_sub_u32 %0,%0,%6\nv_sub_u32 %2,%2,%7\n", "memory")
+KGROUP(g_slow_dep, "v_bcnt_u32_b32 %0,%0,%8\nv_bcnt_u32_b32 %0,%0,%8\nv_bcnt_u32_b32 %1,%1,%8\nv_bcnt_u32_b32 %1,%1,%8\nv_bcnt_u32_b32 %2,%2,%8\nv_bcnt_u32_b32 %2,%2,%8\nv_bcnt_u32_b32 %3,%3,%8\nv_bcnt_u32_b32 %3,%3,%8\n", "memory")
+KGROUP(g_fast_samedst, "v_add_u32 %0,%1,%8\nv_add_u32 %0,%2,%8\nv_add_u32 %0,%3,%8\nv_add_u32 %0,%4,%8\nv_add_u32 %0,%5,%8\nv_add_u32 %0,%6,%8\nv_add_u32 %0,%7,%8\nv_add_u32 %0,%1,%8\n", "memory")
+KGROUP(g_run_7_1, "v_add_u32 %0,%0,%8\nv_xor_b32 %1,%1,%8\nv_add_u32 %2,%2,%8\nv_xor_b32 %3,%3,%8\nv_add_u32 %4,%4,%8\nv_xor_b32 %5,%5,%8\nv_add_u32 %6,%6,%8\nv_bcnt_u32_b32 %0,%0,%8\n", "memory")
+KGROUP(g_run_15_1, "v_add_u32 %0,%0,%8\nv_xor_b32 %1,%1,%8\nv_add_u32 %2,%2,%8\nv_xor_b32 %3,%3,%8\nv_add_u32 %4,%4,%8\nv_xor_b32 %5,%5,%8\nv_add_u32 %6,%6,%8\nv_xor_b32 %7,%7,%8\nv_add_u32 %0,%0,%8\nv_xor_b32 %1,%1,%8\nv_add_u32 %2,%2,%8\nv_xor_b32 %3,%3,%8\nv_add_u32 %4,%4,%8\nv_xor_b32 %5,%5,%8\nv_add_u32 %6,%6,%8\nv_bcnt_u32_b32 %0,%0,%8\n", "memory")
+KGROUP(g_run_31_1, "v_add_u32 %0,%0,%8\nv_xor_b32 %1,%1,%8\nv_add_u32 %2,%2,%8\nv_xor_b32 %3,%3,%8\nv_add_u32 %4,%4,%8\nv_xor_b32 %5,%5,%8\nv_add_u32 %6,%6,%8\nv_xor_b32 %7,%7,%8\nv_add_u32 %0,%0,%8\nv_xor_b32 %1,%1,%8\nv_add_u32 %2,%2,%8\nv_xor_b32 %3,%3,%8\nv_add_u32 %4,%4,%8\nv_xor_b32 %5,%5,%8\nv_add_u32 %6,%6,%8\nv_xor_b32 %7,%7,%8\nv_add_u32 %0,%0,%8\nv_xor_b32 %1,%1,%8\nv_add_u32 %2,%2,%8\nv_xor_b32 %3,%3,%8\nv_add_u32 %4,%4,%8\nv_xor_b32 %5,%5,%8\nv_add_u32 %6,%6,%8\nv_xor_b32 %7,%7,%8\nv_add_u32 %0,%0,%8\nv_xor_b32 %1,%1,%8\nv_add_u32 %2,%2,%8\nv_xor_b32 %3,%3,%8\nv_add_u32 %4,%4,%8\nv_xor_b32 %5,%5,%8\nv_add_u32 %6,%6,%8\nv_bcnt_u32_b32 %0,%0,%8\n", "memory")
+KGROUP(g_run_63_1, "v_add_u32 %0,%0,%8\nv_xor_b32 %1,%1,%8\nv_add_u32 %2,%2,%8\nv_xor_b32 %3,%3,%8\nv_add_u32 %4,%4,%8\nv_xor_b32 %5,%5,%8\nv_add_u32 %6,%6,%8\nv_xor_b32 %7,%7,%8\nv_add_u32 %0,%0,%8\nv_xor_b32 %1,%1,%8\nv_add_u32 %2,%2,%8\nv_xor_b32 %3,%3,%8\nv_add_u32 %4,%4,%8\nv_xor_b32 %5,%5,%8\nv_add_u32 %6,%6,%8\nv_xor_b32 %7,%7,%8\nv_add_u32 %0,%0,%8\nv_xor_b32 %1,%1,%8\nv_add_u32 %2,%2,%8\nv_xor_b32 %3,%3,%8\nv_add_u32 %4,%4,%8\nv_xor_b32 %5,%5,%8\nv_add_u32 %6,%6,%8\nv_xor_b32 %7,%7,%8\nv_add_u32 %0,%0,%8\nv_xor_b32 %1,%1,%8\nv_add_u32 %2,%2,%8\nv_xor_b32 %3,%3,%8\nv_add_u32 %4,%4,%8\nv_xor_b32 %5,%5,%8\nv_add_u32 %6,%6,%8\nv_xor_b32 %7,%7,%8\nv_add_u32 %0,%0,%8\nv_xor_b32 %1,%1,%8\nv_add_u32 %2,%2,%8\nv_xor_b32 %3,%3,%8\nv_add_u32 %4,%4,%8\nv_xor_b32 %5,%5,%8\nv_add_u32 %6,%6,%8\nv_xor_b32 %7,%7,%8\nv_add_u32 %0,%0,%8\nv_xor_b32 %1,%1,%8\nv_add_u32 %2,%2,%8\nv_xor_b32 %3,%3,%8\nv_add_u32 %4,%4,%8\nv_xor_b32 %5,%5,%8\nv_add_u32 %6,%6,%8\nv_xor_b32 %7,%7,%8\nv_add_u32 %0,%0,%8\nv_xor_b32 %1,%1,%8\nv_add_u32 %2,%2,%8\nv_xor_b32 %3,%3,%8\nv_add_u32 %4,%4,%8\nv_xor_b32 %5,%5,%8\nv_add_u32 %6,%6,%8\nv_xor_b32 %7,%7,%8\nv_add_u32 %0,%0,%8\nv_xor_b32 %1,%1,%8\nv_add_u32 %2,%2,%8\nv_xor_b32 %3,%3,%8\nv_add_u32 %4,%4,%8\nv_xor_b32 %5,%5,%8\nv_add_u32 %6,%6,%8\nv_bcnt_u32_b32 %0,%0,%8\n", "memory")
+KGROUP(g_run_16_16, "v_add_u32 %0,%0,%8\nv_xor_b32 %1,%1,%8\nv_add_u32 %2,%2,%8\nv_xor_b32 %3,%3,%8\nv_add_u32 %4,%4,%8\nv_xor_b32 %5,%5,%8\nv_add_u32 %6,%6,%8\nv_xor_b32 %7,%7,%8\nv_add_u32 %0,%0,%8\nv_xor_b32 %1,%1,%8\nv_add_u32 %2,%2,%8\nv_xor_b32 %3,%3,%8\nv_add_u32 %4,%4,%8\nv_xor_b32 %5,%5,%8\nv_add_u32 %6,%6,%8\nv_xor_b32 %7,%7,%8\nv_bcnt_u32_b32 %0,%0,%8\nv_bcnt_u32_b32 %1,%1,%8\nv_bcnt_u32_b32 %2,%2,%8\nv_bcnt_u32_b32 %3,%3,%8\nv_bcnt_u32_b32 %4,%4,%8\nv_bcnt_u32_b32 %5,%5,%8\nv_bcnt_u32_b32 %6,%6,%8\nv_bcnt_u32_b32 %7,%7,%8\nv_bcnt_u32_b32 %0,%0,%8\nv_bcnt_u32_b32 %1,%1,%8\nv_bcnt_u32_b32 %2,%2,%8\nv_bcnt_u32_b32 %3,%3,%8\nv_bcnt_u32_b32 %4,%4,%8\nv_bcnt_u32_b32 %5,%5,%8\nv_bcnt_u32_b32 %6,%6,%8\nv_bcnt_u32_b32 %7,%7,%8\n", "memory")
+KGROUP(g_run_32_32, "v_add_u32 %0,%0,%8\nv_xor_b32 %1,%1,%8\nv_add_u32 %2,%2,%8\nv_xor_b32 %3,%3,%8\nv_add_u32 %4,%4,%8\nv_xor_b32 %5,%5,%8\nv_add_u32 %6,%6,%8\nv_xor_b32 %7,%7,%8\nv_add_u32 %0,%0,%8\nv_xor_b32 %1,%1,%8\nv_add_u32 %2,%2,%8\nv_xor_b32 %3,%3,%8\nv_add_u32 %4,%4,%8\nv_xor_b32 %5,%5,%8\nv_add_u32 %6,%6,%8\nv_xor_b32 %7,%7,%8\nv_add_u32 %0,%0,%8\nv_xor_b32 %1,%1,%8\nv_add_u32 %2,%2,%8\nv_xor_b32 %3,%3,%8\nv_add_u32 %4,%4,%8\nv_xor_b32 %5,%5,%8\nv_add_u32 %6,%6,%8\nv_xor_b32 %7,%7,%8\nv_add_u32 %0,%0,%8\nv_xor_b32 %1,%1,%8\nv_add_u32 %2,%2,%8\nv_xor_b32 %3,%3,%8\nv_add_u32 %4,%4,%8\nv_xor_b32 %5,%5,%8\nv_add_u32 %6,%6,%8\nv_xor_b32 %7,%7,%8\nv_bcnt_u32_b32 %0,%0,%8\nv_bcnt_u32_b32 %1,%1,%8\nv_bcnt_u32_b32 %2,%2,%8\nv_bcnt_u32_b32 %3,%3,%8\nv_bcnt_u32_b32 %4,%4,%8\nv_bcnt_u32_b32 %5,%5,%8\nv_bcnt_u32_b32 %6,%6,%8\nv_bcnt_u32_b32 %7,%7,%8\nv_bcnt_u32_b32 %0,%0,%8\nv_bcnt_u32_b32 %1,%1,%8\nv_bcnt_u32_b32 %2,%2,%8\nv_bcnt_u32_b32 %3,%3,%8\nv_bcnt_u32_b32 %4,%4,%8\nv_bcnt_u32_b32 %5,%5,%8\nv_bcnt_u32_b32 %6,%6,%8\nv_bcnt_u32_b32 %7,%7,%8\nv_bcnt_u32_b32 %0,%0,%8\nv_bcnt_u32_b32 %1,%1,%8\nv_bcnt_u32_b32 %2,%2,%8\nv_bcnt_u32_b32 %3,%3,%8\nv_bcnt_u32_b32 %4,%4,%8\nv_bcnt_u32_b32 %5,%5,%8\nv_bcnt_u32_b32 %6,%6,%8\nv_bcnt_u32_b32 %7,%7,%8\nv_bcnt_u32_b32 %0,%0,%8\nv_bcnt_u32_b32 %1,%1,%8\nv_bcnt_u32_b32 %2,%2,%8\nv_bcnt_u32_b32 %3,%3,%8\nv_bcnt_u32_b32 %4,%4,%8\nv_bcnt_u32_b32 %5,%5,%8\nv_bcnt_u32_b32 %6,%6,%8\nv_bcnt_u32_b32 %7,%7,%8\n", "memory")
+KGROUP(g_run_8_8, "v_add_u32 %0,%0,%8\nv_xor_b32 %1,%1,%8\nv_add_u32 %2,%2,%8\nv_xor_b32 %3,%3,%8\nv_add_u32 %4,%4,%8\nv_xor_b32 %5,%5,%8\nv_add_u32 %6,%6,%8\nv_xor_b32 %7,%7,%8\nv_bcnt_u32_b32 %0,%0,%8\nv_bcnt_u32_b32 %1,%1,%8\nv_bcnt_u32_b32 %2,%2,%8\nv_bcnt_u32_b32 %3,%3,%8\nv_bcnt_u32_b32 %4,%4,%8\nv_bcnt_u32_b32 %5,%5,%8\nv_bcnt_u32_b32 %6,%6,%8\nv_bcnt_u32_b32 %7,%7,%8\n", "memory")
+KGROUP(g_run_4_4, "v_add_u32 %0,%0,%8\nv_xor_b32 %1,%1,%8\nv_add_u32 %2,%2,%8\nv_xor_b32 %3,%3,%8\nv_bcnt_u32_b32 %0,%0,%8\nv_bcnt_u32_b32 %1,%1,%8\nv_bcnt_u32_b32 %2,%2,%8\nv_bcnt_u32_b32 %3,%3,%8\n", "memory")
+KGROUP(g_run_12_4, "v_add_u32 %0,%0,%8\nv_xor_b32 %1,%1,%8\nv_add_u32 %2,%2,%8\nv_xor_b32 %3,%3,%8\nv_add_u32 %4,%4,%8\nv_xor_b32 %5,%5,%8\nv_add_u32 %6,%6,%8\nv_xor_b32 %7,%7,%8\nv_add_u32 %0,%0,%8\nv_xor_b32 %1,%1,%8\nv_add_u32 %2,%2,%8\nv_xor_b32 %3,%3,%8\nv_bcnt_u32_b32 %0,%0,%8\nv_bcnt_u32_b32 %1,%1,%8\nv_bcnt_u32_b32 %2,%2,%8\nv_bcnt_u32_b32 %3,%3,%8\n", "memory")
 KERNEL64(k_lshl64, I_LSHL64, "memory")
 KERNEL64(k_lshl64v, I_LSHL64V, "memory")
 KERNEL64(k_lshr64v, I_LSHR64V, "memory")
@@ -257,7 +308,7 @@ int main(int argc, char **argv) {
         {"v_pk_min_u16", k_pkmin, 128}, {"v_pk_add_u16", k_pkadd, 128}, {"v_pk_sub_u16", k_pksub, 128},
         {"v_readlane+v_writelane pair", k_readlane, 256}, {"v_add_u32_dpp", k_dpp, 128}, {"v_or_b32_sdwa", k_sdwa, 128},
         {"s_add+s_and pair (SALU only)", k_salu, 256}, {"v_add + s_add interleaved", k_mix_vs, 256},
-        {"v_lshlrev_b64 imm", k_lshl64, 128}, {"v_lshlrev_b64 vgpr", k_lshl64v, 128}, {"v_lshrrev_b64 vgpr", k_lshr64v, 128},
+        {"hole group (6 instr: sub,and-lit,bcnt,lshr,xor-lit,sub)", k_holegrp, 768}, {"dependent chain add,xor on one reg", k_depchain, 256}, {"v_xor_b32 literal", k_xorlit, 128}, {"alternating v_add / v_bcnt", k_alt, 256}, {"v_add + s_waitcnt lgkmcnt(0)", k_waitc, 128}, {"v_add + s_nop 0", k_nop, 128}, {"8 different fast ops, independent", g_mixfast, 128}, {"dependent pairs add->xor (4 pairs)", g_deppairs, 128}, {"alt fast/slow, all independent", g_altfs_indep, 128}, {"f f s s independent", g_ffss, 128}, {"f f f s independent", g_fffs, 128}, {"hole group, registers not literals (6)", g_hole_nolit, 96}, {"two interleaved hole groups (12)", g_hole_ilp2, 192}, {"slow dependent pairs (bcnt)", g_slow_dep, 128}, {"fast ops same dst", g_fast_samedst, 128}, {"run: 7 fast then 1 slow", g_run_7_1, 128}, {"run: 15 fast then 1 slow", g_run_15_1, 256}, {"run: 31 fast then 1 slow", g_run_31_1, 512}, {"run: 63 fast then 1 slow", g_run_63_1, 1024}, {"run: 16 fast then 16 slow", g_run_16_16, 512}, {"run: 32 fast then 32 slow", g_run_32_32, 1024}, {"run: 8 fast then 8 slow", g_run_8_8, 256}, {"run: 4 fast then 4 slow", g_run_4_4, 128}, {"run: 12 fast then 4 slow", g_run_12_4, 256}, {"v_lshlrev_b64 imm", k_lshl64, 128}, {"v_lshlrev_b64 vgpr", k_lshl64v, 128}, {"v_lshrrev_b64 vgpr", k_lshr64v, 128},
         {"v_lshl_add_u64", k_add64, 128}, {"v_mad_u64_u32", k_mad64, 128},
         {"ds_read_b32 random 256-dword table (dependent x8)", k_lds_rand, 128},
         {"ds_read_b64 random 64-entry table (dependent x8)", k_lds_b64_rand, 128},
@@ -265,7 +316,7 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1;
     CHK(hipEventCreate(&e0));
     CHK(hipEventCreate(&e1));
-    for (int W : {1, 4}) {
+    for (int W : {4}) {
         printf("---- %d wave(s) per SIMD (grid %d blocks x 256 threads)\n", W, n_cu * W);
         for (auto &b : bs) {
             int it = iters;
