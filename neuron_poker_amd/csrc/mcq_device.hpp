@@ -451,6 +451,14 @@ MCQ_HD void mcq_query_ctx(const McqQueryWords &q, McqQueryCtx &c) {
     c.runs = q.runs();
 }
 
+// Scheduling weight of one wave task of a query (~ VALU instructions per iteration, measured): used only to cut
+// the task list into equally expensive contiguous slices, never for results.
+MCQ_HD uint32_t mcq_task_weight(const McqQueryWords &q) {
+    const uint32_t n = q.n_players(), deal = 5u - q.n_board();
+    return 45u * n + 65u * (n - 1u) + 40u * deal + 60u;
+}
+MCQ_HD uint32_t mcq_task_count(const McqQueryWords &q) { return (q.runs() + MCQ_TASK_ITERS - 1u) / MCQ_TASK_ITERS; }
+
 static inline McqQueryWords mcq_query_words(const mcq_query &q) { /* host side */
     McqQueryWords w;
     __builtin_memcpy(&w, &q, 16);
@@ -493,10 +501,16 @@ MCQ_HD void mcq_hole_reg(uint32_t rb, uint32_t &h, uint32_t &k) {
     h = h + f - 0x01010101u;                          /* every other hole moves down by one */
 }
 
+MCQ_HD uint32_t mcq_bfi(uint32_t mask, uint32_t a, uint32_t b) { /* (mask & a) | (~mask & b): one v_bfi_b32 */
+    return (mask & a) | (~mask & b);
+}
+
+// Store t = r in byte SLOT.  rb7 = r (optionally with bit 7 set) in every byte, as the scan needs it anyway, so
+// the insertion is a single bit-field insert of the low seven bits (the slot's bit 7 is always clear).
 template <int SLOT>
-MCQ_HD void mcq_hole_put(uint32_t &h, uint32_t r) {
+MCQ_HD void mcq_hole_put(uint32_t &h, uint32_t rb7) {
     constexpr uint32_t sh = 8u * (SLOT & 3);
-    h = (h & ~(0xFFu << sh)) | (r << sh);
+    h = mcq_bfi(0x7Fu << sh, rb7, h);
 }
 
 // opponent draw number J (0-based; J holes precede it, all in H[0 .. (J+3)/4))
@@ -507,9 +521,11 @@ MCQ_HD uint32_t mcq_draw_opp(uint32_t r, uint32_t (&H)[5]) {
         const uint32_t rb = mcq_splat_byte(r | 0x80u);
 #pragma unroll
         for (int i = 0; i < (J + 3) / 4; i++) mcq_hole_reg(rb, H[i], k);
+        mcq_hole_put<J>(H[J / 4], rb);
+    } else {
+        mcq_hole_put<0>(H[0], r);
     }
-    mcq_hole_put<J>(H[J / 4], r);
-    return k;
+    return mcq_opaque(k); /* materialise k so that the table address is one shift-add */
 }
 
 // table draw number K (0..4): scans the opponents' holes (n_regs registers, wave-uniform) and the K earlier table holes
@@ -521,8 +537,8 @@ MCQ_HD uint32_t mcq_draw_table(uint32_t r, uint32_t (&H)[5], uint32_t &hb, uint3
     for (int i = 0; i < 5; i++)
         if ((uint32_t)i < n_regs) mcq_hole_reg(rb, H[i], k);
     if (K > 0) mcq_hole_reg(rb, hb, k);
-    if (K < 4) mcq_hole_put<K>(hb, r); /* the hole of a fifth table card is never looked at */
-    return k;
+    if (K < 4) mcq_hole_put<K>(hb, rb); /* the hole of a fifth table card is never looked at */
+    return mcq_opaque(k);
 }
 
 // One Monte-Carlo iteration of one lane.  The opponents' hole cards stay in registers (statically indexed:

@@ -118,13 +118,13 @@ void pick_geometry(const mcq_ctx *c, int mode, uint64_t total_tasks, uint32_t *g
 int run_slice(mcq_ctx *c, int mode, const mcq_query *d_q, uint32_t n, mcq_result *d_res, uint64_t seed,
               uint64_t first_qid, uint64_t total_tasks, const uint8_t *d_draws, const uint64_t *d_off, hipStream_t s,
               bool timed) {
-    HIP_TRY(c->d_prefix.reserve(((size_t)n + 1) * sizeof(uint32_t)));
-    HIP_TRY(mcq_launch_prep(d_q, n, d_res, (uint32_t *)c->d_prefix.p, s));
+    HIP_TRY(c->d_prefix.reserve(((size_t)n + 1) * sizeof(uint64_t)));
+    HIP_TRY(mcq_launch_prep(d_q, n, d_res, (uint64_t *)c->d_prefix.p, s));
     uint32_t grid, block;
     pick_geometry(c, mode, total_tasks, &grid, &block);
     const int slot = (int)(c->n_timed % mcq_ctx::kRing);
     if (timed) HIP_TRY(hipEventRecord(c->ev0[slot], s));
-    HIP_TRY(mcq_launch_eval(mode, d_q, n, (const uint32_t *)c->d_prefix.p, d_res, seed, first_qid, c->d_luts, d_draws,
+    HIP_TRY(mcq_launch_eval(mode, d_q, n, (const uint64_t *)c->d_prefix.p, d_res, seed, first_qid, c->d_luts, d_draws,
                             d_off, grid, block, s));
     if (timed) {
         HIP_TRY(hipEventRecord(c->ev1[slot], s));

@@ -4,10 +4,13 @@
 // wave each run 16 of them (production mode: lane = one RNG stream of 16 consecutive iterations; parity
 // mode: iterations interleaved so that the draw bytes of a wave are contiguous).  All lanes of a wave work
 // on the same query, so deck length, loop bounds and the query record are wave-uniform (SGPRs, scalar
-// branches); only the rare r1 == r2 re-draw diverges.  A persistent grid of waves strides over the task list.
+// branches) and no lane diverges.  The task list, weighted by an instruction estimate per query, is cut into
+// one contiguous slice per resident wave: a wave keeps its tallies in registers while the query stays the
+// same and issues one set of atomics per (wave, query) -- HBM traffic stays at the algorithmic 120 B/query
+// plus a few KB of table image per block.
 //
 // Memory: 16 B in / 104 B out per QUERY; per iteration nothing touches HBM in production mode (parity mode
-// reads <= 23 draw bytes).  LDS holds the three lookup tables and the opponents' hole cards of every lane.
+// reads <= 23 draw bytes).  LDS holds the lookup tables (97 KB per block) and one 64-entry base deck per wave.
 #include <hip/hip_runtime.h>
 
 #include "mcq_device.hpp"
@@ -40,37 +43,39 @@ __device__ __forceinline__ void load_tables(LdsTables &dst, const McqTables *__r
 }
 
 // ---------------------------------------------------------------------------------------------- prep
-// One block.  Validates every query, zeroes its result row and builds the exclusive prefix of wave-task
-// counts (prefix[n] = total).  Invalid queries get no tasks, runs = 0 and passes = UINT64_MAX.
+// One block.  Validates every query, zeroes its result row and builds the exclusive prefix of the queries'
+// scheduling cost (tasks x weight; prefix[n] = total).  Invalid queries cost nothing and get runs = 0,
+// passes = UINT64_MAX.
 __global__ __launch_bounds__(1024) void mcq_prep_kernel(const mcq_query *__restrict__ q, uint32_t n,
-                                                        mcq_result *__restrict__ res, uint32_t *__restrict__ prefix) {
-    __shared__ uint32_t part[1024];
-    __shared__ uint32_t carry;
+                                                        mcq_result *__restrict__ res, uint64_t *__restrict__ prefix) {
+    __shared__ uint64_t part[1024];
+    __shared__ uint64_t carry;
     const uint32_t tid = threadIdx.x;
     if (tid == 0) carry = 0;
     __syncthreads();
     for (uint32_t base = 0; base < n; base += 1024) {
-        uint32_t i = base + tid, tasks = 0;
+        uint32_t i = base + tid;
+        uint64_t cost = 0;
         if (i < n) {
             const uint4 raw = reinterpret_cast<const uint4 *>(q)[i];
             const McqQueryWords qq = {raw.x, raw.y, raw.z, raw.w};
             bool ok = mcq_query_valid(qq);
-            tasks = ok ? (qq.runs() + MCQ_TASK_ITERS - 1) / MCQ_TASK_ITERS : 0u;
+            cost = ok ? (uint64_t)mcq_task_count(qq) * mcq_task_weight(qq) : 0ull;
             uint64_t *r = reinterpret_cast<uint64_t *>(res + i);
             r[0] = ok ? qq.runs() : 0ull;
             r[1] = ok ? 0ull : ~0ull;
 #pragma unroll
             for (int k = 2; k < 13; k++) r[k] = 0;
         }
-        part[tid] = tasks;
+        part[tid] = cost;
         __syncthreads();
         for (uint32_t off = 1; off < 1024; off <<= 1) { /* Hillis-Steele inclusive scan */
-            uint32_t v = tid >= off ? part[tid - off] : 0u;
+            uint64_t v = tid >= off ? part[tid - off] : 0ull;
             __syncthreads();
             part[tid] += v;
             __syncthreads();
         }
-        if (i < n) prefix[i] = carry + part[tid] - tasks;
+        if (i < n) prefix[i] = carry + part[tid] - cost;
         __syncthreads();
         if (tid == 1023) carry += part[1023];
         __syncthreads();
@@ -79,13 +84,53 @@ __global__ __launch_bounds__(1024) void mcq_prep_kernel(const mcq_query *__restr
 }
 
 // ---------------------------------------------------------------------------------------------- eval
+struct WaveTally { /* per-lane running sums of the current (wave, query) pair */
+    uint32_t code[MCQ_N_CODES], tie, passes;
+    bool dirty;
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int c = 0; c < MCQ_N_CODES; c++) code[c] = 0;
+        tie = passes = 0;
+        dirty = false;
+    }
+    __device__ __forceinline__ void add(const McqLaneAcc &a) {
+#pragma unroll
+        for (int c = 0; c < MCQ_N_CODES; c++)
+            if (c != 5) code[c] += (uint32_t)(a.types >> (6 * c)) & 63u;
+        tie += a.tie;
+        passes += a.passes;
+        dirty = true;
+    }
+    /* lanes -> wave (shuffles) -> one 64-bit atomic per counter */
+    __device__ __forceinline__ void flush(mcq_result *row, uint32_t lane) {
+        if (!dirty) return;
+        uint32_t wins = 0;
+        uint64_t mine = 0;
+#pragma unroll
+        for (uint32_t c = 0; c < MCQ_N_CODES; c++) {
+            if (c == 5) continue;
+            const uint32_t v = wave_sum(code[c]);
+            wins += v;
+            if (lane == 3u + mcq_code_to_type(c)) mine = v;
+        }
+        const uint32_t ties = wave_sum(tie);
+        const uint32_t pass = wave_sum(passes);
+        if (lane == 0) mine = pass;
+        if (lane == 1) mine = wins - ties;
+        if (lane == 2) mine = ties;
+        if (lane < 12 && mine != 0)
+            atomicAdd(reinterpret_cast<unsigned long long *>(row) + 1 + lane, (unsigned long long)mine);
+        clear();
+    }
+};
+
 template <int MODE>
 __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__restrict__ queries, uint32_t n,
-                                                                const uint32_t *__restrict__ prefix,
-                                                                mcq_result *__restrict__ res, uint64_t seed,
-                                                                uint64_t first_qid, const McqTables *__restrict__ g_tab,
-                                                                const uint8_t *__restrict__ draws,
-                                                                const uint64_t *__restrict__ draw_off) {
+                                                             const uint64_t *__restrict__ prefix,
+                                                             mcq_result *__restrict__ res, uint64_t seed,
+                                                             uint64_t first_qid, const McqTables *__restrict__ g_tab,
+                                                             const uint8_t *__restrict__ draws,
+                                                             const uint64_t *__restrict__ draw_off) {
     __shared__ __attribute__((aligned(16))) LdsTables tab;
     __shared__ McqCard base_tab[kMaxBlock]; /* per wave: the query's ordered remaining deck, 64 entries x 16 B */
     load_tables(tab, g_tab);
@@ -93,27 +138,52 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t waves_per_block = blockDim.x >> 6;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * waves_per_block + (threadIdx.x >> 6));
-    const uint32_t n_waves = gridDim.x * waves_per_block;
-    const uint32_t total = prefix[n];
+    const uint64_t n_waves = (uint64_t)gridDim.x * waves_per_block;
+    const uint64_t total = prefix[n];
+    /* this wave's slice of the cost axis; a task belongs to the slice its start position falls into */
+    const uint64_t lo = total * wave / n_waves, hi = total * (wave + 1ull) / n_waves;
+    if (lo >= hi) return;
     McqCard *base = base_tab + (threadIdx.x & ~63u);
 
-    for (uint32_t t = wave; t < total; t += n_waves) {
-        /* query of task t: last q with prefix[q] <= t (wave-uniform binary search, scalar loads) */
-        uint32_t lo = 0, hi = n;
-        while (hi - lo > 1) {
-            uint32_t mid = (lo + hi) >> 1;
-            if (prefix[mid] <= t) lo = mid; else hi = mid;
+    uint32_t a = 0, b = n; /* last query with prefix <= lo: it has a positive cost because lo < total */
+    while (b - a > 1) {
+        const uint32_t mid = (a + b) >> 1;
+        if (prefix[mid] <= lo) a = mid; else b = mid;
+    }
+    uint32_t qi = __builtin_amdgcn_readfirstlane(a);
+    uint32_t task = 0, n_tasks = 0, weight = 1;
+    uint64_t pfx = 0;
+    McqQueryCtx qc;
+    WaveTally tally;
+    tally.clear();
+    bool fresh = true; /* query record qi not loaded yet */
+    for (;;) {
+        if (fresh) {
+            if (qi >= n) break;
+            const uint4 raw = reinterpret_cast<const uint4 *>(queries)[qi];
+            const McqQueryWords q = {raw.x, raw.y, raw.z, raw.w};
+            pfx = prefix[qi];
+            const bool ok = prefix[qi + 1] > pfx; /* zero cost: invalid or runs == 0 */
+            n_tasks = ok ? mcq_task_count(q) : 0u;
+            weight = mcq_task_weight(q);
+            task = 0;
+            if (pfx < lo) task = (uint32_t)((lo - pfx + weight - 1) / weight); /* only for the first query */
+            fresh = false;
+            if (ok) {
+                mcq_query_ctx(q, qc);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); /* earlier lookups are done (same wave) */
+                base[lane] = mcq_base_entry(qc, lane, tab.sel8);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
         }
-        const uint32_t qi = __builtin_amdgcn_readfirstlane(lo);
-        const uint32_t task = t - prefix[qi];
-        const uint4 raw = reinterpret_cast<const uint4 *>(queries)[qi];
-        const McqQueryWords q = {raw.x, raw.y, raw.z, raw.w};
-        McqQueryCtx qc;
-        mcq_query_ctx(q, qc);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); /* the previous task's lookups are done (same wave) */
-        base[lane] = mcq_base_entry(qc, lane, tab.sel8);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        if (task >= n_tasks) {
+            tally.flush(res + qi, lane);
+            qi++;
+            fresh = true;
+            continue;
+        }
+        if (pfx + (uint64_t)task * weight >= hi) break;
 
         McqLaneAcc acc = {0, 0, 0};
         if (MODE == MCQ_MODE_PHILOX) {
@@ -140,25 +210,10 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
             }
             acc.passes = 0; /* counted by the host while parsing the MT19937 stream */
         }
-
-        /* tallies: lanes -> wave (shuffles) -> one 64-bit atomic per counter per task */
-        uint32_t wins = 0;
-        uint64_t mine = 0;
-#pragma unroll
-        for (uint32_t code = 0; code < MCQ_N_CODES; code++) {
-            if (code == 5) continue;
-            uint32_t v = wave_sum((uint32_t)(acc.types >> (6 * code)) & 63u);
-            wins += v;
-            if (lane == 3u + mcq_code_to_type(code)) mine = v;
-        }
-        const uint32_t ties = wave_sum(acc.tie);
-        const uint32_t passes = wave_sum(acc.passes);
-        if (lane == 0) mine = passes;
-        if (lane == 1) mine = wins - ties;
-        if (lane == 2) mine = ties;
-        if (lane < 12 && mine != 0)
-            atomicAdd(reinterpret_cast<unsigned long long *>(res + qi) + 1 + lane, (unsigned long long)mine);
+        tally.add(acc);
+        task++;
     }
+    if (qi < n) tally.flush(res + qi, lane);
 }
 
 // ---------------------------------------------------------------------------------------------- showdown
@@ -192,12 +247,12 @@ __global__ __launch_bounds__(256) void mcq_showdown_kernel(const uint8_t *__rest
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------- launchers
-hipError_t mcq_launch_prep(const mcq_query *d_q, uint32_t n, mcq_result *d_res, uint32_t *d_prefix, hipStream_t s) {
+hipError_t mcq_launch_prep(const mcq_query *d_q, uint32_t n, mcq_result *d_res, uint64_t *d_prefix, hipStream_t s) {
     hipLaunchKernelGGL(mcq_prep_kernel, dim3(1), dim3(1024), 0, s, d_q, n, d_res, d_prefix);
     return hipGetLastError();
 }
 
-hipError_t mcq_launch_eval(int mode, const mcq_query *d_q, uint32_t n, const uint32_t *d_prefix, mcq_result *d_res,
+hipError_t mcq_launch_eval(int mode, const mcq_query *d_q, uint32_t n, const uint64_t *d_prefix, mcq_result *d_res,
                            uint64_t seed, uint64_t first_qid, const McqTables *d_luts, const uint8_t *d_draws,
                            const uint64_t *d_draw_off, uint32_t grid, uint32_t block, hipStream_t s) {
     if (mode == MCQ_MODE_PHILOX)
