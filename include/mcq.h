@@ -91,6 +91,13 @@ MCQ_API int mcq_eval_batch(mcq_ctx *ctx, const mcq_query *q, size_t n, uint64_t 
 /* n == 1 convenience: exactly get_equity's arguments after card-string conversion. */
 MCQ_API int mcq_eval_one(mcq_ctx *ctx, const mcq_query *q, uint64_t seed, int mode, mcq_result *out);
 
+/* Parity mode coupled to numpy's GLOBAL random state, as consecutive reference calls are: the n
+ * queries consume ONE MT19937 stream in order.  mt_key[624] / *mt_pos are numpy's state words and position
+ * (np.random.get_state()[1], [2]); on return they hold the state after the last query, so
+ * np.random.set_state(...) leaves numpy exactly where the reference's own calls would have left it. */
+MCQ_API int mcq_eval_batch_numpy_stream(mcq_ctx *ctx, const mcq_query *q, size_t n, uint32_t *mt_key, uint32_t *mt_pos,
+                                mcq_result *out);
+
 /* Same computation with queries and results RESIDENT IN HBM: d_queries -> mcq_query[n], d_results ->
  * mcq_result[n] (overwritten), both device pointers on this context's device; hip_stream is the hipStream_t
  * to launch on (NULL = HIP's null stream, as everywhere in HIP).  Asynchronous: returns after enqueueing,

@@ -76,6 +76,8 @@ def load_library():
         L.mcq_eval_batch.restype = C.c_int
         L.mcq_eval_one.argtypes = [vp, vp, u64, C.c_int, vp]
         L.mcq_eval_one.restype = C.c_int
+        L.mcq_eval_batch_numpy_stream.argtypes = [vp, vp, sz, vp, vp, vp]
+        L.mcq_eval_batch_numpy_stream.restype = C.c_int
         L.mcq_eval_batch_device.argtypes = [vp, vp, sz, u64, u64, vp, vp]
         L.mcq_eval_batch_device.restype = C.c_int
         L.mcq_showdown.argtypes = [vp, vp, sz, C.c_int, vp, vp, vp]
@@ -155,6 +157,21 @@ class Engine:
                                       int(first_query_id) & (2 ** 64 - 1), int(mode), out.ctypes.data)
         if rc:
             _raise(rc)
+        return out
+
+    def eval_batch_numpy_stream(self, queries):
+        """Parity mode on numpy's GLOBAL random state: the queries consume np.random's MT19937 stream in order,
+        exactly as consecutive reference calls do, and np.random is left where those calls would leave it."""
+        q = np.ascontiguousarray(queries, dtype=QUERY_DTYPE).reshape(-1)
+        out = np.zeros(len(q), RESULT_DTYPE)
+        st = np.random.get_state()
+        key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
+        pos = C.c_uint32(int(st[2]))
+        rc = self._lib.mcq_eval_batch_numpy_stream(self._ctx, q.ctypes.data, len(q), key.ctypes.data, C.byref(pos),
+                                                   out.ctypes.data)
+        if rc:
+            _raise(rc)
+        np.random.set_state((st[0], key, int(pos.value), st[3], st[4]))
         return out
 
     def eval_batch_device(self, d_queries, n, seed, d_results, first_query_id=0, stream=None):

@@ -146,6 +146,103 @@ int validate(const mcq_query *q, size_t n) {
 
 }  // namespace
 
+extern "C" int mcq_kernel_times(mcq_ctx *c, float *ms, int max_n);
+
+namespace {
+
+/* parity mode: chunks of queries whose draw bytes fit the staging budget.  stream == nullptr: query i replays
+ * np.random.seed((seed + first_qid + i) mod 2^32) (parsed in parallel); otherwise all queries continue the
+ * one MT19937 stream `stream` in order, as consecutive reference calls share numpy's global state. */
+int replay_batch(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed, uint64_t first_query_id, McqMt19937 *stream,
+                 mcq_result *out) {
+    std::vector<uint64_t> passes(n, 0);
+    float replay_ms = 0.f;
+    size_t a = 0;
+    while (a < n) {
+        size_t b = a;
+        uint64_t bytes = 0, tasks = 0;
+        HIP_TRY(c->h_off.reserve((n - a < 65536 ? n - a : 65536) * sizeof(uint64_t)));
+        uint64_t *off = (uint64_t *)c->h_off.p;
+        while (b < n && b - a < 65536) {
+            uint64_t stride = ((uint64_t)q[b].runs + 63u) & ~63ull;
+            uint64_t need = stride * mcq_draws_per_iteration(q[b]);
+            if (b > a && bytes + need > kReplayChunkBytes) break;
+            off[b - a] = bytes;
+            bytes += need;
+            tasks += tasks_of(q[b]);
+            b++;
+        }
+        const size_t m = b - a;
+        HIP_TRY(c->h_draws.reserve(bytes + 64));
+        HIP_TRY(c->d_draws.reserve(bytes + 64));
+        HIP_TRY(c->d_off.reserve(m * sizeof(uint64_t)));
+        uint8_t *hd = (uint8_t *)c->h_draws.p;
+        if (stream) {
+            for (size_t i = 0; i < m; i++) {
+                const mcq_query &qq = q[a + i];
+                uint64_t stride = ((uint64_t)qq.runs + 63u) & ~63ull;
+                passes[a + i] = mcq_replay_parse_stream(qq, *stream, hd + off[i], stride);
+            }
+        } else {
+            std::atomic<size_t> next(0);
+            unsigned hw = std::thread::hardware_concurrency();
+            size_t nt = hw ? hw : 4;
+            if (nt > 32) nt = 32;
+            if (nt > m) nt = m;
+            auto work = [&]() {
+                for (size_t i = next.fetch_add(1); i < m; i = next.fetch_add(1)) {
+                    const mcq_query &qq = q[a + i];
+                    uint64_t stride = ((uint64_t)qq.runs + 63u) & ~63ull;
+                    passes[a + i] = mcq_replay_parse(qq, (uint32_t)(seed + first_query_id + a + i), hd + off[i], stride);
+                }
+            };
+            std::vector<std::thread> th;
+            for (size_t t = 1; t < nt; t++) th.emplace_back(work);
+            work();
+            for (auto &t : th) t.join();
+        }
+        HIP_TRY(hipMemcpyAsync(c->d_draws.p, hd, bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_off.p, off, m * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+        int rc = run_slice(c, MCQ_MODE_REPLAY_MT19937, (const mcq_query *)c->d_q.p + a, (uint32_t)m,
+                           (mcq_result *)c->d_res.p + a, seed, first_query_id + a, tasks, (const uint8_t *)c->d_draws.p,
+                           (const uint64_t *)c->d_off.p, c->stream, true);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(c->stream)); /* staging buffers are reused by the next chunk */
+        float ms = 0.f;
+        if (mcq_kernel_times(c, &ms, 1) == 1) replay_ms += ms;
+        a = b;
+    }
+    HIP_TRY(hipMemcpyAsync(c->h_res.p, c->d_res.p, n * sizeof(mcq_result), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(out, c->h_res.p, n * sizeof(mcq_result));
+    for (size_t i = 0; i < n; i++) out[i].passes = passes[i];
+    c->last_ms = replay_ms;
+    return MCQ_OK;
+}
+
+/* validation + query upload shared by the host entry points */
+int stage_queries(mcq_ctx *c, const mcq_query *q, size_t n, mcq_result *out, const char *who) {
+    if (!c) return fail(MCQ_EINVAL, who, "null context");
+    if (!q || !out) return fail(MCQ_EINVAL, who, "null buffer");
+    if (n > 0x7fffffffu) return fail(MCQ_EINVAL, who, "n too large");
+    int rc = validate(q, n);
+    if (rc) return rc;
+    uint64_t total_tasks = 0;
+    for (size_t i = 0; i < n; i++) total_tasks += tasks_of(q[i]);
+    if (total_tasks > 0xfffffff0ull) return fail(MCQ_EINVAL, who, "too many iterations in one call");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(c->h_q.reserve(n * sizeof(mcq_query)));
+    HIP_TRY(c->h_res.reserve(n * sizeof(mcq_result)));
+    HIP_TRY(c->d_q.reserve(n * sizeof(mcq_query)));
+    HIP_TRY(c->d_res.reserve(n * sizeof(mcq_result)));
+    memcpy(c->h_q.p, q, n * sizeof(mcq_query));
+    HIP_TRY(hipMemcpyAsync(c->d_q.p, c->h_q.p, n * sizeof(mcq_query), hipMemcpyHostToDevice, c->stream));
+    c->last_ms = 0.f;
+    return MCQ_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 const char *mcq_last_error(void) { return g_err.c_str(); }
@@ -263,25 +360,12 @@ int mcq_eval_batch_device(mcq_ctx *c, const void *d_queries, size_t n, uint64_t 
 
 int mcq_eval_batch(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed, uint64_t first_query_id, int mode,
                    mcq_result *out) {
-    if (!c) return fail(MCQ_EINVAL, "mcq_eval_batch: null context");
     if (mode != MCQ_MODE_PHILOX && mode != MCQ_MODE_REPLAY_MT19937) return fail(MCQ_EINVAL, "mcq_eval_batch: bad mode");
     if (n == 0) return MCQ_OK;
-    if (!q || !out) return fail(MCQ_EINVAL, "mcq_eval_batch: null buffer");
-    if (n > 0x7fffffffu) return fail(MCQ_EINVAL, "mcq_eval_batch: n too large");
-    int rc = validate(q, n);
+    int rc = stage_queries(c, q, n, out, "mcq_eval_batch");
     if (rc) return rc;
     uint64_t total_tasks = 0;
     for (size_t i = 0; i < n; i++) total_tasks += tasks_of(q[i]);
-    if (total_tasks > 0xfffffff0ull) return fail(MCQ_EINVAL, "mcq_eval_batch: too many iterations in one call");
-
-    HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(c->h_q.reserve(n * sizeof(mcq_query)));
-    HIP_TRY(c->h_res.reserve(n * sizeof(mcq_result)));
-    HIP_TRY(c->d_q.reserve(n * sizeof(mcq_query)));
-    HIP_TRY(c->d_res.reserve(n * sizeof(mcq_result)));
-    memcpy(c->h_q.p, q, n * sizeof(mcq_query));
-    HIP_TRY(hipMemcpyAsync(c->d_q.p, c->h_q.p, n * sizeof(mcq_query), hipMemcpyHostToDevice, c->stream));
-    c->last_ms = 0.f;
 
     if (mode == MCQ_MODE_PHILOX) {
         rc = run_slice(c, mode, (const mcq_query *)c->d_q.p, (uint32_t)n, (mcq_result *)c->d_res.p, seed,
@@ -294,68 +378,27 @@ int mcq_eval_batch(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed, uint
         return MCQ_OK;
     }
 
-    /* parity mode: chunks of queries whose draw bytes fit the staging budget */
-    std::vector<uint64_t> passes(n, 0);
-    float replay_ms = 0.f;
-    size_t a = 0;
-    while (a < n) {
-        size_t b = a;
-        uint64_t bytes = 0, tasks = 0;
-        HIP_TRY(c->h_off.reserve((n - a < 65536 ? n - a : 65536) * sizeof(uint64_t)));
-        uint64_t *off = (uint64_t *)c->h_off.p;
-        while (b < n && b - a < 65536) {
-            uint64_t stride = ((uint64_t)q[b].runs + 63u) & ~63ull;
-            uint64_t need = stride * mcq_draws_per_iteration(q[b]);
-            if (b > a && bytes + need > kReplayChunkBytes) break;
-            off[b - a] = bytes;
-            bytes += need;
-            tasks += tasks_of(q[b]);
-            b++;
-        }
-        const size_t m = b - a;
-        HIP_TRY(c->h_draws.reserve(bytes + 64));
-        HIP_TRY(c->d_draws.reserve(bytes + 64));
-        HIP_TRY(c->d_off.reserve(m * sizeof(uint64_t)));
-        uint8_t *hd = (uint8_t *)c->h_draws.p;
-        {
-            std::atomic<size_t> next(0);
-            unsigned hw = std::thread::hardware_concurrency();
-            size_t nt = hw ? hw : 4;
-            if (nt > 32) nt = 32;
-            if (nt > m) nt = m;
-            auto work = [&]() {
-                for (size_t i = next.fetch_add(1); i < m; i = next.fetch_add(1)) {
-                    const mcq_query &qq = q[a + i];
-                    uint64_t stride = ((uint64_t)qq.runs + 63u) & ~63ull;
-                    passes[a + i] = mcq_replay_parse(qq, (uint32_t)(seed + first_query_id + a + i), hd + off[i], stride);
-                }
-            };
-            std::vector<std::thread> th;
-            for (size_t t = 1; t < nt; t++) th.emplace_back(work);
-            work();
-            for (auto &t : th) t.join();
-        }
-        HIP_TRY(hipMemcpyAsync(c->d_draws.p, hd, bytes, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->d_off.p, off, m * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-        rc = run_slice(c, mode, (const mcq_query *)c->d_q.p + a, (uint32_t)m, (mcq_result *)c->d_res.p + a, seed,
-                       first_query_id + a, tasks, (const uint8_t *)c->d_draws.p, (const uint64_t *)c->d_off.p,
-                       c->stream, true);
-        if (rc) return rc;
-        HIP_TRY(hipStreamSynchronize(c->stream)); /* staging buffers are reused by the next chunk */
-        float ms = 0.f;
-        if (mcq_kernel_times(c, &ms, 1) == 1) replay_ms += ms;
-        a = b;
-    }
-    HIP_TRY(hipMemcpyAsync(c->h_res.p, c->d_res.p, n * sizeof(mcq_result), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    memcpy(out, c->h_res.p, n * sizeof(mcq_result));
-    for (size_t i = 0; i < n; i++) out[i].passes = passes[i];
-    c->last_ms = replay_ms;
-    return MCQ_OK;
+    return replay_batch(c, q, n, seed, first_query_id, nullptr, out);
 }
 
 int mcq_eval_one(mcq_ctx *c, const mcq_query *q, uint64_t seed, int mode, mcq_result *out) {
     return mcq_eval_batch(c, q, 1, seed, 0, mode, out);
+}
+
+int mcq_eval_batch_numpy_stream(mcq_ctx *c, const mcq_query *q, size_t n, uint32_t *mt_key, uint32_t *mt_pos,
+                                mcq_result *out) {
+    if (n == 0) return MCQ_OK;
+    if (!mt_key || !mt_pos || *mt_pos > 624) return fail(MCQ_EINVAL, "mcq_eval_batch_numpy_stream: bad MT19937 state");
+    int rc = stage_queries(c, q, n, out, "mcq_eval_batch_numpy_stream");
+    if (rc) return rc;
+    McqMt19937 g;
+    memcpy(g.mt, mt_key, sizeof g.mt);
+    g.pos = *mt_pos;
+    rc = replay_batch(c, q, n, 0, 0, &g, out);
+    if (rc) return rc;
+    memcpy(mt_key, g.mt, sizeof g.mt);
+    *mt_pos = g.pos;
+    return MCQ_OK;
 }
 
 int mcq_showdown(mcq_ctx *c, const uint8_t *hands, size_t n_tables, int n_players, uint8_t *winner,

@@ -60,10 +60,10 @@ static inline uint32_t mcq_draws_per_iteration(const mcq_query &q) {
     return 2u * (q.n_players - 1u) + (5u - q.n_board);
 }
 
-// Fills draws[d * stride + it] for it < q.runs, d < mcq_draws_per_iteration(q); returns `passes`.
-static inline uint64_t mcq_replay_parse(const mcq_query &q, uint32_t seed32, uint8_t *draws, size_t stride) {
-    McqMt19937 g;
-    g.seed(seed32);
+// Fills draws[d * stride + it] for it < q.runs, d < mcq_draws_per_iteration(q), continuing the stream of `g`
+// (so consecutive queries can share one generator, as the reference's calls share numpy's global state);
+// returns `passes`.
+static inline uint64_t mcq_replay_parse_stream(const mcq_query &q, McqMt19937 &g, uint8_t *draws, size_t stride) {
     const uint32_t n_opp = q.n_players - 1u, n_deal = 5u - q.n_board;
     uint64_t passes = 0;
     for (uint32_t it = 0; it < q.runs; it++) {
@@ -88,4 +88,11 @@ static inline uint64_t mcq_replay_parse(const mcq_query &q, uint32_t seed32, uin
         }
     }
     return passes;
+}
+
+// One query replaying np.random.seed(seed32).
+static inline uint64_t mcq_replay_parse(const mcq_query &q, uint32_t seed32, uint8_t *draws, size_t stride) {
+    McqMt19937 g;
+    g.seed(seed32);
+    return mcq_replay_parse_stream(q, g, draws, stride);
 }

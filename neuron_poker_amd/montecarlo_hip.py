@@ -32,7 +32,7 @@ from .cards import TYPES, card_id
 
 __all__ = ["get_equity", "get_equity_batch", "MonteCarlo", "seed", "configure"]
 
-_state = {"seed": int.from_bytes(os.urandom(8), "little"), "counter": 0,
+_state = {"seed": int.from_bytes(os.urandom(8), "little"), "counter": 0, "couple_numpy": False,
           "mode": _lib.MODE_REPLAY_MT19937 if os.environ.get("MCQ_MODE", "philox").lower() == "replay"
           else _lib.MODE_PHILOX}
 _lock = threading.Lock()
@@ -47,12 +47,17 @@ def seed(s):
         _state["counter"] = 0
 
 
-def configure(mode=None):
-    """mode: 'philox' (default, production) or 'replay' (bit-exact MT19937 replay of the reference)."""
+def configure(mode=None, couple_numpy=None):
+    """mode: 'philox' (default, production) or 'replay' (bit-exact MT19937 replay of the reference).
+    couple_numpy=True (replay mode only): draw from numpy's GLOBAL random state and advance it exactly as the
+    reference does, so that code sharing np.random with the equity call (gym_env/env.py:142,680,686 deals with
+    it) follows the reference's trajectory after np.random.seed(s)."""
     if mode is not None:
         if mode not in _MODES:
             raise ValueError("mode must be 'philox' or 'replay'")
         _state["mode"] = _MODES[mode]
+    if couple_numpy is not None:
+        _state["couple_numpy"] = bool(couple_numpy)
 
 
 def _take_ids(n):
@@ -101,11 +106,14 @@ class MonteCarlo(object):
         q = _query(list(original_player_card_list[0]), list(original_table_card_list), player_amount, maxRuns)
         eng = self._engine or _lib.default_engine()
         m = _state["mode"] if mode is None else _MODES[mode]
-        if seed is None:
-            s, first = _take_ids(1)
+        if m == _lib.MODE_REPLAY_MT19937 and _state["couple_numpy"] and seed is None:
+            res = eng.eval_batch_numpy_stream(q)[0]
         else:
-            s, first = int(seed), 0
-        res = eng.eval_batch(q, s, first_query_id=first, mode=m)[0]
+            if seed is None:
+                s, first = _take_ids(1)
+            else:
+                s, first = int(seed), 0
+            res = eng.eval_batch(q, s, first_query_id=first, mode=m)[0]
         runs = int(res["runs"])
         wins = int(res["win"]) + int(res["tie"])
         self.result = res

@@ -14,6 +14,7 @@ What is captured (ids follow SURVEY.md section 8c):
   F2  deal_traces.npz       per (seed, hero, board, N): first K iterations' dealt cards, MT words/iteration
   F3  tallies.json          seeded run_montecarlo tallies (wins, passes, per-type wins, MT words)
   F4  stat_expectations.json the (hero, board, N, expected %) rows of tests/test_montecarlo_python.py
+  F6  sequence.json         consecutive calls on ONE seeded numpy stream, with a randint in between (8f-4)
 """
 import json
 import os
@@ -312,7 +313,40 @@ def gen_stats():
     print("stat_expectations:", len(rows))
 
 
+# ----------------------------------------------------------------------------- F6
+SEQUENCE = [  # consecutive calls sharing numpy's global state after ONE np.random.seed, like gym_env/env.py does
+    (['AH', 'KH'], [], 2, 3000), (['2C', '7D'], ['AS', 'KS', 'QS'], 6, 2000), (['TC', 'TH'], ['4D', 'QD', 'KC', '2S'], 3, 1500),
+    (['3H', '3S'], ['8S', '4S', 'QH', '8C', '4H'], 4, 1000), (['AS', 'AC'], [], 10, 500),
+]
+
+
+def gen_sequence():
+    out = []
+    for seed in (0, 20261004):
+        np.random.seed(seed)
+        calls = []
+        for hero, board, n, runs in SEQUENCE:
+            sim = mp.MonteCarlo()
+            sim.run_montecarlo([list(hero)], list(board), n, 1, maxRuns=runs, timeout=FAR, ghost_cards='',
+                               opponent_range=1)
+            by_type = {t: 0 for t in TYPES}
+            for k, v in sim.winnerCardTypeList.items():
+                by_type[k] = int(round(v * sim.runs))
+            between = int(np.random.randint(0, 52))  # the env deals with the same stream between equity calls
+            calls.append({"hero": hero, "board": board, "n_players": n, "runs": runs,
+                          "wins": int(round(sim.equity * sim.runs)), "passes": int(sim.passes),
+                          "by_type": [by_type[t] for t in TYPES], "randint52_after": between})
+        tail = [int(x) for x in np.random.randint(0, 2 ** 32, size=4, dtype=np.uint32)]
+        out.append({"seed": seed, "calls": calls, "next_words": tail})
+    with open(os.path.join(HERE, "sequence.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    print("sequence:", len(out))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "sequence":
+        gen_sequence()
+        sys.exit(0)
     g = np.random.default_rng(20261004)
     gen_stats()
     gen_cases()
@@ -320,3 +354,4 @@ if __name__ == "__main__":
     gen_showdowns(g)
     gen_traces()
     gen_tallies()
+    gen_sequence()

@@ -76,3 +76,17 @@ def philox(ctr, key):
     c, k, o = np.array(ctr, np.uint32), np.array(key, np.uint32), np.zeros(4, np.uint32)
     lib().hs_philox(_p(c, C.c_uint32), _p(k, C.c_uint32), _p(o, C.c_uint32))
     return o
+
+
+def run_replay_numpy_stream(query16):
+    """Consumes np.random's global MT19937 stream like a reference call and leaves it advanced."""
+    q = np.ascontiguousarray(query16, np.uint8)
+    out = np.zeros(13, np.uint64)
+    st = np.random.get_state()
+    key = np.ascontiguousarray(st[1], np.uint32).copy()
+    pos = C.c_uint32(int(st[2]))
+    rc = lib().hs_run_replay_stream(_p(q, C.c_uint8), _p(key, C.c_uint32), C.byref(pos), _p(out, C.c_uint64))
+    if rc:
+        raise ValueError(rc)
+    np.random.set_state((st[0], key, int(pos.value), st[3], st[4]))
+    return out

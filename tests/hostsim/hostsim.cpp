@@ -111,6 +111,34 @@ int hs_run_replay(const mcq_query *q, uint32_t seed32, mcq_result *out) {
     return MCQ_OK;
 }
 
+// parity mode continuing an MT19937 stream given as numpy state (key[624], pos); state updated in place
+int hs_run_replay_stream(const mcq_query *q, uint32_t *key, uint32_t *pos, mcq_result *out) {
+    if (!mcq_query_valid(mcq_query_words(*q))) return MCQ_EINVAL;
+    const McqTables &t = luts();
+    McqQueryCtx qc;
+    mcq_query_ctx(mcq_query_words(*q), qc);
+    McqCard base[64];
+    make_base(qc, t, base);
+    memset(out, 0, sizeof(*out));
+    out->runs = q->runs;
+    size_t stride = q->runs ? q->runs : 1;
+    std::vector<uint8_t> draws((size_t)mcq_draws_per_iteration(*q) * stride + 1);
+    McqMt19937 g;
+    memcpy(g.mt, key, sizeof g.mt);
+    g.pos = *pos;
+    out->passes = mcq_replay_parse_stream(*q, g, draws.data(), stride);
+    memcpy(key, g.mt, sizeof g.mt);
+    *pos = g.pos;
+    for (uint32_t it = 0; it < q->runs; it++) {
+        McqReplayDraws dr = {draws.data() + it, stride};
+        McqLaneAcc acc = {0, 0, 0};
+        mcq_iteration(qc, dr, base, t.tf, t.tops, t.sd, t.inv, acc);
+        acc.passes = 0;
+        fold(acc, out);
+    }
+    return MCQ_OK;
+}
+
 void hs_mt_words(uint32_t seed, uint32_t n, uint32_t *out) {
     McqMt19937 g;
     g.seed(seed);

@@ -263,3 +263,21 @@ def test_dropin_module_matches_reference_call_surface(eng):
     with pytest.raises(NotImplementedError):
         mh.MonteCarlo(eng).run_montecarlo([["AS", "KS"]], [], 2, 1, maxRuns=10, timeout=0, ghost_cards="",
                                           opponent_range=0.25)
+
+
+def test_numpy_stream_coupling_on_gpu(eng):
+    """replay mode drawing from and advancing numpy's GLOBAL state like the reference's calls."""
+    mh.configure(mode="replay", couple_numpy=True)
+    try:
+        for s in jload("sequence.json"):
+            np.random.seed(s["seed"])
+            for c in s["calls"]:
+                sim = mh.MonteCarlo(eng)
+                eq, _ = sim.run_montecarlo([c["hero"]], c["board"], c["n_players"], 1, maxRuns=c["runs"], timeout=0,
+                                           ghost_cards="")
+                assert (round(eq * c["runs"]), sim.passes) == (c["wins"], c["passes"]), c
+                assert [int(x) for x in sim.result["by_type"]] == c["by_type"]
+                assert int(np.random.randint(0, 52)) == c["randint52_after"]
+            assert [int(x) for x in np.random.randint(0, 2 ** 32, size=4, dtype=np.uint32)] == s["next_words"]
+    finally:
+        mh.configure(mode="philox", couple_numpy=False)

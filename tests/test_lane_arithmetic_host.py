@@ -111,3 +111,18 @@ def test_ctr_mode_equals_oracle_ctr(hero, board, n, runs):
         got = H.run_ctr(q, seed, qid)
         exp = O.run(O.MODE_CTR, hero, board, n, runs, seed, qid=qid)["tallies"]
         assert np.array_equal(got, exp), (seed, qid, got, exp)
+
+
+def test_numpy_stream_coupling_matches_reference_sequence():
+    """consecutive calls share numpy's global state; after each call np.random is exactly where the
+    reference leaves it (tests/golden/sequence.json was recorded from the reference)."""
+    with open(os.path.join(G, "sequence.json")) as f:
+        seqs = json.load(f)
+    for s in seqs:
+        np.random.seed(s["seed"])
+        for c in s["calls"]:
+            r = H.run_replay_numpy_stream(q16(c["hero"], c["board"], c["n_players"], c["runs"]))
+            assert int(r[2] + r[3]) == c["wins"] and int(r[1]) == c["passes"], c
+            assert [int(x) for x in r[4:]] == c["by_type"], c
+            assert int(np.random.randint(0, 52)) == c["randint52_after"]
+        assert [int(x) for x in np.random.randint(0, 2 ** 32, size=4, dtype=np.uint32)] == s["next_words"]
