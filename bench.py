@@ -71,6 +71,29 @@ def cpu_baseline(n_players, runs, seconds=12.0):
                       (len(hole), iters, n_players, threads, dt)}
 
 
+def cpu_reference_cpp(n_players, seconds=4.0):
+    """The reference's own C++ variant (tools/montecarlo_cpp, built into oracle/_ref by `make -C oracle ref` where
+    /root/reference exists; the binary travels with the repo snapshot), one thread, timed on this host."""
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_mc")
+    if not os.path.exists(exe):
+        return None
+    iters = 4000
+    try:
+        out = subprocess.run([exe, "equity", "AS", "KS", str(n_players), str(iters)], capture_output=True, text=True,
+                             timeout=120, check=True).stdout.split()
+        dt = float(out[1])
+        iters = int(max(iters, min(400000, iters * seconds / max(dt, 1e-3))))
+        out = subprocess.run([exe, "equity", "AS", "KS", str(n_players), str(iters)], capture_output=True, text=True,
+                             timeout=300, check=True).stdout.split()
+        dt = float(out[1])
+    except (OSError, subprocess.SubprocessError, ValueError, IndexError):
+        return None
+    return {"value": iters * n_players / dt, "unit": "hand-evals/s", "cores": 1, "kind": "reference",
+            "sample": "tools/montecarlo_cpp/Montecarlo.cpp montecarlo(AS KS, no table cards, %d players, %d "
+                      "iterations), %.1f s; uniform dealing, so a timing reference only" % (n_players, iters, dt)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -208,6 +231,9 @@ def main():
         out["other_configs"] = extras
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(N, runs)
+        ref = cpu_reference_cpp(N)
+        if ref:
+            out["cpu_baseline_reference_cpp"] = ref
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -45,6 +45,11 @@ extern "C" {
 #define MCQ_MODE_REPLAY_MT19937 1 /* parity: query i replays np.random.seed((seed + first_query_id + i) mod 2^32)
                                      exactly as tools/montecarlo_python.py consumes it -> bit-exact tallies */
 
+/* dealing law of MCQ_MODE_PHILOX (mcq_set_dealing_law); the parity mode always follows the reference */
+#define MCQ_LAW_REFERENCE 0 /* default: tools/montecarlo_python.py's law incl. its index bias (:170, :188) */
+#define MCQ_LAW_UNIFORM 1   /* opt-in: every remaining card equally likely -- what tools/montecarlo_cython.pyx:188
+                               and tools/montecarlo_cpp/Montecarlo.cpp:296-312 deal */
+
 /* One equity query (16 bytes, no pointers).  Mirrors the arguments of get_equity
  * (tools/montecarlo_python.py:401): hero's two cards, 0/3/4/5 known table cards, players, runs. */
 typedef struct mcq_query {
@@ -114,6 +119,9 @@ MCQ_API int mcq_eval_batch_device(mcq_ctx *ctx, const void *d_queries, size_t n,
 #define MCQ_KEY_TYPE(key) (((key) >> 28) - (((key) >> 28) >= 6u ? 1u : 0u))
 MCQ_API int mcq_showdown(mcq_ctx *ctx, const uint8_t *hands, size_t n_tables, int n_players, uint8_t *winner,
                  uint8_t *winner_type, uint32_t *keys);
+
+/* Select the dealing law used by MCQ_MODE_PHILOX on this context (MCQ_LAW_*). */
+MCQ_API int mcq_set_dealing_law(mcq_ctx *ctx, int law);
 
 /* Every evaluation-kernel launch is bracketed by a pair of HIP events on the stream it is launched on (a ring
  * of the 64 most recent launches).  mcq_kernel_times writes the durations in milliseconds of the latest

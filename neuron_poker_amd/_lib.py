@@ -82,6 +82,8 @@ def load_library():
         L.mcq_eval_batch_device.restype = C.c_int
         L.mcq_showdown.argtypes = [vp, vp, sz, C.c_int, vp, vp, vp]
         L.mcq_showdown.restype = C.c_int
+        L.mcq_set_dealing_law.argtypes = [vp, C.c_int]
+        L.mcq_set_dealing_law.restype = C.c_int
         L.mcq_kernel_times.argtypes = [vp, vp, C.c_int]
         L.mcq_kernel_times.restype = C.c_int
         L.mcq_last_kernel_ms.argtypes = [vp]
@@ -148,6 +150,15 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+    def set_dealing_law(self, law):
+        """'reference' (default: the Python reference's law incl. its index bias) or 'uniform' (unbiased)."""
+        code = {"reference": 0, "uniform": 1, 0: 0, 1: 1}.get(law)
+        if code is None:
+            raise ValueError("law must be 'reference' or 'uniform'")
+        rc = self._lib.mcq_set_dealing_law(self._ctx, code)
+        if rc:
+            _raise(rc)
 
     def eval_batch(self, queries, seed, first_query_id=0, mode=MODE_PHILOX):
         """queries: array of QUERY_DTYPE (host).  -> array of RESULT_DTYPE."""

@@ -211,16 +211,21 @@ struct McqXoshiro { /* xoshiro128++ (Blackman & Vigna) */
 //   is ever rejected, hence `passes` = one per opponent per iteration (added by the caller).
 //   Table cards, two per word: even draw: u = next(), idx = mulhi32(u, n), w = u * n; odd draw: idx = mulhi32(w, n)
 //   (n = deck length - 1: never the last card, montecarlo_python.py:188).  Bias of either <= 2401 / 2^32.
-// inv[d] = 2^20 / d + 1 makes (x * inv[d]) >> 20 == x / d exactly for x < d * d <= 2601 (checked in the tests).
-struct McqCtrDraws {
+// inv[d] = 2^20 / d + 1 makes (x * inv[d]) >> 20 == x / d exactly for x < (d + 1) * d <= 2652 (checked in the tests).
+// UNIFORM = true is the opt-in unbiased law (what montecarlo_cython.pyx:188 and
+// Montecarlo.cpp:296-312 intend): x = mulhi32(u, L (L-1)), (r1, r2) = (x / (L-1), x % (L-1)) -- every ordered pair
+// of distinct cards -- and table draws over all n = deck length cards.
+template <bool UNIFORM>
+struct McqCtrDrawsT {
+    static constexpr uint32_t kTableShort = UNIFORM ? 0u : 1u; /* table draw range = deck length - kTableShort */
     McqXoshiro rng;
     uint32_t w;
     MCQ_HDM void pair(uint32_t L, const uint32_t *inv, uint32_t &r1, uint32_t &r2) {
         const uint32_t dd = L - 1u;
-        const uint32_t x = mcq_mulhi(rng.next(), dd * dd);
+        const uint32_t x = mcq_mulhi(rng.next(), (UNIFORM ? L : dd) * dd);
         const uint32_t a = (x * inv[dd]) >> 20;
         const uint32_t c = x - a * dd;
-        r1 = a == c ? dd : a;
+        r1 = (!UNIFORM && a == c) ? dd : a;
         r2 = c;
     }
     template <int K>
@@ -233,11 +238,14 @@ struct McqCtrDraws {
         return mcq_mulhi(w, n);
     }
 };
+typedef McqCtrDrawsT<false> McqCtrDraws;
+typedef McqCtrDrawsT<true> McqCtrDrawsUniform;
 
 // Draw policy of the parity mode: the host has already turned the MT19937 stream into the accepted draw
 // values (one byte each, draw-major: draws[d * stride + iteration]); rejected pairs only count in `passes`,
 // which the host supplies.
 struct McqReplayDraws {
+    static constexpr uint32_t kTableShort = 1u;
     const uint8_t *p; /* &draws[iteration] */
     uint64_t stride;
     MCQ_HDM void pair(uint32_t, const uint32_t *, uint32_t &r1, uint32_t &r2) {
@@ -566,7 +574,7 @@ MCQ_HD void mcq_iteration(const McqQueryCtx &qc, Draws &dr, const McqCard *base,
     McqBoard b = qc.board;
 #define MCQ_TABLE(K)                                                                                           \
     if (K < qc.n_deal) {                                                                                       \
-        b.add(base[mcq_draw_table<K>(dr.template table<K>(L - 1), H, hb, n_regs)]); /* never the last card (l.188) */ \
+        b.add(base[mcq_draw_table<K>(dr.template table<K>(L - Draws::kTableShort), H, hb, n_regs)]); /* l.188 */ \
         L -= 1;                                                                                                \
     }
     MCQ_TABLE(0) MCQ_TABLE(1) MCQ_TABLE(2) MCQ_TABLE(3) MCQ_TABLE(4)

@@ -85,7 +85,8 @@ constexpr uint32_t kBlock = 1024;                /* threads per block of the eva
 struct mcq_ctx {
     int device = 0;
     int n_cu = 0;
-    int occ[2] = {1, 1}; /* resident kBlock-thread blocks per CU of the two eval kernels */
+    int occ[3] = {1, 1, 1}; /* resident kBlock-thread blocks per CU of the eval kernels (by internal mode) */
+    int law = MCQ_LAW_REFERENCE;
     hipStream_t stream = nullptr;
     static constexpr int kRing = 64; /* event pairs around the most recent evaluation-kernel launches */
     hipEvent_t ev0[kRing] = {}, ev1[kRing] = {};
@@ -118,6 +119,7 @@ void pick_geometry(const mcq_ctx *c, int mode, uint64_t total_tasks, uint32_t *g
 int run_slice(mcq_ctx *c, int mode, const mcq_query *d_q, uint32_t n, mcq_result *d_res, uint64_t seed,
               uint64_t first_qid, uint64_t total_tasks, const uint8_t *d_draws, const uint64_t *d_off, hipStream_t s,
               bool timed) {
+    if (mode == MCQ_MODE_PHILOX && c->law == MCQ_LAW_UNIFORM) mode = MCQ_INTERNAL_MODE_UNIFORM;
     HIP_TRY(c->d_prefix.reserve(((size_t)n + 1) * sizeof(uint64_t)));
     HIP_TRY(mcq_launch_prep(d_q, n, d_res, (uint64_t *)c->d_prefix.p, s));
     uint32_t grid, block;
@@ -315,7 +317,7 @@ mcq_ctx *mcq_create(int device, int flags) {
     }
     CREATE_TRY(hipMalloc((void **)&c->d_luts, sizeof(McqTables)));
     CREATE_TRY(hipMemcpy(c->d_luts, tabs, sizeof(McqTables), hipMemcpyHostToDevice));
-    for (int mode = 0; mode < 2; mode++) {
+    for (int mode = 0; mode < 3; mode++) {
         int occ = 0;
         CREATE_TRY(mcq_eval_occupancy(mode, (int)kBlock, &occ));
         c->occ[mode] = occ < 1 ? 1 : (occ > 8 ? 8 : occ);
@@ -335,6 +337,12 @@ int mcq_kernel_times(mcq_ctx *c, float *ms, int max_n) {
         HIP_TRY(hipEventElapsedTime(&ms[i], c->ev0[slot], c->ev1[slot]));
     }
     return n;
+}
+
+int mcq_set_dealing_law(mcq_ctx *c, int law) {
+    if (!c || (law != MCQ_LAW_REFERENCE && law != MCQ_LAW_UNIFORM)) return fail(MCQ_EINVAL, "mcq_set_dealing_law: bad argument");
+    c->law = law;
+    return MCQ_OK;
 }
 
 float mcq_last_kernel_ms(mcq_ctx *c) {

@@ -7,6 +7,8 @@
 
 struct McqTables;
 
+#define MCQ_INTERNAL_MODE_UNIFORM 2 /* MCQ_MODE_PHILOX with the context's dealing law set to MCQ_LAW_UNIFORM */
+
 hipError_t mcq_launch_prep(const mcq_query *d_q, uint32_t n, mcq_result *d_res, uint64_t *d_prefix, hipStream_t s);
 hipError_t mcq_launch_eval(int mode, const mcq_query *d_q, uint32_t n, const uint64_t *d_prefix, mcq_result *d_res,
                            uint64_t seed, uint64_t first_qid, const McqTables *d_luts, const uint8_t *d_draws,

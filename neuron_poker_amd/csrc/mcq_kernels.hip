@@ -186,11 +186,11 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
         if (pfx + (uint64_t)task * weight >= hi) break;
 
         McqLaneAcc acc = {0, 0, 0};
-        if (MODE == MCQ_MODE_PHILOX) {
+        if (MODE != MCQ_MODE_REPLAY_MT19937) {
             const uint32_t stream = task * MCQ_WAVE + lane;
             const uint64_t it0 = (uint64_t)stream * MCQ_STREAM_ITERS;
             if (it0 < qc.runs) {
-                McqCtrDraws dr;
+                McqCtrDrawsT<MODE == MCQ_INTERNAL_MODE_UNIFORM> dr;
                 dr.w = 0;
                 dr.rng.seed(seed, first_qid + qi, stream);
                 const uint32_t cnt = (uint32_t)min((uint64_t)MCQ_STREAM_ITERS, (uint64_t)qc.runs - it0);
@@ -258,6 +258,9 @@ hipError_t mcq_launch_eval(int mode, const mcq_query *d_q, uint32_t n, const uin
     if (mode == MCQ_MODE_PHILOX)
         hipLaunchKernelGGL(mcq_eval_kernel<MCQ_MODE_PHILOX>, dim3(grid), dim3(block), 0, s, d_q, n, d_prefix, d_res,
                            seed, first_qid, d_luts, d_draws, d_draw_off);
+    else if (mode == MCQ_INTERNAL_MODE_UNIFORM)
+        hipLaunchKernelGGL(mcq_eval_kernel<MCQ_INTERNAL_MODE_UNIFORM>, dim3(grid), dim3(block), 0, s, d_q, n, d_prefix,
+                           d_res, seed, first_qid, d_luts, d_draws, d_draw_off);
     else
         hipLaunchKernelGGL(mcq_eval_kernel<MCQ_MODE_REPLAY_MT19937>, dim3(grid), dim3(block), 0, s, d_q, n, d_prefix,
                            d_res, seed, first_qid, d_luts, d_draws, d_draw_off);
@@ -277,5 +280,8 @@ hipError_t mcq_launch_showdown(const uint8_t *d_hands, uint32_t n_tables, uint32
 hipError_t mcq_eval_occupancy(int mode, int block, int *blocks_per_cu) {
     if (mode == MCQ_MODE_PHILOX)
         return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, mcq_eval_kernel<MCQ_MODE_PHILOX>, block, 0);
+    if (mode == MCQ_INTERNAL_MODE_UNIFORM)
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, mcq_eval_kernel<MCQ_INTERNAL_MODE_UNIFORM>,
+                                                            block, 0);
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, mcq_eval_kernel<MCQ_MODE_REPLAY_MT19937>, block, 0);
 }

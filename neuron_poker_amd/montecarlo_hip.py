@@ -47,8 +47,10 @@ def seed(s):
         _state["counter"] = 0
 
 
-def configure(mode=None, couple_numpy=None):
+def configure(mode=None, couple_numpy=None, dealing=None):
     """mode: 'philox' (default, production) or 'replay' (bit-exact MT19937 replay of the reference).
+    dealing: 'reference' (default: the Python reference's law incl. its index bias) or 'uniform' (unbiased, what
+    the reference's Cython/C++ variants deal; production mode only) -- applied to the default engine.
     couple_numpy=True (replay mode only): draw from numpy's GLOBAL random state and advance it exactly as the
     reference does, so that code sharing np.random with the equity call (gym_env/env.py:142,680,686 deals with
     it) follows the reference's trajectory after np.random.seed(s)."""
@@ -58,6 +60,8 @@ def configure(mode=None, couple_numpy=None):
         _state["mode"] = _MODES[mode]
     if couple_numpy is not None:
         _state["couple_numpy"] = bool(couple_numpy)
+    if dealing is not None:
+        _lib.default_engine().set_dealing_law(dealing)
 
 
 def _take_ids(n):

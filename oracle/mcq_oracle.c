@@ -141,6 +141,8 @@ typedef struct {
 } rng_t;
 
 static uint32_t draw(rng_t *r, uint32_t n) { return r->kind == 0 ? np_randint(r->mt, n) : xo_draw(r->xo, n); }
+/* kind: 0 = MT19937 + numpy randint (the reference), 1 = MCQ-CTR v2 with the reference's dealing law,
+ * 2 = MCQ-CTR v2 with the UNIFORM law (what montecarlo_cython.pyx:188 and Montecarlo.cpp:296-312 intend) */
 
 /* ------------------------------------------------------------------------------------------ evaluator */
 enum { T_HIGH, T_PAIR, T_TWOPAIR, T_TRIPS, T_STRAIGHT, T_FLUSH, T_FULL, T_QUADS, T_SF };
@@ -340,6 +342,14 @@ static uint32_t deal_iteration(rng_t *rng, const uint8_t hero[2], const uint8_t 
     hole[0][0] = hero[0]; hole[0][1] = hero[1];
     deck_remove(&d, hero[0]); /* l.154-161 */
     deck_remove(&d, hero[1]);
+    for (int p = 1; p < n_players && rng->kind == 2; p++) { /* MCQ-CTR v2, UNIFORM law */
+        uint32_t dd = (uint32_t)d.n - 1;
+        uint32_t x = (uint32_t)(((uint64_t)xo_next(rng->xo) * ((dd + 1) * dd)) >> 32);
+        uint32_t r1 = x / dd, r2 = x % dd; /* every ordered pair of distinct cards equally likely */
+        passes++;
+        hole[p][0] = deck_pop(&d, (int)r1);
+        hole[p][1] = deck_pop(&d, (int)r2);
+    }
     for (int p = 1; p < n_players && rng->kind == 1; p++) { /* MCQ-CTR v2 */
         uint32_t dd = (uint32_t)d.n - 1;
         uint32_t x = (uint32_t)(((uint64_t)xo_next(rng->xo) * (dd * dd)) >> 32);
@@ -365,7 +375,7 @@ static uint32_t deal_iteration(rng_t *rng, const uint8_t hero[2], const uint8_t 
     } else {
         uint32_t w = 0;
         for (int k = nb; k < 5; k++) {
-            uint32_t n = (uint32_t)d.n - 1;
+            uint32_t n = (uint32_t)d.n - (rng->kind == 2 ? 0u : 1u); /* uniform law: any remaining card */
             if (((k - nb) & 1) == 0) {
                 uint32_t u = xo_next(rng->xo);
                 table[k] = deck_pop(&d, (int)(((uint64_t)u * n) >> 32));
@@ -465,7 +475,7 @@ int mcqo_run(int mode, const uint8_t *hero, const uint8_t *board, int nb, int n_
     mt.words = 0;
     if (mode == 0) mt_seed(&mt, (uint32_t)seed);
     for (uint32_t it = 0; it < runs; it++) {
-        if (mode == 1 && it % STREAM_ITERS == 0) xo_seed(&xo, seed, qid, it / STREAM_ITERS);
+        if (mode >= 1 && it % STREAM_ITERS == 0) xo_seed(&xo, seed, qid, it / STREAM_ITERS);
         uint64_t w0 = mt.words;
         out[1] += deal_iteration(&rng, hero, board, nb, n_players, hands);
         out[0]++;
@@ -522,13 +532,14 @@ int mcqo_run_batch(int mode, const uint8_t *queries, size_t n, uint64_t seed, ui
 }
 
 /* ------------------------------------------------------------------------- exact expectation (small cases)
- * Exact probabilities of {hero wins strictly, hero wins a tie} under the REFERENCE'S dealing law (the
+ * Exact probabilities of {hero wins strictly, hero wins a tie} under the REFERENCE'S dealing law (uniform = 0; the
  * accepted (r1, r2) pairs are equally likely; each table draw is uniform on [0, L-2]).  Enumerates the
- * whole tree, so only for n_players <= 3 and enough known board cards.  out[0] = P(win strictly),
+ * whole tree, so only for n_players <= 3 and enough known board cards; uniform = 1 enumerates the unbiased
+ * law instead (every ordered pair, every remaining table card).  out[0] = P(win strictly),
  * out[1] = P(tie, hero credited), out[2] = number of leaves.  Returns -1 if the tree is too large. */
 typedef struct {
     const uint8_t *hero, *board;
-    int nb, n_players;
+    int nb, n_players, uniform;
     double win, tie, leaves;
 } enum_t;
 
@@ -545,7 +556,7 @@ static void enum_table(enum_t *e, deck_t *d, uint8_t hole[][2], uint8_t *table, 
         e->leaves += 1;
         return;
     }
-    int choices = d->n - 1;
+    int choices = d->n - (e->uniform ? 0 : 1);
     for (int i = 0; i < choices; i++) {
         deck_t d2 = *d;
         table[k] = deck_pop(&d2, i);
@@ -556,10 +567,10 @@ static void enum_table(enum_t *e, deck_t *d, uint8_t hole[][2], uint8_t *table, 
 static void enum_players(enum_t *e, deck_t *d, uint8_t hole[][2], uint8_t *table, int p, double w) {
     if (p == e->n_players) { enum_table(e, d, hole, table, e->nb, w); return; }
     int L = d->n;
-    double pairs = (double)(L - 1) * (L - 1); /* accepted ordered (r1, r2): L*(L-1) - (L-1) */
+    double pairs = e->uniform ? (double)L * (L - 1) : (double)(L - 1) * (L - 1); /* accepted ordered (r1, r2) */
     for (int r1 = 0; r1 < L; r1++)
         for (int r2 = 0; r2 < L - 1; r2++) {
-            if (r1 == r2) continue;
+            if (r1 == r2 && !e->uniform) continue;
             deck_t d2 = *d;
             hole[p][0] = deck_pop(&d2, r1);
             hole[p][1] = deck_pop(&d2, r2);
@@ -567,14 +578,14 @@ static void enum_players(enum_t *e, deck_t *d, uint8_t hole[][2], uint8_t *table
         }
 }
 
-int mcqo_exact(const uint8_t *hero, const uint8_t *board, int nb, int n_players, double *out) {
+int mcqo_exact(const uint8_t *hero, const uint8_t *board, int nb, int n_players, int uniform, double *out) {
     if (!valid_query(hero, board, nb, n_players)) return -1;
     double leaves = 1;
     int L = 50 - nb;
-    for (int p = 1; p < n_players; p++) { leaves *= (double)(L - 1) * (L - 1); L -= 2; }
-    for (int k = nb; k < 5; k++) { leaves *= L - 1; L--; }
+    for (int p = 1; p < n_players; p++) { leaves *= (double)(L - 1) * (uniform ? L : L - 1); L -= 2; }
+    for (int k = nb; k < 5; k++) { leaves *= uniform ? L : L - 1; L--; }
     if (leaves > 3e8) return -1;
-    enum_t e = {hero, board, nb, n_players, 0, 0, 0};
+    enum_t e = {hero, board, nb, n_players, uniform, 0, 0, 0};
     deck_t d;
     uint8_t hole[10][2], table[5];
     deck_init(&d);

@@ -17,7 +17,7 @@ TYPES = ["HighCard", "Pair", "TwoPair", "ThreeOfAKind", "Straight", "Flush", "Fu
          "StraightFlush"]
 RANKS = "23456789TJQKA"
 SUITS = "CDHS"
-MODE_MT, MODE_CTR = 0, 1
+MODE_MT, MODE_CTR, MODE_CTR_UNIFORM = 0, 1, 2
 
 
 def card_id(s):
@@ -64,7 +64,7 @@ def lib():
         L.mcqo_run.restype = C.c_int
         L.mcqo_run_batch.argtypes = [C.c_int, u8p, C.c_size_t, C.c_uint64, C.c_uint64, u64p, C.c_int]
         L.mcqo_run_batch.restype = C.c_int
-        L.mcqo_exact.argtypes = [u8p, u8p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        L.mcqo_exact.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.mcqo_exact.restype = C.c_int
         _lib = L
     return _lib
@@ -172,13 +172,14 @@ def run_batch(mode, queries, seed, first_qid=0, threads=1):
     return out
 
 
-def exact(hero, board, n_players):
-    """Exact (P(strict win), P(tie credited to hero), leaves) under the reference's dealing law."""
+def exact(hero, board, n_players, uniform=False):
+    """Exact (P(strict win), P(tie credited to hero), leaves) under the reference's dealing law, or under the
+    uniform law (every remaining card equally likely) with uniform=True."""
     h, b = _ids(hero), _ids(board)
     bb = np.zeros(5, np.uint8)
     bb[:len(b)] = b
     out = (C.c_double * 3)()
-    rc = lib().mcqo_exact(_p(h, C.c_uint8), _p(bb, C.c_uint8), len(b), n_players, out)
+    rc = lib().mcqo_exact(_p(h, C.c_uint8), _p(bb, C.c_uint8), len(b), n_players, 1 if uniform else 0, out)
     if rc:
         raise ValueError("query invalid or tree too large for exact enumeration")
     return out[0], out[1], int(out[2])

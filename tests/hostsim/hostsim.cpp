@@ -63,7 +63,10 @@ void hs_philox(const uint32_t *ctr, const uint32_t *key, uint32_t *out) {
 }
 
 // production mode, lane/stream decomposition exactly as the kernel: lane <-> stream of 16 iterations
-int hs_run_ctr(const mcq_query *q, uint64_t seed, uint64_t qid, mcq_result *out) {
+}  // extern "C"
+
+template <class Draws>
+static int run_ctr_t(const mcq_query *q, uint64_t seed, uint64_t qid, mcq_result *out) {
     if (!mcq_query_valid(mcq_query_words(*q))) return MCQ_EINVAL;
     const McqTables &t = luts();
     McqQueryCtx qc;
@@ -74,7 +77,7 @@ int hs_run_ctr(const mcq_query *q, uint64_t seed, uint64_t qid, mcq_result *out)
     out->runs = q->runs;
     uint32_t n_streams = (q->runs + MCQ_STREAM_ITERS - 1) / MCQ_STREAM_ITERS;
     for (uint32_t s = 0; s < n_streams; s++) {
-        McqCtrDraws dr;
+        Draws dr;
         dr.w = 0;
         dr.rng.seed(seed, qid, s);
         McqLaneAcc acc = {0, 0, 0};
@@ -86,6 +89,15 @@ int hs_run_ctr(const mcq_query *q, uint64_t seed, uint64_t qid, mcq_result *out)
         fold(acc, out);
     }
     return MCQ_OK;
+}
+
+extern "C" {
+
+int hs_run_ctr(const mcq_query *q, uint64_t seed, uint64_t qid, mcq_result *out) {
+    return run_ctr_t<McqCtrDraws>(q, seed, qid, out);
+}
+int hs_run_ctr_uniform(const mcq_query *q, uint64_t seed, uint64_t qid, mcq_result *out) {
+    return run_ctr_t<McqCtrDrawsUniform>(q, seed, qid, out);
 }
 
 // parity mode: host parse of the MT19937 stream + the same lane arithmetic
@@ -149,7 +161,7 @@ void hs_mt_words(uint32_t seed, uint32_t n, uint32_t *out) {
 extern "C" int hs_check_inv(void) { /* (x * inv[d]) >> 20 == x / d for every x < d * d, d in [1, 51] */
     const McqTables &t = luts();
     for (uint32_t d = 1; d <= 51; d++)
-        for (uint32_t x = 0; x < d * d; x++)
+        for (uint32_t x = 0; x < (d + 1) * d; x++)
             if (((x * t.inv[d]) >> 20) != x / d) return (int)(d * 10000 + x);
     return 0;
 }

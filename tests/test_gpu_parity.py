@@ -281,3 +281,30 @@ def test_numpy_stream_coupling_on_gpu(eng):
             assert [int(x) for x in np.random.randint(0, 2 ** 32, size=4, dtype=np.uint32)] == s["next_words"]
     finally:
         mh.configure(mode="philox", couple_numpy=False)
+
+
+def test_uniform_dealing_law(eng):
+    """opt-in unbiased law == oracle bit for bit, converges to the exact uniform expectation, which
+    is the one the reference's C++ tests expect (Test.cpp:176-217: 40.2 / 51.8 / 67.7 % within 1 %)."""
+    eng.set_dealing_law("uniform")
+    try:
+        g = np.random.default_rng(8)
+        hole, board, npl = [], [], []
+        for i in range(64):
+            nb = [0, 3, 4, 5][i % 4]
+            cards = g.choice(52, 2 + nb, replace=False)
+            hole.append(cards[:2]); board.append(list(cards[2:]) + [255] * (5 - nb)); npl.append(1 + i % 10)
+        q = npa.pack_queries(hole, board, npl, 2500)
+        got = u64(eng.eval_batch(q, seed=4, first_query_id=9))
+        exp = O.run_batch(O.MODE_CTR_UNIFORM, q.view(np.uint8).reshape(-1, 16), 4, 9, threads=4)
+        assert np.array_equal(got, exp)
+        hero, brd = ["3H", "3S"], ["8S", "4S", "QH", "8C", "4H"]
+        w, t, _ = O.exact(hero, brd, 2, uniform=True)
+        r = u64(eng.eval_batch(np.repeat(mkq(hero, brd, 2, 4000000), 50), seed=1))
+        est = float((r[:, 2] + r[:, 3]).sum()) / float(r[:, 0].sum())
+        assert abs(est - (w + t)) < 1e-4 and abs(100 * est - 40.2) < 1.0
+        # Test.cpp montecarlo3/4: AS KS preflop, 3 and 2 players: 51.8 % and 67.7 % within 1 %
+        eq, _ = mh.get_equity_batch([[51, 47], [51, 47]], [[255] * 5] * 2, [3, 2], 4000000, seed=2, engine=eng)
+        assert abs(100 * eq[0] - 51.8) < 1.0 and abs(100 * eq[1] - 67.7) < 1.0
+    finally:
+        eng.set_dealing_law("reference")

@@ -126,3 +126,13 @@ def test_numpy_stream_coupling_matches_reference_sequence():
             assert [int(x) for x in r[4:]] == c["by_type"], c
             assert int(np.random.randint(0, 52)) == c["randint52_after"]
         assert [int(x) for x in np.random.randint(0, 2 ** 32, size=4, dtype=np.uint32)] == s["next_words"]
+
+
+@pytest.mark.parametrize("hero,board,n,runs", [(["AH", "KH"], [], 6, 3001), (["TC", "TH"], ["4D", "QD", "KC", "2S"], 3, 4097),
+                                               (["AS", "AC"], [], 10, 1500), (["7H", "2C"], ["2D", "2S", "AC", "KD", "QD"], 2, 999)])
+def test_uniform_law_equals_oracle(hero, board, n, runs):
+    """the opt-in unbiased dealing law, lane arithmetic == oracle."""
+    q = q16(hero, board, n, runs)
+    got = H.run_ctr(q, 77, 5, uniform=True)
+    exp = O.run(O.MODE_CTR_UNIFORM, hero, board, n, runs, 77, qid=5)["tallies"]
+    assert np.array_equal(got, exp)

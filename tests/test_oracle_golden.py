@@ -162,6 +162,38 @@ def test_exact_enumeration_agrees_with_both_front_ends():
         assert abs(r["tie"] / r["runs"] - t) < 4.5 * (max(t, 1e-4) / 200000) ** 0.5 + 1e-4
 
 
+def test_uniform_law_exact_and_reference_cpp_expectations():
+    """under the UNIFORM law the oracle converges to the exact uniform expectation, and that
+    expectation is what the reference's own C++ tests expect (tools/montecarlo_cpp/Test.cpp:176-217: 40.2 % for
+    3H 3S on 8S 4S QH 8C 4H heads-up, within 1 %)."""
+    hero, board = ["3H", "3S"], ["8S", "4S", "QH", "8C", "4H"]
+    w, t, leaves = O.exact(hero, board, 2, uniform=True)
+    assert leaves == 45 * 44
+    assert abs(100 * (w + t) - 40.2) < 1.0
+    r = O.run(O.MODE_CTR_UNIFORM, hero, board, 2, 300000, 3)
+    p = w + t
+    assert abs(r["equity"] - p) < 4.5 * (p * (1 - p) / 300000) ** 0.5
+    # the reference's (biased) law differs measurably on the same query
+    wb, tb, _ = O.exact(hero, board, 2)
+    assert abs((wb + tb) - p) > 1e-3
+
+
+def test_reference_cpp_agrees_with_uniform_law():
+    """oracle/_ref/ref_mc is the reference's own C++ variant compiled from /root/reference (make -C oracle ref);
+    it shuffles uniformly, so it must estimate the exact UNIFORM expectation (and not the Python law's)."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(O.__file__), "_ref", "ref_mc")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_mc not built (needs /root/reference)")
+    hero, board = ["TC", "TH"], ["4D", "QD", "KC", "2S"]
+    w, t, _ = O.exact(hero, board, 2, uniform=True)
+    out = subprocess.run([exe, "equity", hero[0], hero[1], "2", "40000"] + board, capture_output=True, text=True,
+                         check=True).stdout.split()
+    eq = float(out[0])
+    p = w + t
+    assert abs(eq - p) < 5 * (p * (1 - p) / 40000) ** 0.5, (eq, p)
+
+
 def test_single_player_and_invalid():
     r = O.run(O.MODE_MT, ["7H", "2C"], [], 1, 3000, 9)
     assert (r["wins"], r["passes"], r["win"]) == (3000, 0, 3000)
