@@ -531,6 +531,118 @@ int mcqo_run_batch(int mode, const uint8_t *queries, size_t n, uint64_t seed, ui
     return err ? -1 : 0;
 }
 
+/* ------------------------------------------------------------------------- ranges, ghost cards, known hands
+ * montecarlo_python.py:36-112 (preflop classes), :133-163 (known hands, hero given as a set of
+ * classes), :165-181 (opponents restricted to a range), :206-208 (ghost cards).
+ * A range is a 169-bit set; the bit of two cards is how get_two_short_notation (:24-34) names them:
+ * suited -> 13*min+max, off-suit -> 13*max+min, pair -> 14*rank (both spellings of a class map to one bit). */
+static int class_index(uint8_t a, uint8_t b) {
+    int ra = a >> 2, rb = b >> 2, lo = ra < rb ? ra : rb, hi = ra < rb ? rb : ra;
+    if (ra == rb) return 14 * ra;
+    return (a & 3) == (b & 3) ? 13 * lo + hi : 13 * hi + lo;
+}
+
+static int in_range(const uint32_t *bits, uint8_t a, uint8_t b) {
+    int i = class_index(a, b);
+    return !bits || ((bits[i >> 5] >> (i & 31)) & 1u);
+}
+
+/* one trial of the pair loop: indices on the CURRENT list, r1 in [0,L), r2 in [0,L-1) */
+static int draw_pair(rng_t *rng, int L, uint32_t *r1, uint32_t *r2) {
+    if (rng->kind == 0) {
+        *r1 = np_randint(rng->mt, (uint32_t)L);
+        *r2 = np_randint(rng->mt, (uint32_t)L - 1);
+        return *r1 != *r2;
+    }
+    uint32_t dd = (uint32_t)L - 1;
+    uint32_t x = (uint32_t)(((uint64_t)xo_next(rng->xo) * (dd * dd)) >> 32);
+    uint32_t a = x / dd, c = x % dd;
+    *r1 = a != c ? a : dd;
+    *r2 = c;
+    return 1;
+}
+
+/* mode 0 / 1 as mcqo_run.  hero: two cards, or NULL when hero_range (6 words) is given; known2: a second known
+ * hand or NULL; ghost: two cards taken out of the deck or NULL; opp_range: 6 words or NULL (= every class). */
+int mcqo_run_ex(int mode, const uint8_t *hero, const uint32_t *hero_range, const uint8_t *known2, const uint8_t *ghost,
+                const uint8_t *board, int nb, int n_players, uint32_t runs, uint64_t seed, uint64_t qid,
+                const uint32_t *opp_range, uint64_t *out, uint64_t *total_words) {
+    uint64_t seen = 0;
+    const uint8_t *sets[4] = {hero, known2, ghost, board};
+    int lens[4] = {hero ? 2 : 0, known2 ? 2 : 0, ghost ? 2 : 0, nb};
+    int known = 1 + (known2 ? 1 : 0);
+    if (mode < 0 || mode > 1 || nb < 0 || nb > 5 || n_players < known || n_players > 10) return -1;
+    if ((hero == 0) == (hero_range == 0)) return -1;
+    for (int s = 0; s < 4; s++)
+        for (int i = 0; i < lens[s]; i++) {
+            uint8_t c = sets[s][i];
+            if (c >= 52 || (seen >> c) & 1) return -1;
+            seen |= 1ull << c;
+        }
+    mt_t mt;
+    xo_t xo;
+    rng_t rng = {mode, &mt, &xo};
+    memset(out, 0, 13 * sizeof(uint64_t));
+    mt.words = 0;
+    if (mode == 0) mt_seed(&mt, (uint32_t)seed);
+    deck_t original;
+    deck_init(&original);
+    if (ghost) { deck_remove(&original, ghost[0]); deck_remove(&original, ghost[1]); } /* l.206-208 */
+    for (uint32_t it = 0; it < runs; it++) {
+        if (mode == 1 && it % STREAM_ITERS == 0) xo_seed(&xo, seed, qid, it / STREAM_ITERS);
+        deck_t d = original;
+        uint8_t table[5], hole[10][2], hands[70];
+        int w = 0; /* table draws of this iteration (CTR: two per word) */
+        uint32_t word = 0;
+        for (int i = 0; i < nb; i++) { deck_remove(&d, board[i]); table[i] = board[i]; } /* l.126-128 */
+        int p = 0;
+        if (hero_range) { /* l.136-148: both indices on the UNPOPPED list */
+            uint32_t r1, r2;
+            for (;;) {
+                out[1]++;
+                if (draw_pair(&rng, d.n, &r1, &r2) && in_range(hero_range, d.c[r1], d.c[r2])) break;
+            }
+            hole[0][0] = d.c[r1]; hole[0][1] = d.c[r2];
+        } else {
+            hole[0][0] = hero[0]; hole[0][1] = hero[1];
+        }
+        deck_remove(&d, hole[0][0]); /* l.154-161 */
+        deck_remove(&d, hole[0][1]);
+        p = 1;
+        if (known2) {
+            hole[1][0] = known2[0]; hole[1][1] = known2[1];
+            deck_remove(&d, known2[0]);
+            deck_remove(&d, known2[1]);
+            p = 2;
+        }
+        for (; p < n_players; p++) { /* l.165-181: the range test looks at the UNPOPPED list, the deal pops in turn */
+            uint32_t r1, r2;
+            for (;;) {
+                out[1]++;
+                if (draw_pair(&rng, d.n, &r1, &r2) && in_range(opp_range, d.c[r1], d.c[r2])) break;
+            }
+            hole[p][0] = deck_pop(&d, (int)r1);
+            hole[p][1] = deck_pop(&d, (int)r2);
+        }
+        for (int k = nb; k < 5; k++, w++) { /* l.186-188 */
+            uint32_t n = (uint32_t)d.n - 1, idx;
+            if (mode == 0) idx = np_randint(&mt, n);
+            else if ((w & 1) == 0) { uint32_t u = xo_next(&xo); idx = (uint32_t)(((uint64_t)u * n) >> 32); word = u * n; }
+            else idx = (uint32_t)(((uint64_t)word * n) >> 32);
+            table[k] = deck_pop(&d, (int)idx);
+        }
+        for (int q = 0; q < n_players; q++) {
+            hands[7 * q] = hole[q][0];
+            hands[7 * q + 1] = hole[q][1];
+            memcpy(hands + 7 * q + 2, table, 5);
+        }
+        out[0]++;
+        tally(out, hands, n_players);
+    }
+    if (total_words) *total_words = mode == 0 ? mt.words : 0;
+    return 0;
+}
+
 /* ------------------------------------------------------------------------- exact expectation (small cases)
  * Exact probabilities of {hero wins strictly, hero wins a tie} under the REFERENCE'S dealing law (uniform = 0; the
  * accepted (r1, r2) pairs are equally likely; each table draw is uniform on [0, L-2]).  Enumerates the

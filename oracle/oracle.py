@@ -64,6 +64,9 @@ def lib():
         L.mcqo_run.restype = C.c_int
         L.mcqo_run_batch.argtypes = [C.c_int, u8p, C.c_size_t, C.c_uint64, C.c_uint64, u64p, C.c_int]
         L.mcqo_run_batch.restype = C.c_int
+        L.mcqo_run_ex.argtypes = [C.c_int, u8p, u32p, u8p, u8p, u8p, C.c_int, C.c_int, C.c_uint32, C.c_uint64, C.c_uint64,
+                                  u32p, u64p, u64p]
+        L.mcqo_run_ex.restype = C.c_int
         L.mcqo_exact.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.mcqo_exact.restype = C.c_int
         _lib = L
@@ -183,3 +186,49 @@ def exact(hero, board, n_players, uniform=False):
     if rc:
         raise ValueError("query invalid or tree too large for exact enumeration")
     return out[0], out[1], int(out[2])
+
+
+def class_bit(name):
+    """Bit of a preflop class string such as 'AKS', 'KAO', 'TT' (both spellings of a class give the same bit)."""
+    r1, r2 = RANKS.index(name[0]), RANKS.index(name[1])
+    lo, hi = min(r1, r2), max(r1, r2)
+    if r1 == r2:
+        return 14 * r1 if len(name) == 2 else None  # 'AAO' never matches get_two_short_notation's output
+    if len(name) < 3 or name[2] not in "SO":
+        return None
+    return 13 * lo + hi if name[2] == "S" else 13 * hi + lo
+
+
+def range_bits(classes):
+    """169-bit set (6 uint32 words) of a collection of class strings."""
+    w = np.zeros(6, np.uint32)
+    for c in classes:
+        b = class_bit(c)
+        if b is not None:
+            w[b >> 5] |= np.uint32(1 << (b & 31))
+    return w
+
+
+def run_ex(mode, hero, board, n_players, runs, seed, qid=0, known2=None, ghost=None, opp_range=None):
+    """hero: two cards, or a set/list of class strings (hero range).  opp_range: None (all) or class strings."""
+    hero_is_range = not (len(hero) == 2 and all(isinstance(c, (int, np.integer)) or (isinstance(c, str) and len(c) == 2
+                                                                                       and c[1] in SUITS) for c in hero))
+    b = _ids(board)
+    bb = np.zeros(5, np.uint8)
+    bb[:len(b)] = b
+    out = np.zeros(13, np.uint64)
+    tw = C.c_uint64(0)
+    h = None if hero_is_range else _ids(hero)
+    hr = range_bits(hero) if hero_is_range else None
+    k2 = _ids(known2) if known2 else None
+    gh = _ids(ghost) if ghost else None
+    orr = range_bits(opp_range) if opp_range is not None else None
+    pp = lambda a, t: _p(a, t) if a is not None else None  # noqa: E731
+    rc = lib().mcqo_run_ex(mode, pp(h, C.c_uint8), pp(hr, C.c_uint32), pp(k2, C.c_uint8), pp(gh, C.c_uint8),
+                           _p(bb, C.c_uint8), len(b), n_players, runs, seed, qid, pp(orr, C.c_uint32),
+                           _p(out, C.c_uint64), C.byref(tw))
+    if rc:
+        raise ValueError("invalid extended query")
+    return {"runs": int(out[0]), "passes": int(out[1]), "win": int(out[2]), "tie": int(out[3]),
+            "by_type": [int(x) for x in out[4:]], "wins": int(out[2] + out[3]), "mt_words": int(tw.value),
+            "tallies": out}

@@ -14,6 +14,8 @@ What is captured (ids follow SURVEY.md section 8c):
   F2  deal_traces.npz       per (seed, hero, board, N): first K iterations' dealt cards, MT words/iteration
   F3  tallies.json          seeded run_montecarlo tallies (wins, passes, per-type wins, MT words)
   F4  stat_expectations.json the (hero, board, N, expected %) rows of tests/test_montecarlo_python.py
+  F7  ext_tallies.json      seeded runs with opponent ranges, hero ranges, ghost cards, two known hands (8f-2);
+      ../../neuron_poker_amd/preflop_classes.json  the 169 classes in the reference's sort order
   F6  sequence.json         consecutive calls on ONE seeded numpy stream, with a randint in between (8f-4)
 """
 import json
@@ -343,7 +345,63 @@ def gen_sequence():
     print("sequence:", len(out))
 
 
+# ----------------------------------------------------------------------------- F7
+EXT_GRID = [  # (player_card_list, board, n_players, runs, seed, ghost_cards, opponent_range)
+    ([['KS', 'KC']], ['3D', '9H', 'AS', '7S', 'QH'], 3, 8000, 0, '', 0.25),           # tests/test_montecarlo_python.py:215-222
+    ([{'AKO', 'AA'}], ['3D', '9H', 'AS', '7S', 'QH'], 3, 8000, 1, '', 0.25),          # :225-232 hero given as a range
+    ([['AH', 'KH']], [], 2, 6000, 2, '', 0.1), ([['AH', 'KH']], [], 4, 4000, 3, '', 0.5),
+    ([['AH', 'KH']], [], 3, 4000, 4, ['AS', 'AD'], 1), ([['7C', '2D']], ['AS', 'KS', 'QS'], 6, 3000, 5, ['AH', 'KH'], 0.3),
+    ([['AH', 'KH'], ['QS', 'QD']], [], 4, 4000, 6, '', 1), ([['AH', 'KH'], ['QS', 'QD']], ['2C', '3C', '4C'], 5, 3000, 7, '', 0.4),
+    ([{'22', '33', '44', 'TJS', '9TS'}], [], 2, 4000, 8, '', 1), ([{'AA', 'KK', 'QQ', 'AKS'}], ['2H', '7D', 'JC', 'JD'], 6, 3000, 9, ['2C', '2D'], 0.6),
+    ([['9S', '9H']], [], 3, 4000, 10, '', {'AA', 'KK', 'AKS', 'AKO', 'QQ', 'JJ', 'TT'}),
+    ([{'AKS', 'KQS', '67S', '78S'}, ['QS', 'QD']], ['2C', '3C', '4C'], 4, 3000, 11, '', 0.8),
+    ([['AH', 'KH']], [], 10, 1500, 12, '', 0.9), ([{'AA', 'KK', '72O', '27O', 'AKO'}], [], 10, 1500, 13, '', 0.35),
+    ([['AH', 'KH']], [], 2, 3000, 14, '', 0.001),                                      # int(169 * r) == 0 -> every class
+]
+
+
+def gen_ext():
+    out = []
+    for pcl, board, n, runs, seed, ghost, rng in EXT_GRID:
+        np.random.seed(seed)
+        rec = Recorder(0)
+        mp.eval_best_hand = rec
+        try:
+            rec.start()
+            sim = mp.MonteCarlo()
+            pl = [set(x) if isinstance(x, set) else list(x) for x in pcl]
+            sim.run_montecarlo(pl, list(board), n, 1, maxRuns=runs, timeout=FAR, ghost_cards=ghost, opponent_range=rng)
+        finally:
+            mp.eval_best_hand = rec.orig
+        by_type = {t: 0 for t in TYPES}
+        for k, v in sim.winnerCardTypeList.items():
+            by_type[k] = int(round(v * sim.runs))
+        out.append({"players": [sorted(x) if isinstance(x, set) else x for x in pcl],
+                    "hero_is_range": isinstance(pcl[0], set), "board": board, "n_players": n, "runs": runs,
+                    "seed": seed, "ghost": list(ghost) if ghost else [], "opponent_range": sorted(rng) if isinstance(rng, set) else rng,
+                    "wins": int(round(sim.equity * sim.runs)), "passes": int(sim.passes),
+                    "by_type": [by_type[t] for t in TYPES], "mt_words": int(rec.total_words)})
+        print("ext", out[-1]["players"], board, n, rng, "->", out[-1]["wins"], out[-1]["passes"])
+    with open(os.path.join(HERE, "ext_tallies.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    # the 169 preflop classes in the order the reference sorts them (ascending equity; ties keep dict order):
+    # run_montecarlo(opponent_range=r) keeps the LAST int(169 * r) of them (montecarlo_python.py:105-112)
+    sim = mp.MonteCarlo()
+    sim.get_opponent_allowed_cards_list(1)
+    import operator
+    order = [k for k, _ in sorted(sim.preflop_equities.items(), key=operator.itemgetter(1))]
+    assert len(order) == 169 and len(set(order)) == 169
+    for r in (0.25, 0.5, 0.9, 1):
+        assert set(order[-int(169 * r):]) == sim.get_opponent_allowed_cards_list(r)
+    with open(os.path.join(HERE, "..", "..", "neuron_poker_amd", "preflop_classes.json"), "w") as f:
+        json.dump(order, f)
+    print("ext_tallies:", len(out), "preflop classes:", len(order))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "ext":
+        gen_ext()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "sequence":
         gen_sequence()
         sys.exit(0)
@@ -355,3 +413,4 @@ if __name__ == "__main__":
     gen_traces()
     gen_tallies()
     gen_sequence()
+    gen_ext()

@@ -194,6 +194,43 @@ def test_reference_cpp_agrees_with_uniform_law():
     assert abs(eq - p) < 5 * (p * (1 - p) / 40000) ** 0.5, (eq, p)
 
 
+def _ext_range(row):
+    """opponent_range of a fixture row -> class strings (None = every class), as run_montecarlo derives it
+    (montecarlo_python.py:105-112: the LAST int(169 * r) classes of the equity-sorted list; 0 -> all)."""
+    r = row["opponent_range"]
+    if isinstance(r, list):
+        return r
+    with open(os.path.join(os.path.dirname(G), "..", "neuron_poker_amd", "preflop_classes.json")) as f:
+        order = json.load(f)
+    take = int(169 * r)
+    return None if take == 0 or take >= 169 else order[-take:]
+
+
+def test_ranges_ghost_cards_known_hands_fixture():
+    """tests/golden/ext_tallies.json was recorded from seeded reference runs (incl. the inputs of
+    tests/test_montecarlo_python.py:215-232)."""
+    rows = jload("ext_tallies.json")
+    assert len(rows) >= 15
+    for t in rows:
+        pl = t["players"]
+        r = O.run_ex(O.MODE_MT, pl[0], t["board"], t["n_players"], t["runs"], t["seed"],
+                     known2=pl[1] if len(pl) > 1 else None, ghost=t["ghost"] or None, opp_range=_ext_range(t))
+        assert (r["wins"], r["passes"], r["by_type"]) == (t["wins"], t["passes"], t["by_type"]), t
+        if t["passes"] < 20 * t["runs"]:  # the recorder counts MT words modulo 624 per iteration: only valid
+            assert r["mt_words"] == t["mt_words"], t  # while an iteration consumes fewer than 624 words
+
+
+def test_reference_range_tests_statistically():
+    # tests/test_montecarlo_python.py:215-232: 12.8 % and 77.8 % within 3 points
+    board = ["3D", "9H", "AS", "7S", "QH"]
+    rows = jload("ext_tallies.json")
+    rng = _ext_range(rows[0])
+    for mode in (O.MODE_MT, O.MODE_CTR):
+        a = O.run_ex(mode, ["KS", "KC"], board, 3, 30000, 5, opp_range=rng)
+        b = O.run_ex(mode, ["AKO", "AA"], board, 3, 30000, 6, opp_range=rng)
+        assert abs(100 * a["wins"] / a["runs"] - 12.8) < 3 and abs(100 * b["wins"] / b["runs"] - 77.8) < 3
+
+
 def test_single_player_and_invalid():
     r = O.run(O.MODE_MT, ["7H", "2C"], [], 1, 3000, 9)
     assert (r["wins"], r["passes"], r["win"]) == (3000, 0, 3000)
