@@ -75,6 +75,22 @@ typedef struct mcq_result {
     uint64_t by_type[9];
 } mcq_result;
 
+/* Optional extension of a query (64 bytes) for the rest of run_montecarlo's arguments:
+ * ghost_cards (tools/montecarlo_python.py:206-208), a second known hand (collusion player, :133-163), the hero
+ * given as a SET of preflop classes instead of two cards (:136-148) and opponents restricted to a range
+ * (:165-181 with :36-112).  A range is a 169-bit set of classes; the bit of a class is how
+ * get_two_short_notation (:24-34) names two cards: suited -> 13*min+max, off-suit -> 13*max+min, pair -> 14*rank
+ * (rank = index in "23456789TJQKA").  "Every class" = all 169 bits set. */
+typedef struct mcq_query_ext {
+    uint8_t ghost[2];      /* two cards taken out of the deck, 0xFF 0xFF = none */
+    uint8_t known2[2];     /* a second known hand, 0xFF 0xFF = none; it counts in n_players */
+    uint8_t hero_is_range; /* 1: mcq_query.hole is ignored, hero's hand is drawn from hero_range every iteration */
+    uint8_t reserved[3];   /* must be 0 */
+    uint32_t opp_range[6];
+    uint32_t hero_range[6];
+    uint32_t pad[2];
+} mcq_query_ext;
+
 typedef struct mcq_ctx mcq_ctx;
 
 /* Number of HIP devices visible, or a negative MCQ_E* code. */
@@ -95,6 +111,11 @@ MCQ_API int mcq_eval_batch(mcq_ctx *ctx, const mcq_query *q, size_t n, uint64_t 
 
 /* n == 1 convenience: exactly get_equity's arguments after card-string conversion. */
 MCQ_API int mcq_eval_one(mcq_ctx *ctx, const mcq_query *q, uint64_t seed, int mode, mcq_result *out);
+
+/* mcq_eval_batch with one mcq_query_ext per query (host buffers).  A range that cannot be dealt from the cards
+ * left (the reference would loop forever) gives MCQ_EINVAL after a bounded number of attempts. */
+MCQ_API int mcq_eval_batch_ext(mcq_ctx *ctx, const mcq_query *q, const mcq_query_ext *ext, size_t n, uint64_t seed,
+                       uint64_t first_query_id, int mode, mcq_result *out);
 
 /* Parity mode coupled to numpy's GLOBAL random state, as consecutive reference calls are: the n
  * queries consume ONE MT19937 stream in order.  mt_key[624] / *mt_pos are numpy's state words and position

@@ -19,7 +19,10 @@ QUERY_DTYPE = np.dtype([("hole", "u1", (2,)), ("board", "u1", (5,)), ("n_board",
                         ("reserved", "u1", (3,)), ("runs", "<u4")])
 RESULT_DTYPE = np.dtype([("runs", "<u8"), ("passes", "<u8"), ("win", "<u8"), ("tie", "<u8"),
                          ("by_type", "<u8", (9,))])
-assert QUERY_DTYPE.itemsize == 16 and RESULT_DTYPE.itemsize == 104
+QUERY_EXT_DTYPE = np.dtype([("ghost", "u1", (2,)), ("known2", "u1", (2,)), ("hero_is_range", "u1"), ("reserved", "u1", (3,)),
+                            ("opp_range", "<u4", (6,)), ("hero_range", "<u4", (6,)), ("pad", "<u4", (2,))])
+assert QUERY_DTYPE.itemsize == 16 and RESULT_DTYPE.itemsize == 104 and QUERY_EXT_DTYPE.itemsize == 64
+ALL_CLASSES = np.array([0xFFFFFFFF] * 5 + [0x1FF], np.uint32)  # 169 bits
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _lib = None
@@ -76,6 +79,8 @@ def load_library():
         L.mcq_eval_batch.restype = C.c_int
         L.mcq_eval_one.argtypes = [vp, vp, u64, C.c_int, vp]
         L.mcq_eval_one.restype = C.c_int
+        L.mcq_eval_batch_ext.argtypes = [vp, vp, vp, sz, u64, u64, C.c_int, vp]
+        L.mcq_eval_batch_ext.restype = C.c_int
         L.mcq_eval_batch_numpy_stream.argtypes = [vp, vp, sz, vp, vp, vp]
         L.mcq_eval_batch_numpy_stream.restype = C.c_int
         L.mcq_eval_batch_device.argtypes = [vp, vp, sz, u64, u64, vp, vp]
@@ -129,6 +134,45 @@ def pack_queries(hole, board, n_players, runs):
     return q
 
 
+def class_bit(name):
+    """Bit of a preflop class string ('AKS', 'KAO', 'TT', ...) in a 169-bit range set; None if the string can never
+    equal what get_two_short_notation produces (tools/montecarlo_python.py:24-34)."""
+    from .cards import RANKS
+    if not isinstance(name, str) or len(name) < 2:
+        return None
+    r1, r2 = RANKS.find(name[0]), RANKS.find(name[1])
+    if r1 < 0 or r2 < 0:
+        return None
+    if r1 == r2:
+        return 14 * r1 if len(name) == 2 else None
+    if len(name) != 3 or name[2] not in "SO":
+        return None
+    lo, hi = min(r1, r2), max(r1, r2)
+    return 13 * lo + hi if name[2] == "S" else 13 * hi + lo
+
+
+def range_bits(classes):
+    """169-bit set (6 little-endian uint32 words) of a collection of preflop class strings."""
+    w = np.zeros(6, np.uint32)
+    for c in classes:
+        b = class_bit(c)
+        if b is not None:
+            w[b >> 5] |= np.uint32(1 << (b & 31))
+    return w
+
+
+def pack_query_ext(n, ghost=None, known2=None, hero_range=None, opp_range=None):
+    """n mcq_query_ext records with the same settings: ghost / known2 = two card ids or None, hero_range /
+    opp_range = 6-word sets (range_bits) or None (hero given as cards / every class)."""
+    e = np.zeros(n, QUERY_EXT_DTYPE)
+    e["ghost"] = 255 if ghost is None else np.asarray(ghost, np.uint8)
+    e["known2"] = 255 if known2 is None else np.asarray(known2, np.uint8)
+    e["hero_is_range"] = 0 if hero_range is None else 1
+    e["hero_range"] = 0 if hero_range is None else np.asarray(hero_range, np.uint32)
+    e["opp_range"] = ALL_CLASSES if opp_range is None else np.asarray(opp_range, np.uint32)
+    return e
+
+
 class Engine:
     """One mcq_ctx: an equity engine bound to one GPU.  Not re-entrant (one call in flight per engine)."""
 
@@ -166,6 +210,19 @@ class Engine:
         out = np.zeros(len(q), RESULT_DTYPE)
         rc = self._lib.mcq_eval_batch(self._ctx, q.ctypes.data, len(q), int(seed) & (2 ** 64 - 1),
                                       int(first_query_id) & (2 ** 64 - 1), int(mode), out.ctypes.data)
+        if rc:
+            _raise(rc)
+        return out
+
+    def eval_batch_ext(self, queries, ext, seed, first_query_id=0, mode=MODE_PHILOX):
+        """queries with one QUERY_EXT_DTYPE record each (ranges, hero range, ghost cards, second known hand)."""
+        q = np.ascontiguousarray(queries, dtype=QUERY_DTYPE).reshape(-1)
+        e = np.ascontiguousarray(ext, dtype=QUERY_EXT_DTYPE).reshape(-1)
+        if len(e) != len(q):
+            raise ValueError("one mcq_query_ext per query")
+        out = np.zeros(len(q), RESULT_DTYPE)
+        rc = self._lib.mcq_eval_batch_ext(self._ctx, q.ctypes.data, e.ctypes.data, len(q), int(seed) & (2 ** 64 - 1),
+                                          int(first_query_id) & (2 ** 64 - 1), int(mode), out.ctypes.data)
         if rc:
             _raise(rc)
         return out

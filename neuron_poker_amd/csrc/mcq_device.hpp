@@ -594,3 +594,228 @@ MCQ_HD void mcq_iteration(const McqQueryCtx &qc, Draws &dr, const McqCard *base,
     acc.types += won << (6u * (hk >> MCQ_KEY_SHIFT));
     acc.tie += hk == best ? 1u : 0u;
 }
+
+// ================================================================================================ extended queries
+// opponent ranges (montecarlo_python.py:165-181 with :36-112), hero given as a set of preflop
+// classes (:136-148), ghost cards (:206-208) and a second known hand (:133-163).  This path favours
+// simplicity over speed: the deck is the 52-bit mask with the popcount search (mcq_select_pop), cards come
+// from a 52-entry table, the dealt hands' card ids wait in LDS.
+//
+// A range is a 169-bit set; the bit of two cards is how get_two_short_notation (:24-34) names them:
+// suited -> 13*min+max, off-suit -> 13*max+min, pair -> 14*rank.
+struct McqExtWords { /* the 64-byte mcq_query_ext record as words */
+    uint32_t w[16];
+    MCQ_HDM uint32_t ghost(uint32_t i) const { return (w[0] >> (8u * i)) & 0xFFu; }        /* 0xFF = none */
+    MCQ_HDM uint32_t known2(uint32_t i) const { return (w[0] >> (16u + 8u * i)) & 0xFFu; } /* 0xFF = none */
+    MCQ_HDM uint32_t hero_is_range() const { return w[1] & 0xFFu; }
+    MCQ_HDM uint32_t reserved() const { return w[1] >> 8; }
+    MCQ_HDM uint32_t opp_range(uint32_t i) const { return w[2 + i]; }
+    MCQ_HDM uint32_t hero_range(uint32_t i) const { return w[8 + i]; }
+};
+
+MCQ_HD uint32_t mcq_class_index(uint32_t a, uint32_t b) {
+    const uint32_t ra = a >> 2, rb = b >> 2, lo = ra < rb ? ra : rb, hi = ra < rb ? rb : ra;
+    if (ra == rb) return 14u * ra;
+    return (a & 3u) == (b & 3u) ? 13u * lo + hi : 13u * hi + lo;
+}
+MCQ_HD bool mcq_in_range(const uint32_t *bits, uint32_t a, uint32_t b) {
+    const uint32_t i = mcq_class_index(a, b);
+    return (bits[i >> 5] >> (i & 31u)) & 1u;
+}
+
+struct McqExtCtx { /* wave-uniform */
+    uint32_t deck_lo, deck_hi;
+    uint32_t k2_lo, k2_hi; /* a second known hand is taken out AFTER a hero range was dealt (loop order of l.133-163:
+                              the hero may even be dealt one of its cards, the reference's try/except swallows it) */
+    uint32_t n_players, n_random, n_deal, runs;
+    bool hero_is_range, has_known2;
+    McqHole hero, known2;
+    McqBoard board;
+};
+
+// hole/board/ghost/known2 must be distinct valid cards; a range that is used must not be empty
+MCQ_HD bool mcq_query_ext_valid(const McqQueryWords &q, const McqExtWords &e) {
+    if (q.n_board() > 5 || q.n_players() < 1 || q.n_players() > 10 || q.reserved() != 0 || e.reserved() != 0) return false;
+    if (e.hero_is_range() > 1) return false;
+    uint64_t seen = 0;
+    bool ok = true;
+    const bool g = e.ghost(0) != 0xFFu || e.ghost(1) != 0xFFu, k2 = e.known2(0) != 0xFFu || e.known2(1) != 0xFFu;
+    for (uint32_t i = 0; i < 11; i++) {
+        uint32_t c;
+        bool used;
+        if (i < 2) { c = q.card(i); used = !e.hero_is_range(); }
+        else if (i < 7) { c = q.card(i); used = i - 2 < q.n_board(); }
+        else if (i < 9) { c = e.ghost(i - 7); used = g; }
+        else { c = e.known2(i - 9); used = k2; }
+        if (!used) continue;
+        ok = ok && c < 52 && !((seen >> (c & 63u)) & 1);
+        seen |= 1ull << (c & 63u);
+    }
+    const uint32_t known = 1u + (k2 ? 1u : 0u);
+    if (q.n_players() < known) return false;
+    uint32_t any_opp = 0, any_hero = 0;
+    for (uint32_t i = 0; i < 6; i++) { any_opp |= e.opp_range(i); any_hero |= e.hero_range(i); }
+    if (q.n_players() > known && any_opp == 0) return false;
+    if (e.hero_is_range() && any_hero == 0) return false;
+    return ok;
+}
+
+MCQ_HD void mcq_ext_ctx(const McqQueryWords &q, const McqExtWords &e, McqExtCtx &c) {
+    uint64_t deck = (1ull << 52) - 1;
+    c.board.clear();
+    for (uint32_t i = 0; i < q.n_board(); i++) {
+        const uint32_t cd = q.card(2u + i);
+        deck &= ~(1ull << cd);
+        c.board.add(mcq_card(cd));
+    }
+    c.hero_is_range = e.hero_is_range() != 0;
+    c.has_known2 = e.known2(0) != 0xFFu;
+    if (!c.hero_is_range) {
+        deck &= ~(1ull << q.card(0));
+        deck &= ~(1ull << q.card(1));
+        c.hero.set(mcq_card(q.card(0)), mcq_card(q.card(1)));
+    }
+    c.k2_lo = c.k2_hi = 0;
+    if (c.has_known2) {
+        const uint64_t k2 = (1ull << e.known2(0)) | (1ull << e.known2(1));
+        if (c.hero_is_range) {
+            c.k2_lo = (uint32_t)k2;
+            c.k2_hi = (uint32_t)(k2 >> 32);
+        } else {
+            deck &= ~k2;
+        }
+        c.known2.set(mcq_card(e.known2(0)), mcq_card(e.known2(1)));
+    }
+    if (e.ghost(0) != 0xFFu) {
+        deck &= ~(1ull << e.ghost(0));
+        deck &= ~(1ull << e.ghost(1));
+    }
+    c.deck_lo = (uint32_t)deck;
+    c.deck_hi = (uint32_t)(deck >> 32);
+    c.n_players = q.n_players();
+    c.n_random = q.n_players() - (c.hero_is_range ? 0u : 1u) - (c.has_known2 ? 1u : 0u);
+    c.n_deal = 5u - q.n_board();
+    c.runs = q.runs();
+}
+
+#define MCQ_EXT_MAX_TRIALS 65536u /* bound of the range re-draw loop: a range that cannot be dealt must not hang */
+
+// Draw policies with run-time draw numbers (the extended path is not unrolled).
+struct McqExtCtrDraws {
+    static constexpr bool kReplay = false;
+    McqXoshiro rng;
+    uint32_t w;
+    MCQ_HDM void pair(uint32_t L, const uint32_t *inv, uint32_t &r1, uint32_t &r2) {
+        const uint32_t dd = L - 1u;
+        const uint32_t x = mcq_mulhi(rng.next(), dd * dd);
+        const uint32_t a = (x * inv[dd]) >> 20;
+        const uint32_t c = x - a * dd;
+        r1 = a == c ? dd : a;
+        r2 = c;
+    }
+    MCQ_HDM uint32_t table(uint32_t k, uint32_t n) {
+        if ((k & 1u) == 0) {
+            const uint32_t u = rng.next();
+            w = u * n;
+            return mcq_mulhi(u, n);
+        }
+        return mcq_mulhi(w, n);
+    }
+};
+struct McqExtReplayDraws { /* accepted draws from the host, all in list.pop order */
+    static constexpr bool kReplay = true;
+    const uint8_t *p;
+    uint64_t stride;
+    MCQ_HDM void pair(uint32_t, const uint32_t *, uint32_t &r1, uint32_t &r2) {
+        r1 = p[0];
+        r2 = p[stride];
+        p += 2 * stride;
+    }
+    MCQ_HDM uint32_t table(uint32_t, uint32_t) {
+        uint32_t v = p[0];
+        p += stride;
+        return v;
+    }
+};
+
+// One iteration of an extended query.  ids: this lane's slot array (stride `ids_stride` words) for the dealt
+// hands; cards: the 52-entry card table; hero_set / opp_set: 6-word range sets.  Returns false when a range could
+// not be dealt within MCQ_EXT_MAX_TRIALS attempts.
+template <class Draws>
+MCQ_HD bool mcq_iteration_ext(const McqExtCtx &qc, Draws &dr, const McqCard *cards, const uint32_t *sel8,
+                              const uint32_t *hero_set, const uint32_t *opp_set, uint32_t *ids, uint32_t ids_stride,
+                              const uint32_t *tf, const uint32_t *tops, const uint32_t *sd, const uint32_t *inv,
+                              McqLaneAcc &acc) {
+    uint32_t dlo = qc.deck_lo, dhi = qc.deck_hi;
+    bool dealt = true;
+    for (uint32_t h = 0; h < qc.n_random; h++) {
+        const bool is_hero = qc.hero_is_range && h == 0;
+        const uint32_t L = mcq_popc(dlo) + mcq_popc(dhi);
+        uint32_t r1 = 0, r2 = 0, c1, c2;
+        if (Draws::kReplay) {
+            dr.pair(L, inv, r1, r2);
+            c1 = mcq_select_pop(dlo, dhi, r1, sel8);
+            c2 = mcq_select_pop(dlo, dhi, r2, sel8);
+        } else {
+            const uint32_t *set = is_hero ? hero_set : opp_set;
+            bool ok = false;
+            c1 = c2 = 0;
+            for (uint32_t trial = 0; trial < MCQ_EXT_MAX_TRIALS && !ok; trial++) {
+                acc.passes++;
+                dr.pair(L, inv, r1, r2);
+                uint32_t tl = dlo, th = dhi;
+                c1 = mcq_select_pop(tl, th, r1, sel8); /* deck[r1] */
+                tl = dlo; th = dhi;
+                c2 = mcq_select_pop(tl, th, r2, sel8); /* deck[r2] on the UNPOPPED list (l.142, l.173) */
+                ok = mcq_in_range(set, c1, c2);
+            }
+            dealt = dealt && ok;
+            if (is_hero) { /* the two cards looked at are the hand; they leave the deck by value (l.146-161) */
+                const uint64_t m = ~((1ull << c1) | (1ull << c2));
+                dlo &= (uint32_t)m;
+                dhi &= (uint32_t)(m >> 32);
+            } else { /* deck.pop(r1); deck.pop(r2) on the shrunk list (l.178-179) */
+                c1 = mcq_select_pop(dlo, dhi, r1, sel8);
+                c2 = mcq_select_pop(dlo, dhi, r2, sel8);
+            }
+        }
+        ids[h * ids_stride] = c1 | (c2 << 8);
+        if (is_hero) {
+            dlo &= ~qc.k2_lo;
+            dhi &= ~qc.k2_hi;
+        }
+    }
+    McqBoard b = qc.board;
+    for (uint32_t k = 0; k < qc.n_deal; k++) {
+        const uint32_t L = mcq_popc(dlo) + mcq_popc(dhi);
+        const uint32_t c = mcq_select_pop(dlo, dhi, dr.table(k, L - 1u), sel8);
+        b.add(cards[c < 52u ? c : 0u]);
+    }
+    McqFlushSel fs;
+    fs.from_board(b);
+    uint32_t hk, best = 0, h0 = 0;
+    if (qc.hero_is_range) {
+        const uint32_t v = ids[0];
+        McqHole hh;
+        hh.set(cards[v & 0xFFu], cards[(v >> 8) & 0xFFu]);
+        hk = mcq_eval_key(b, fs, hh, tf, tops, sd);
+        h0 = 1;
+    } else {
+        hk = mcq_eval_key(b, fs, qc.hero, tf, tops, sd);
+    }
+    if (qc.has_known2) {
+        const uint32_t k = mcq_eval_key(b, fs, qc.known2, tf, tops, sd);
+        best = k > best ? k : best;
+    }
+    for (uint32_t h = h0; h < qc.n_random; h++) {
+        const uint32_t v = ids[h * ids_stride];
+        McqHole hh;
+        hh.set(cards[v & 0xFFu], cards[(v >> 8) & 0xFFu]);
+        const uint32_t k = mcq_eval_key(b, fs, hh, tf, tops, sd);
+        best = k > best ? k : best;
+    }
+    uint64_t won = hk >= best ? 1u : 0u;
+    acc.types += won << (6u * (hk >> MCQ_KEY_SHIFT));
+    acc.tie += hk == best ? 1u : 0u;
+    return dealt;
+}

@@ -93,7 +93,7 @@ struct mcq_ctx {
     uint64_t n_timed = 0;
     float last_ms = 0.f;
     McqTables *d_luts = nullptr;
-    DevBuf d_q, d_res, d_prefix, d_draws, d_off, d_hands, d_win, d_wt, d_keys;
+    DevBuf d_q, d_res, d_prefix, d_draws, d_off, d_hands, d_win, d_wt, d_keys, d_ext;
     PinBuf h_q, h_res, h_draws, h_off, h_misc;
 };
 
@@ -267,7 +267,7 @@ void mcq_destroy(mcq_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *db[] = {&c->d_q, &c->d_res, &c->d_prefix, &c->d_draws, &c->d_off, &c->d_hands, &c->d_win, &c->d_wt,
-                    &c->d_keys};
+                    &c->d_keys, &c->d_ext};
     for (DevBuf *b : db) b->release();
     PinBuf *pb[] = {&c->h_q, &c->h_res, &c->h_draws, &c->h_off, &c->h_misc};
     for (PinBuf *b : pb) b->release();
@@ -391,6 +391,98 @@ int mcq_eval_batch(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed, uint
 
 int mcq_eval_one(mcq_ctx *c, const mcq_query *q, uint64_t seed, int mode, mcq_result *out) {
     return mcq_eval_batch(c, q, 1, seed, 0, mode, out);
+}
+
+int mcq_eval_batch_ext(mcq_ctx *c, const mcq_query *q, const mcq_query_ext *ext, size_t n, uint64_t seed,
+                       uint64_t first_query_id, int mode, mcq_result *out) {
+    if (mode != MCQ_MODE_PHILOX && mode != MCQ_MODE_REPLAY_MT19937) return fail(MCQ_EINVAL, "mcq_eval_batch_ext: bad mode");
+    if (n == 0) return MCQ_OK;
+    if (!c) return fail(MCQ_EINVAL, "mcq_eval_batch_ext: null context");
+    if (!q || !ext || !out) return fail(MCQ_EINVAL, "mcq_eval_batch_ext: null buffer");
+    if (n > 0x7fffffffu) return fail(MCQ_EINVAL, "mcq_eval_batch_ext: n too large");
+    uint64_t total_tasks = 0;
+    for (size_t i = 0; i < n; i++) {
+        McqExtWords ew;
+        memcpy(ew.w, &ext[i], 64);
+        if (!mcq_query_ext_valid(mcq_query_words(q[i]), ew)) {
+            char buf[200];
+            snprintf(buf, sizeof buf, "extended query %zu invalid (distinct card ids < 52 among hole/table/ghost/known2, "
+                     "n_players >= known hands, used ranges not empty)", i);
+            return fail(MCQ_EINVAL, buf);
+        }
+        total_tasks += tasks_of(q[i]);
+    }
+    if (total_tasks > 0xfffffff0ull) return fail(MCQ_EINVAL, "mcq_eval_batch_ext: too many iterations in one call");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(c->h_q.reserve(n * (sizeof(mcq_query) + sizeof(mcq_query_ext))));
+    HIP_TRY(c->h_res.reserve(n * sizeof(mcq_result)));
+    HIP_TRY(c->d_q.reserve(n * sizeof(mcq_query)));
+    HIP_TRY(c->d_ext.reserve(n * sizeof(mcq_query_ext)));
+    HIP_TRY(c->d_res.reserve(n * sizeof(mcq_result)));
+    HIP_TRY(c->d_prefix.reserve((n + 1) * sizeof(uint64_t)));
+    uint8_t *hq = (uint8_t *)c->h_q.p;
+    memcpy(hq, q, n * sizeof(mcq_query));
+    memcpy(hq + n * sizeof(mcq_query), ext, n * sizeof(mcq_query_ext));
+    HIP_TRY(hipMemcpyAsync(c->d_q.p, hq, n * sizeof(mcq_query), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_ext.p, hq + n * sizeof(mcq_query), n * sizeof(mcq_query_ext), hipMemcpyHostToDevice,
+                           c->stream));
+    c->last_ms = 0.f;
+    std::vector<uint64_t> passes;
+    uint32_t grid, block;
+    pick_geometry(c, mode, total_tasks, &grid, &block);
+    if (mode == MCQ_MODE_REPLAY_MT19937) { /* one chunk: the extended path is a feature path, not a bulk path */
+        passes.assign(n, 0);
+        std::vector<uint64_t> off(n);
+        uint64_t bytes = 0;
+        for (size_t i = 0; i < n; i++) {
+            off[i] = bytes;
+            bytes += (((uint64_t)q[i].runs + 63u) & ~63ull) * mcq_ext_draws_per_iteration(q[i], ext[i]);
+        }
+        if (bytes > (1ull << 31)) return fail(MCQ_EINVAL, "mcq_eval_batch_ext: replay batch too large (split it)");
+        HIP_TRY(c->h_draws.reserve(bytes + 64));
+        HIP_TRY(c->d_draws.reserve(bytes + 64));
+        HIP_TRY(c->d_off.reserve(n * sizeof(uint64_t)));
+        HIP_TRY(c->h_off.reserve(n * sizeof(uint64_t)));
+        memcpy(c->h_off.p, off.data(), n * sizeof(uint64_t));
+        uint8_t *hd = (uint8_t *)c->h_draws.p;
+        std::atomic<size_t> next(0);
+        std::atomic<int> bad(0);
+        unsigned hw = std::thread::hardware_concurrency();
+        size_t nt = hw ? hw : 4;
+        if (nt > 32) nt = 32;
+        if (nt > n) nt = n;
+        auto work = [&]() {
+            for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+                McqMt19937 g;
+                g.seed((uint32_t)(seed + first_query_id + i));
+                uint64_t stride = ((uint64_t)q[i].runs + 63u) & ~63ull;
+                passes[i] = mcq_replay_parse_ext(q[i], ext[i], g, hd + off[i], stride, 1000000u);
+                if (passes[i] == ~0ull) bad.store(1);
+            }
+        };
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < nt; t++) th.emplace_back(work);
+        work();
+        for (auto &t : th) t.join();
+        if (bad.load()) return fail(MCQ_EINVAL, "mcq_eval_batch_ext: a range cannot be dealt from the remaining cards");
+        HIP_TRY(hipMemcpyAsync(c->d_draws.p, hd, bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_off.p, c->h_off.p, n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_TRY(mcq_launch_prep_ext((const mcq_query *)c->d_q.p, (const mcq_query_ext *)c->d_ext.p, (uint32_t)n,
+                                (mcq_result *)c->d_res.p, (uint64_t *)c->d_prefix.p, c->stream));
+    HIP_TRY(mcq_launch_eval_ext(mode, (const mcq_query *)c->d_q.p, (const mcq_query_ext *)c->d_ext.p, (uint32_t)n,
+                                (const uint64_t *)c->d_prefix.p, (mcq_result *)c->d_res.p, seed, first_query_id, c->d_luts,
+                                (const uint8_t *)c->d_draws.p, (const uint64_t *)c->d_off.p, grid, block, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_res.p, c->d_res.p, n * sizeof(mcq_result), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const mcq_result *hr = (const mcq_result *)c->h_res.p;
+    for (size_t i = 0; i < n; i++)
+        if (hr[i].runs != q[i].runs)
+            return fail(MCQ_EINVAL, "mcq_eval_batch_ext: a range cannot be dealt from the remaining cards");
+    memcpy(out, hr, n * sizeof(mcq_result));
+    if (mode == MCQ_MODE_REPLAY_MT19937)
+        for (size_t i = 0; i < n; i++) out[i].passes = passes[i];
+    return MCQ_OK;
 }
 
 int mcq_eval_batch_numpy_stream(mcq_ctx *c, const mcq_query *q, size_t n, uint32_t *mt_key, uint32_t *mt_pos,

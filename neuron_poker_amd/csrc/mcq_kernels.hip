@@ -216,6 +216,158 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
     if (qi < n) tally.flush(res + qi, lane);
 }
 
+// ---------------------------------------------------------------------------------------------- extended queries
+// SURVEY 8f-2 (ranges, hero range, ghost cards, second known hand): same slicing and tallying as above, the
+// simpler mask-based iteration of mcq_iteration_ext.  A range that could not be dealt zeroes the row's `runs`.
+__global__ __launch_bounds__(1024) void mcq_prep_ext_kernel(const mcq_query *__restrict__ q,
+                                                            const mcq_query_ext *__restrict__ ext, uint32_t n,
+                                                            mcq_result *__restrict__ res, uint64_t *__restrict__ prefix) {
+    __shared__ uint64_t part[1024];
+    __shared__ uint64_t carry;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+        uint32_t i = base + tid;
+        uint64_t cost = 0;
+        if (i < n) {
+            const uint4 raw = reinterpret_cast<const uint4 *>(q)[i];
+            const McqQueryWords qq = {raw.x, raw.y, raw.z, raw.w};
+            McqExtWords ew;
+#pragma unroll
+            for (int k = 0; k < 16; k++) ew.w[k] = reinterpret_cast<const uint32_t *>(ext + i)[k];
+            bool ok = mcq_query_ext_valid(qq, ew);
+            cost = ok ? (uint64_t)mcq_task_count(qq) * (3u * mcq_task_weight(qq)) : 0ull;
+            uint64_t *r = reinterpret_cast<uint64_t *>(res + i);
+            r[0] = ok ? qq.runs() : 0ull;
+            r[1] = ok ? 0ull : ~0ull;
+#pragma unroll
+            for (int k = 2; k < 13; k++) r[k] = 0;
+        }
+        part[tid] = cost;
+        __syncthreads();
+        for (uint32_t off = 1; off < 1024; off <<= 1) {
+            uint64_t v = tid >= off ? part[tid - off] : 0ull;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        if (i < n) prefix[i] = carry + part[tid] - cost;
+        __syncthreads();
+        if (tid == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (tid == 0) prefix[n] = carry;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kMaxBlock) void mcq_eval_ext_kernel(const mcq_query *__restrict__ queries,
+                                                                 const mcq_query_ext *__restrict__ ext, uint32_t n,
+                                                                 const uint64_t *__restrict__ prefix,
+                                                                 mcq_result *__restrict__ res, uint64_t seed,
+                                                                 uint64_t first_qid, const McqTables *__restrict__ g_tab,
+                                                                 const uint8_t *__restrict__ draws,
+                                                                 const uint64_t *__restrict__ draw_off) {
+    __shared__ __attribute__((aligned(16))) LdsTables tab;
+    __shared__ McqCard cards[64];
+    __shared__ uint32_t sets[(kMaxBlock / 64) * 12]; /* per wave: hero_range[6], opp_range[6] */
+    __shared__ uint32_t ids[(MCQ_MAX_OPP + 1) * kMaxBlock];
+    if (threadIdx.x < 64) cards[threadIdx.x] = mcq_card(threadIdx.x < 52 ? threadIdx.x : 0u);
+    load_tables(tab, g_tab);
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * waves_per_block + (threadIdx.x >> 6));
+    const uint64_t n_waves = (uint64_t)gridDim.x * waves_per_block;
+    const uint64_t total = prefix[n];
+    const uint64_t lo = total * wave / n_waves, hi = total * (wave + 1ull) / n_waves;
+    if (lo >= hi) return;
+    uint32_t *my_sets = sets + (threadIdx.x >> 6) * 12;
+    uint32_t *my_ids = ids + threadIdx.x;
+
+    uint32_t a = 0, b = n;
+    while (b - a > 1) {
+        const uint32_t mid = (a + b) >> 1;
+        if (prefix[mid] <= lo) a = mid; else b = mid;
+    }
+    uint32_t qi = __builtin_amdgcn_readfirstlane(a);
+    uint32_t task = 0, n_tasks = 0, weight = 1;
+    uint64_t pfx = 0;
+    McqExtCtx qc;
+    WaveTally tally;
+    tally.clear();
+    bool failed = false, fresh = true;
+    for (;;) {
+        if (fresh) {
+            if (qi >= n) break;
+            const uint4 raw = reinterpret_cast<const uint4 *>(queries)[qi];
+            const McqQueryWords q = {raw.x, raw.y, raw.z, raw.w};
+            pfx = prefix[qi];
+            const bool ok = prefix[qi + 1] > pfx;
+            n_tasks = ok ? mcq_task_count(q) : 0u;
+            weight = 3u * mcq_task_weight(q);
+            task = 0;
+            if (pfx < lo) task = (uint32_t)((lo - pfx + weight - 1) / weight);
+            fresh = false;
+            if (ok) {
+                McqExtWords ew;
+#pragma unroll
+                for (int k = 0; k < 16; k++) ew.w[k] = reinterpret_cast<const uint32_t *>(ext + qi)[k];
+                mcq_ext_ctx(q, ew, qc);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                if (lane < 12) /* words 8..13 = hero_range, 2..7 = opp_range */
+                    my_sets[lane] = reinterpret_cast<const uint32_t *>(ext + qi)[lane < 6 ? 8u + lane : lane - 4u];
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (task >= n_tasks) {
+            if (__any(failed)) {
+                if (lane == 0) atomicExch(reinterpret_cast<unsigned long long *>(res + qi), 0ull); /* runs := 0 */
+                failed = false;
+            }
+            tally.flush(res + qi, lane);
+            qi++;
+            fresh = true;
+            continue;
+        }
+        if (pfx + (uint64_t)task * weight >= hi) break;
+
+        McqLaneAcc acc = {0, 0, 0};
+        if (MODE == MCQ_MODE_PHILOX) {
+            const uint32_t stream = task * MCQ_WAVE + lane;
+            const uint64_t it0 = (uint64_t)stream * MCQ_STREAM_ITERS;
+            if (it0 < qc.runs) {
+                McqExtCtrDraws dr;
+                dr.w = 0;
+                dr.rng.seed(seed, first_qid + qi, stream);
+                const uint32_t cnt = (uint32_t)min((uint64_t)MCQ_STREAM_ITERS, (uint64_t)qc.runs - it0);
+                for (uint32_t j = 0; j < cnt && !failed; j++)
+                    failed = !mcq_iteration_ext(qc, dr, cards, tab.sel8, my_sets, my_sets + 6, my_ids, kMaxBlock, tab.tf,
+                                                tab.tops, tab.sd, tab.inv, acc);
+            }
+        } else {
+            const uint64_t stride = (qc.runs + 63u) & ~63ull;
+            const uint8_t *dbase = draws + draw_off[qi];
+            for (uint32_t j = 0; j < MCQ_STREAM_ITERS; j++) {
+                const uint64_t it = (uint64_t)task * MCQ_TASK_ITERS + j * MCQ_WAVE + lane;
+                if (it < qc.runs) {
+                    McqExtReplayDraws dr = {dbase + it, stride};
+                    mcq_iteration_ext(qc, dr, cards, tab.sel8, my_sets, my_sets + 6, my_ids, kMaxBlock, tab.tf, tab.tops,
+                                      tab.sd, tab.inv, acc);
+                }
+            }
+            acc.passes = 0;
+        }
+        tally.add(acc);
+        task++;
+    }
+    if (qi < n) {
+        if (__any(failed) && lane == 0) atomicExch(reinterpret_cast<unsigned long long *>(res + qi), 0ull);
+        tally.flush(res + qi, lane);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- showdown
 __global__ __launch_bounds__(256) void mcq_showdown_kernel(const uint8_t *__restrict__ hands, uint32_t n_tables,
                                                            uint32_t n_players, const McqTables *__restrict__ g_tab,
@@ -264,6 +416,25 @@ hipError_t mcq_launch_eval(int mode, const mcq_query *d_q, uint32_t n, const uin
     else
         hipLaunchKernelGGL(mcq_eval_kernel<MCQ_MODE_REPLAY_MT19937>, dim3(grid), dim3(block), 0, s, d_q, n, d_prefix,
                            d_res, seed, first_qid, d_luts, d_draws, d_draw_off);
+    return hipGetLastError();
+}
+
+hipError_t mcq_launch_prep_ext(const mcq_query *d_q, const mcq_query_ext *d_ext, uint32_t n, mcq_result *d_res,
+                               uint64_t *d_prefix, hipStream_t s) {
+    hipLaunchKernelGGL(mcq_prep_ext_kernel, dim3(1), dim3(1024), 0, s, d_q, d_ext, n, d_res, d_prefix);
+    return hipGetLastError();
+}
+
+hipError_t mcq_launch_eval_ext(int mode, const mcq_query *d_q, const mcq_query_ext *d_ext, uint32_t n,
+                               const uint64_t *d_prefix, mcq_result *d_res, uint64_t seed, uint64_t first_qid,
+                               const McqTables *d_luts, const uint8_t *d_draws, const uint64_t *d_draw_off, uint32_t grid,
+                               uint32_t block, hipStream_t s) {
+    if (mode == MCQ_MODE_PHILOX)
+        hipLaunchKernelGGL(mcq_eval_ext_kernel<MCQ_MODE_PHILOX>, dim3(grid), dim3(block), 0, s, d_q, d_ext, n, d_prefix,
+                           d_res, seed, first_qid, d_luts, d_draws, d_draw_off);
+    else
+        hipLaunchKernelGGL(mcq_eval_ext_kernel<MCQ_MODE_REPLAY_MT19937>, dim3(grid), dim3(block), 0, s, d_q, d_ext, n,
+                           d_prefix, d_res, seed, first_qid, d_luts, d_draws, d_draw_off);
     return hipGetLastError();
 }
 

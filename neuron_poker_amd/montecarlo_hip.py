@@ -18,9 +18,12 @@ Deliberate differences:
     mode 'replay' a call after seed(s) returns exactly what the reference returns after np.random.seed(s);
   * a hero card that is also on the table is rejected with ValueError (the reference silently swallows it,
     montecarlo_python.py:154-161);
-  * opponent ranges, hero ranges, ghost cards and several known hands are not on this path yet
-    (SURVEY.md 8f-2): they raise NotImplementedError instead of returning something else.
+  * opponent ranges (a fraction of the 169 preflop classes or an explicit set), a hero given as a set of
+    classes, ghost cards and ONE additional known hand are supported (tools/montecarlo_python.py:36-112, 133-181,
+    206-208; bit-exact in mode 'replay'); more than two known hands raise NotImplementedError.  A range that
+    cannot be dealt from the remaining cards raises ValueError where the reference would loop forever.
 """
+import json
 import os
 import threading
 from collections import Counter
@@ -64,6 +67,31 @@ def configure(mode=None, couple_numpy=None, dealing=None):
         _lib.default_engine().set_dealing_law(dealing)
 
 
+_CLASS_ORDER = None
+
+
+def _class_order():
+    """The 169 preflop classes in the order the reference sorts them by equity (ascending); generated from the
+    reference by tests/golden/gen_golden.py into preflop_classes.json."""
+    global _CLASS_ORDER
+    if _CLASS_ORDER is None:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "preflop_classes.json")) as f:
+            _CLASS_ORDER = json.load(f)
+    return _CLASS_ORDER
+
+
+def _opponent_range_bits(opponent_range):
+    """run_montecarlo's opponent_range -> 169-bit set or None for "every class" (montecarlo_python.py:194-199 and
+    :105-112: a number keeps the LAST int(169 * r) classes of the equity-sorted list -- and all of them when that
+    is 0, as list[-0:] does --, anything else is used as the set of allowed classes)."""
+    if type(opponent_range) in (float, int):
+        take = int(169 * opponent_range)
+        if take <= 0 or take >= 169:
+            return None
+        return _lib.range_bits(_class_order()[-take:])
+    return _lib.range_bits(opponent_range)
+
+
 def _take_ids(n):
     with _lock:
         first = _state["counter"]
@@ -99,25 +127,35 @@ class MonteCarlo(object):
 
     def run_montecarlo(self, original_player_card_list, original_table_card_list, player_amount, ui, maxRuns,
                        timeout, ghost_cards, opponent_range=1, *, mode=None, seed=None):
-        if ghost_cards != '' and ghost_cards is not None:
-            raise NotImplementedError("ghost_cards are not on the HIP path yet (SURVEY.md 8f-2)")
-        if not (isinstance(opponent_range, (int, float)) and float(opponent_range) >= 1.0):
-            raise NotImplementedError("opponent_range < 1 / explicit ranges are not on the HIP path yet "
-                                      "(SURVEY.md 8f-2)")
-        if len(original_player_card_list) != 1 or isinstance(original_player_card_list[0], (set, frozenset)):
-            raise NotImplementedError("only one known hand given as two cards is on the HIP path "
-                                      "(hero ranges / collusion hands: SURVEY.md 8f-2)")
-        q = _query(list(original_player_card_list[0]), list(original_table_card_list), player_amount, maxRuns)
         eng = self._engine or _lib.default_engine()
         m = _state["mode"] if mode is None else _MODES[mode]
-        if m == _lib.MODE_REPLAY_MT19937 and _state["couple_numpy"] and seed is None:
-            res = eng.eval_batch_numpy_stream(q)[0]
-        else:
-            if seed is None:
-                s, first = _take_ids(1)
+        players = list(original_player_card_list)
+        if not 1 <= len(players) <= 2:
+            raise NotImplementedError("one or two known hands are supported (hero and one collusion hand)")
+        hero = players[0]
+        hero_is_range = isinstance(hero, (set, frozenset))
+        if len(players) == 2 and isinstance(players[1], (set, frozenset)):
+            raise NotImplementedError("only the first hand may be given as a range")
+        opp_bits = _opponent_range_bits(opponent_range)
+        plain = not hero_is_range and len(players) == 1 and opp_bits is None and (ghost_cards == '' or ghost_cards is None)
+        q = _query(["2C", "2D"] if hero_is_range else list(hero), list(original_table_card_list), player_amount, maxRuns)
+        if plain:
+            if m == _lib.MODE_REPLAY_MT19937 and _state["couple_numpy"] and seed is None:
+                res = eng.eval_batch_numpy_stream(q)[0]
             else:
-                s, first = int(seed), 0
-            res = eng.eval_batch(q, s, first_query_id=first, mode=m)[0]
+                s, first = _take_ids(1) if seed is None else (int(seed), 0)
+                res = eng.eval_batch(q, s, first_query_id=first, mode=m)[0]
+        else:
+            if hero_is_range:
+                q["hole"] = 0
+            ghost = None
+            if ghost_cards != '' and ghost_cards is not None:
+                ghost = [card_id(ghost_cards[0]), card_id(ghost_cards[1])]
+            ext = _lib.pack_query_ext(1, ghost=ghost,
+                                      known2=[card_id(c) for c in players[1]] if len(players) == 2 else None,
+                                      hero_range=_lib.range_bits(hero) if hero_is_range else None, opp_range=opp_bits)
+            s, first = _take_ids(1) if seed is None else (int(seed), 0)
+            res = eng.eval_batch_ext(q, ext, s, first_query_id=first, mode=m)[0]
         runs = int(res["runs"])
         wins = int(res["win"]) + int(res["tie"])
         self.result = res

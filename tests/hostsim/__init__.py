@@ -91,3 +91,15 @@ def run_replay_numpy_stream(query16):
         raise ValueError(rc)
     np.random.set_state((st[0], key, int(pos.value), st[3], st[4]))
     return out
+
+
+def run_ext(replay, query16, ext64, seed, qid=0):
+    q = np.ascontiguousarray(query16, np.uint8)
+    e = np.ascontiguousarray(ext64).view(np.uint8)
+    out = np.zeros(13, np.uint64)
+    lib().hs_run_ext.restype = C.c_int
+    rc = lib().hs_run_ext(C.c_int(1 if replay else 0), _p(q, C.c_uint8), _p(e, C.c_uint8), C.c_uint64(seed),
+                          C.c_uint64(qid), _p(out, C.c_uint64))
+    if rc:
+        raise ValueError(rc)
+    return out

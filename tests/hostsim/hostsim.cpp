@@ -158,6 +158,56 @@ void hs_mt_words(uint32_t seed, uint32_t n, uint32_t *out) {
 }
 }
 
+// ---- extended queries (ranges, hero range, ghost cards, second known hand)
+static void ext_words(const mcq_query_ext *e, McqExtWords &w) { memcpy(w.w, e, 64); }
+
+extern "C" int hs_run_ext(int replay, const mcq_query *q, const mcq_query_ext *e, uint64_t seed, uint64_t qid,
+                          mcq_result *out) {
+    McqExtWords ew;
+    ext_words(e, ew);
+    const McqQueryWords qw = mcq_query_words(*q);
+    if (!mcq_query_ext_valid(qw, ew)) return MCQ_EINVAL;
+    const McqTables &t = luts();
+    McqExtCtx qc;
+    mcq_ext_ctx(qw, ew, qc);
+    McqCard cards[64];
+    for (uint32_t c = 0; c < 64; c++) cards[c] = mcq_card(c < 52 ? c : 0);
+    memset(out, 0, sizeof(*out));
+    out->runs = q->runs;
+    uint32_t ids[MCQ_MAX_OPP + 1];
+    if (replay) {
+        size_t stride = q->runs ? q->runs : 1;
+        std::vector<uint8_t> draws((size_t)mcq_ext_draws_per_iteration(*q, *e) * stride + 1);
+        McqMt19937 g;
+        g.seed((uint32_t)seed);
+        uint64_t passes = mcq_replay_parse_ext(*q, *e, g, draws.data(), stride, 1000000u);
+        if (passes == ~0ull) return MCQ_EINVAL;
+        out->passes = passes;
+        for (uint32_t it = 0; it < q->runs; it++) {
+            McqExtReplayDraws dr = {draws.data() + it, stride};
+            McqLaneAcc acc = {0, 0, 0};
+            mcq_iteration_ext(qc, dr, cards, t.sel8, ew.w + 8, ew.w + 2, ids, 1, t.tf, t.tops, t.sd, t.inv, acc);
+            acc.passes = 0;
+            fold(acc, out);
+        }
+        return MCQ_OK;
+    }
+    uint32_t n_streams = (q->runs + MCQ_STREAM_ITERS - 1) / MCQ_STREAM_ITERS;
+    for (uint32_t s = 0; s < n_streams; s++) {
+        McqExtCtrDraws dr;
+        dr.w = 0;
+        dr.rng.seed(seed, qid, s);
+        McqLaneAcc acc = {0, 0, 0};
+        for (uint32_t j = 0; j < MCQ_STREAM_ITERS; j++) {
+            if ((uint64_t)s * MCQ_STREAM_ITERS + j >= q->runs) break;
+            if (!mcq_iteration_ext(qc, dr, cards, t.sel8, ew.w + 8, ew.w + 2, ids, 1, t.tf, t.tops, t.sd, t.inv, acc))
+                return MCQ_EINVAL;
+        }
+        fold(acc, out);
+    }
+    return MCQ_OK;
+}
+
 extern "C" int hs_check_inv(void) { /* (x * inv[d]) >> 20 == x / d for every x < d * d, d in [1, 51] */
     const McqTables &t = luts();
     for (uint32_t d = 1; d <= 51; d++)

@@ -261,8 +261,8 @@ def test_dropin_module_matches_reference_call_surface(eng):
     with pytest.raises(ValueError):
         mh.get_equity({"AS", "Kx"}, set(), 2, 100)
     with pytest.raises(NotImplementedError):
-        mh.MonteCarlo(eng).run_montecarlo([["AS", "KS"]], [], 2, 1, maxRuns=10, timeout=0, ghost_cards="",
-                                          opponent_range=0.25)
+        mh.MonteCarlo(eng).run_montecarlo([["AS", "KS"], ["2C", "2D"], ["3C", "3D"]], [], 4, 1, maxRuns=10, timeout=0,
+                                          ghost_cards="")
 
 
 def test_numpy_stream_coupling_on_gpu(eng):
@@ -308,3 +308,44 @@ def test_uniform_dealing_law(eng):
         assert abs(100 * eq[0] - 51.8) < 1.0 and abs(100 * eq[1] - 67.7) < 1.0
     finally:
         eng.set_dealing_law("reference")
+
+
+def test_ranges_ghost_cards_known_hands(eng):
+    """SURVEY 8f-2 through the drop-in surface: replay mode == the reference's seeded results
+    (tests/golden/ext_tallies.json, incl. the inputs of tests/test_montecarlo_python.py:215-232), production
+    mode == the oracle's CTR mode."""
+    rows = jload("ext_tallies.json")
+    with open(os.path.join(os.path.dirname(G), "..", "neuron_poker_amd", "preflop_classes.json")) as f:
+        order = json.load(f)
+    for t in rows:
+        pl = [set(p) if (i == 0 and t["hero_is_range"]) else p for i, p in enumerate(t["players"])]
+        rng = set(t["opponent_range"]) if isinstance(t["opponent_range"], list) else t["opponent_range"]
+        sim = mh.MonteCarlo(eng)
+        eq, _ = sim.run_montecarlo(pl, t["board"], t["n_players"], 1, maxRuns=t["runs"], timeout=0,
+                                   ghost_cards=t["ghost"] or "", opponent_range=rng, mode="replay", seed=t["seed"])
+        assert (round(eq * t["runs"]), sim.passes) == (t["wins"], t["passes"]), t
+        assert [int(x) for x in sim.result["by_type"]] == t["by_type"], t
+        # production mode against the oracle
+        sim.run_montecarlo(pl, t["board"], t["n_players"], 1, maxRuns=1500, timeout=0, ghost_cards=t["ghost"] or "",
+                           opponent_range=rng, mode="philox", seed=31)
+        if isinstance(rng, set):
+            opp = sorted(rng)
+        else:
+            take = int(169 * rng)
+            opp = None if take == 0 or take >= 169 else order[-take:]
+        exp = O.run_ex(O.MODE_CTR, t["players"][0], t["board"], t["n_players"], 1500, 31,
+                       known2=t["players"][1] if len(t["players"]) > 1 else None, ghost=t["ghost"] or None,
+                       opp_range=opp)["tallies"]
+        assert np.array_equal(sim.result.view(np.uint64).reshape(13), exp), t
+    # tests/test_montecarlo_python.py:215-232: 12.8 % and 77.8 % within 3 points
+    board = ["3D", "9H", "AS", "7S", "QH"]
+    a = mh.MonteCarlo(eng)
+    a.run_montecarlo([["KS", "KC"]], board, 3, 1, maxRuns=100000, timeout=0, ghost_cards="", opponent_range=0.25, seed=1)
+    b = mh.MonteCarlo(eng)
+    b.run_montecarlo([{"AKO", "AA"}], board, 3, 1, maxRuns=100000, timeout=0, ghost_cards="", opponent_range=0.25, seed=2)
+    assert abs(100 * a.equity - 12.8) < 3 and abs(100 * b.equity - 77.8) < 3
+    assert abs(sum(b.winnerCardTypeList.values()) - b.equity) < 1e-4
+    # a range that cannot be dealt (both remaining aces are dead) raises instead of hanging
+    with pytest.raises(ValueError):
+        mh.MonteCarlo(eng).run_montecarlo([["AS", "AH"]], ["AD", "AC", "2C"], 2, 1, maxRuns=100, timeout=0,
+                                          ghost_cards="", opponent_range={"AA"}, seed=3)

@@ -136,3 +136,43 @@ def test_uniform_law_equals_oracle(hero, board, n, runs):
     got = H.run_ctr(q, 77, 5, uniform=True)
     exp = O.run(O.MODE_CTR_UNIFORM, hero, board, n, runs, 77, qid=5)["tallies"]
     assert np.array_equal(got, exp)
+
+
+def _ext_case(t):
+    """fixture row of tests/golden/ext_tallies.json -> (query16, ext record, oracle kwargs)"""
+    import neuron_poker_amd as npa
+    pl = t["players"]
+    r = t["opponent_range"]
+    if isinstance(r, list):
+        opp = r
+    else:
+        with open(os.path.join(os.path.dirname(G), "..", "neuron_poker_amd", "preflop_classes.json")) as f:
+            order = json.load(f)
+        take = int(169 * r)
+        opp = None if take == 0 or take >= 169 else order[-take:]
+    hero_cards = ["2C", "2D"] if t["hero_is_range"] else pl[0]
+    q = q16(hero_cards, t["board"], t["n_players"], t["runs"])
+    if t["hero_is_range"]:
+        q = q.copy()
+        q[0:2] = 0
+    ext = npa.pack_query_ext(1, ghost=[O.card_id(c) for c in t["ghost"]] if t["ghost"] else None,
+                             known2=[O.card_id(c) for c in pl[1]] if len(pl) > 1 else None,
+                             hero_range=npa.range_bits(pl[0]) if t["hero_is_range"] else None,
+                             opp_range=npa.range_bits(opp) if opp is not None else None)
+    kw = dict(known2=pl[1] if len(pl) > 1 else None, ghost=t["ghost"] or None, opp_range=opp)
+    return q, ext, kw
+
+
+def test_extended_queries_replay_equals_reference_and_ctr_equals_oracle():
+    """ranges, hero range, ghost cards, second known hand through the product's lane code."""
+    with open(os.path.join(G, "ext_tallies.json")) as f:
+        rows = json.load(f)
+    for t in rows:
+        q, ext, kw = _ext_case(t)
+        r = H.run_ext(True, q, ext, t["seed"])
+        assert (int(r[2] + r[3]), int(r[1]), [int(x) for x in r[4:]]) == (t["wins"], t["passes"], t["by_type"]), t
+        small = q.copy()
+        small[12:16] = np.array([700], "<u4").view(np.uint8)
+        got = H.run_ext(False, small, ext, 99, qid=4)
+        exp = O.run_ex(O.MODE_CTR, t["players"][0], t["board"], t["n_players"], 700, 99, qid=4, **kw)["tallies"]
+        assert np.array_equal(got, exp), t
