@@ -336,7 +336,7 @@ def test_ranges_ghost_cards_known_hands(eng):
         exp = O.run_ex(O.MODE_CTR, t["players"][0], t["board"], t["n_players"], 1500, 31,
                        known2=t["players"][1] if len(t["players"]) > 1 else None, ghost=t["ghost"] or None,
                        opp_range=opp)["tallies"]
-        assert np.array_equal(sim.result.view(np.uint64).reshape(13), exp), t
+        assert np.array_equal(np.frombuffer(sim.result.tobytes(), np.uint64), exp), t
     # tests/test_montecarlo_python.py:215-232: 12.8 % and 77.8 % within 3 points
     board = ["3D", "9H", "AS", "7S", "QH"]
     a = mh.MonteCarlo(eng)
