@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--states", type=int, default=4096, help="states per GPU")
     ap.add_argument("--iters", type=int, default=100000)
     ap.add_argument("--players", type=int, default=6)
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) for real runs; gloo rehearses the N > 1 control "
+                    "flow (tallies all-reduced through host memory)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
@@ -118,11 +121,16 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
                              "--master-addr 127.0.0.1 bench.py --gpus %d ..." % (args.gpus, args.gpus))
         raise SystemExit("--gpus (%d) != WORLD_SIZE (%d)" % (args.gpus, world))
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     eng = npa.Engine(local_rank)
     B, N, runs = args.states, args.players, args.iters
@@ -140,7 +148,12 @@ def main():
         eng.eval_batch_device(d_q.data_ptr(), B, seed + i, mine.data_ptr(), first_query_id=rank * B,
                               stream=stream.cuda_stream)
         if world > 1:
-            dist.all_reduce(tallies, op=dist.ReduceOp.SUM)  # the path's one collective: integer tallies over xGMI
+            if args.backend == "nccl":
+                dist.all_reduce(tallies, op=dist.ReduceOp.SUM)  # the path's one collective: integer tallies over xGMI
+            else:  # rehearsal through host memory
+                host = tallies.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                tallies.copy_(host)
 
     def fence():
         torch.cuda.synchronize()
@@ -157,7 +170,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
@@ -228,6 +241,28 @@ def main():
             dt = (time.perf_counter() - t1) / 5
             extras["configs[2]_4096x3x50k"] = {"call_ms_host_buffers": 1e3 * dt, "kernel_ms": eng.last_kernel_ms,
                                                "hand_evals_per_s": 4096 * 3 * 50000 / dt}
+        # BASELINE configs[4], equity side only: one lock-step of 512 six-seat tables issues <= 2 x 512 queries of 1000
+        # runs (gym_env/env.py:22,261-262) in ONE call; state mix as observed in reference episodes (SURVEY 8c F5:
+        # table cards 0/3/4/5 = 59/19/11/10 %, players alive 2..6 = 41/28/17/9/6 %).  The table logic itself is
+        # not part of this number (not built yet).
+        g = np.random.default_rng(512)
+        nb = g.choice([0, 3, 4, 5], size=1024, p=[0.59, 0.19, 0.11, 0.11])
+        npl = g.choice([2, 3, 4, 5, 6], size=1024, p=[0.41, 0.28, 0.17, 0.09, 0.05])
+        hq, bq = [], []
+        for i in range(1024):
+            cards = g.choice(52, 2 + nb[i], replace=False)
+            hq.append(cards[:2])
+            bq.append(list(cards[2:]) + [255] * (5 - nb[i]))
+        q5 = npa.pack_queries(hq, bq, npl, 1000)
+        for _ in range(3):
+            eng.eval_batch(q5, seed=1)
+        t1 = time.perf_counter()
+        for i in range(50):
+            eng.eval_batch(q5, seed=i)
+        dt = (time.perf_counter() - t1) / 50
+        extras["configs[4]_equity_side_only_1024x1000"] = {"call_ms_host_buffers": 1e3 * dt, "kernel_ms": eng.last_kernel_ms,
+                                                           "hand_evals_per_s": float((npl * 1000).sum()) / dt,
+                                                           "lock_steps_per_s": 1.0 / dt}
         out["other_configs"] = extras
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(N, runs)

@@ -105,15 +105,14 @@ uint32_t tasks_of(const mcq_query &q) { return (q.runs + MCQ_TASK_ITERS - 1) / M
 void pick_geometry(const mcq_ctx *c, int mode, uint64_t total_tasks, uint32_t *grid, uint32_t *block) {
     const uint32_t full = (uint32_t)c->n_cu * (uint32_t)c->occ[mode];
     if (total_tasks == 0) { *block = kBlock; *grid = full; return; }
-    if (total_tasks <= (uint64_t)c->n_cu * 4) { /* few tasks (single query): one wave per block spreads over CUs */
-        *block = 64;
-        *grid = (uint32_t)total_tasks;
-        return;
-    }
-    const uint64_t wpb = kBlock / 64;
-    uint64_t blocks = (total_tasks + wpb - 1) / wpb;
-    *block = kBlock;
-    *grid = (uint32_t)(blocks < full ? blocks : full);
+    /* one block per CU (the LDS tables allow no more); few tasks are spread over all CUs with fewer waves per
+     * block: 98 tasks of a single 100k query -> 98 one-wave blocks, 1024 tasks -> 256 four-wave blocks */
+    uint64_t wpb = (total_tasks + (uint64_t)c->n_cu - 1) / (uint64_t)c->n_cu;
+    if (wpb < 1) wpb = 1;
+    if (wpb > kBlock / 64) wpb = kBlock / 64;
+    const uint64_t blocks = (total_tasks + wpb - 1) / wpb;
+    *block = (uint32_t)(64 * wpb);
+    *grid = (uint32_t)(blocks < (uint64_t)c->n_cu ? blocks : (wpb == kBlock / 64 ? full : (uint64_t)c->n_cu));
 }
 
 int run_slice(mcq_ctx *c, int mode, const mcq_query *d_q, uint32_t n, mcq_result *d_res, uint64_t seed,

@@ -349,3 +349,32 @@ def test_ranges_ghost_cards_known_hands(eng):
     with pytest.raises(ValueError):
         mh.MonteCarlo(eng).run_montecarlo([["AS", "AH"]], ["AD", "AC", "2C"], 2, 1, maxRuns=100, timeout=0,
                                           ghost_cards="", opponent_range={"AA"}, seed=3)
+
+
+def test_table_driver_reproduces_reference_episodes_on_gpu(eng):
+    """seeded episodes of the reference's own table (tests/golden/env_traces.json) replayed by
+    neuron_poker_amd/table_driver.py with the GPU doing every equity query (parity mode on numpy's global
+    stream) and every showdown."""
+    from neuron_poker_amd import table_driver as td
+
+    def showdown(hands):
+        w, _ = eng.showdown(np.array([hands], np.uint8))
+        return int(w[0])
+
+    for ep in jload("env_traces.json")[:6]:
+        table = td.TableSim([td.equity_policy(c, b) for c, b in ep["policies"]], initial_stacks=ep["stacks"],
+                            showdown=showdown)
+        table.log = []
+        np.random.seed(ep["seed"])
+        g = table.episode()
+        try:
+            hole, board, alive = next(g)
+            while True:
+                q = npa.pack_queries([hole], [list(board) + [255] * (5 - len(board))], alive, 1000)
+                r = eng.eval_batch_numpy_stream(q)[0]
+                hole, board, alive = g.send(float(int(r["win"] + r["tie"]) / 1000))
+        except StopIteration:
+            pass
+        assert table.log == ep["events"], ep["seed"]
+        assert table.winner_ix == ep["winner"] and [float(s) for s in table.stacks] == ep["final_stacks"]
+        assert [int(x) for x in np.random.randint(0, 2 ** 32, size=2, dtype=np.uint32)] == ep["np_next_words"]
