@@ -465,7 +465,9 @@ MCQ_HD uint32_t mcq_task_weight(const McqQueryWords &q) {
     const uint32_t n = q.n_players(), deal = 5u - q.n_board();
     return 45u * n + 65u * (n - 1u) + 40u * deal + 60u;
 }
-MCQ_HD uint32_t mcq_task_count(const McqQueryWords &q) { return (q.runs() + MCQ_TASK_ITERS - 1u) / MCQ_TASK_ITERS; }
+MCQ_HD uint32_t mcq_task_count(const McqQueryWords &q) { /* no overflow for runs up to 2^32 - 1 */
+    return q.runs() / MCQ_TASK_ITERS + (q.runs() % MCQ_TASK_ITERS != 0u ? 1u : 0u);
+}
 
 static inline McqQueryWords mcq_query_words(const mcq_query &q) { /* host side */
     McqQueryWords w;

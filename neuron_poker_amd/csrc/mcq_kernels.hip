@@ -38,7 +38,16 @@ static_assert(sizeof(LdsTables) == sizeof(McqTables), "table image is copied wor
 __device__ __forceinline__ void load_tables(LdsTables &dst, const McqTables *__restrict__ g) {
     const uint4 *src = reinterpret_cast<const uint4 *>(g);
     uint4 *d = reinterpret_cast<uint4 *>(&dst);
-    for (uint32_t i = threadIdx.x; i < sizeof(LdsTables) / 16; i += blockDim.x) d[i] = src[i];
+    constexpr uint32_t kVec = sizeof(LdsTables) / 16;
+    uint32_t i = threadIdx.x;
+    for (; i + 7u * blockDim.x < kVec; i += 8u * blockDim.x) { /* eight 16-byte loads in flight per lane */
+        uint4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = src[i + k * blockDim.x];
+#pragma unroll
+        for (int k = 0; k < 8; k++) d[i + k * blockDim.x] = v[k];
+    }
+    for (; i < kVec; i += blockDim.x) d[i] = src[i];
     __syncthreads();
 }
 
