@@ -31,7 +31,7 @@
 #define MCQ_HDM inline
 #endif
 
-#define MCQ_STREAM_ITERS 16u /* iterations per RNG stream (MCQ-CTR v1) */
+#define MCQ_STREAM_ITERS 16u /* iterations per RNG stream (MCQ-CTR v2) */
 #define MCQ_WAVE 64u
 #define MCQ_TASK_ITERS (MCQ_STREAM_ITERS * MCQ_WAVE) /* iterations per wave task */
 #define MCQ_MAX_OPP 9
@@ -59,14 +59,8 @@ MCQ_HD uint32_t mcq_mulhi(uint32_t a, uint32_t b) {
 #endif
 }
 MCQ_HD uint32_t mcq_rotl(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
-MCQ_HD uint32_t mcq_topbit(uint32_t m) { return 0x80000000u >> (mcq_clz(m) & 31u); } /* garbage for m == 0 */
-MCQ_HD uint32_t mcq_droplow(uint32_t m) { return m & (m - 1); }
-MCQ_HD uint32_t mcq_nz_mask(uint32_t x) { /* x < 2^31: all ones if x != 0 else 0, without compare/select */
-    return (uint32_t)((int32_t)(0u - x) >> 31);
-}
-// Hide a value from the optimiser (device: pins it in a VGPR).  Used (a) to keep arithmetic masks as AND/XOR
-// instead of v_cmp + v_cndmask (8.6 vs 2.3 cycles) and (b) to keep wave-uniform operands out of SGPRs, which
-// would turn the 2.3-cycle VALU forms into 4.3-cycle ones.
+// Hide a value from the optimiser (device: pins it in a VGPR): keeps the compiler from re-associating a sum into
+// separately shifted parts, so that a table address stays ONE shift-add.
 MCQ_HD uint32_t mcq_opaque(uint32_t x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" : "+v"(x));
@@ -165,7 +159,7 @@ static inline void mcq_fill_tables(McqTables *t) {
     }
 }
 
-// ------------------------------------------------------------------------------------------ RNG: MCQ-CTR v1
+// ------------------------------------------------------------------------------------------ RNG: MCQ-CTR v2
 MCQ_HD void mcq_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                               uint32_t out[4]) {
 #pragma unroll

@@ -5,7 +5,7 @@
  * product: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it, and only
  * as the checker / the reported CPU baseline.  Nothing under neuron_poker_amd/ links, imports or calls it.
  *
- * Parity status: PINNED.  tests/test_oracle_golden.py checks every function below against fixtures that
+ * Parity status: PINNED.  tests/test_oracle_golden.py checks every reference-facing function below against fixtures that
  * were produced by running the reference itself (tests/golden/gen_golden.py imports
  * /root/reference/tools/{montecarlo_python,hand_evaluator}.py under np.random.seed): evaluator scores,
  * showdown winners, per-iteration dealt cards, MT19937 word counts and final tallies.
@@ -17,9 +17,10 @@
  *   tools/hand_evaluator.py:27-119    _calc_score           -> calc_score()
  *   tools/hand_evaluator.py:20-24     eval_best_hand        -> best_hand()
  *   tools/montecarlo_python.py:114-119 create_card_deck     -> deck_init()
- *   tools/montecarlo_python.py:121-183 distribute_cards_to_players -> deal_players()
- *   tools/montecarlo_python.py:185-189 distribute_cards_to_table   -> deal_table()
- *   tools/montecarlo_python.py:191-252 run_montecarlo       -> run_one()
+ *   tools/montecarlo_python.py:121-183 distribute_cards_to_players -> deal_iteration(), mcqo_run_ex()
+ *   tools/montecarlo_python.py:185-189 distribute_cards_to_table   -> deal_iteration(), mcqo_run_ex()
+ *   tools/montecarlo_python.py:191-252 run_montecarlo       -> mcqo_run(), mcqo_run_ex()
+ *   tools/montecarlo_python.py:24-112  preflop classes / ranges    -> class_index(), in_range()
  *   numpy 1.26.4 (uv.lock:325-326; third party, not under /root/reference):
  *     numpy/random/src/mt19937/mt19937.c  init_genrand / genrand  -> mt_seed()/mt_next()
  *     numpy/random/src/distributions/distributions.c  buffered_bounded_masked_uint32 (legacy
