@@ -58,6 +58,18 @@ MCQ_HD uint32_t mcq_mulhi(uint32_t a, uint32_t b) {
     return (uint32_t)(((uint64_t)a * b) >> 32);
 #endif
 }
+// mulhi32(a, b) + 128: draw indices travel as r | 0x80 (r < 64), the form the byte-SWAR hole scan wants, so the
+// bias comes for free with the multiply (one v_mad_u64_u32)
+MCQ_HD uint32_t mcq_mulhi_p128(uint32_t a, uint32_t b) {
+    return (uint32_t)(((uint64_t)a * b + (128ull << 32)) >> 32);
+}
+MCQ_HD bool mcq_any(bool pred) { /* true if the predicate holds in any active lane of the wave */
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __any(pred) != 0;
+#else
+    return pred;
+#endif
+}
 MCQ_HD uint32_t mcq_rotl(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
 // Hide a value from the optimiser (device: pins it in a VGPR): keeps the compiler from re-associating a sum into
 // separately shifted parts, so that a table address stays ONE shift-add.
@@ -117,13 +129,11 @@ MCQ_HD uint32_t mcq_straight_runs(uint32_t m) {
 //   tf[m]   (u32, byte offset m4):  complete key of the SUIT mask m: StraightFlush (all ranks of the suit
 //           plus the -1 slot when it holds the ace, hand_evaluator.py:71-80,93), Flush (top five, :98-100), or 0
 //           when popcount(m) < 5
-//   inv[d]: 2^20 / d + 1, so that (x * inv[d]) >> 20 == x / d for x < d * d
 struct McqTables {
     uint32_t tf[8192];
     uint32_t tops[8192];
     uint32_t sd[8192];
     uint32_t sel8[256];
-    uint32_t inv[64];
 };
 
 static inline void mcq_fill_tables(McqTables *t) {
@@ -133,8 +143,6 @@ static inline void mcq_fill_tables(McqTables *t) {
             if (v >> b & 1) e |= b << (3 * j++);
         t->sel8[v] = e;
     }
-    t->inv[0] = 0;
-    for (uint32_t d = 1; d < 64; d++) t->inv[d] = (1u << 20) / d + 1u;
     for (uint32_t m = 0; m < 8192; m++) {
         uint32_t runs = mcq_straight_runs(m);
         uint32_t st = runs ? (0x80u | (32u - (uint32_t)__builtin_clz(runs))) : 0;
@@ -197,29 +205,30 @@ struct McqXoshiro { /* xoshiro128++ (Blackman & Vigna) */
     }
 };
 
-// Draw policy of the production mode, "MCQ-CTR v2": the reference's dealing law without its re-draw loop.
-//   Opponent pair on a deck of length L from ONE word u: x = mulhi32(u, (L-1)^2), a = x / (L-1), c = x % (L-1);
-//   (r1, r2) = (a, c) if a != c else (L-1, a).  That is a bijection from [0, (L-1)^2) onto the pairs the
-//   reference accepts (r1 in [0,L), r2 in [0,L-1), r1 != r2; montecarlo_python.py:167-176), so every accepted
-//   pair is as likely as after the reference's rejection loop, with no divergent loop on the GPU.  No attempt
-//   is ever rejected, hence `passes` = one per opponent per iteration (added by the caller).
+// Draw policy of the production mode, "MCQ-CTR v3": the reference's dealing law without its re-draw loop.
+//   Opponent pair on a deck of length L from ONE word u, d = L - 1:  a = mulhi32(u, d), c = mulhi32(u * d mod 2^32, d)
+//   -- (a, c) is uniform on [0, d)^2 up to d^2 / 2^32 -- and (r1, r2) = (a, c) if a != c else (d, a).  That is a
+//   bijection from [0, d)^2 onto the pairs the reference accepts (r1 in [0,L), r2 in [0,L-1), r1 != r2;
+//   montecarlo_python.py:167-176), so every accepted pair is as likely as after the reference's rejection loop,
+//   with no divergent loop on the GPU.  No attempt is ever rejected, hence `passes` = one per opponent per
+//   iteration (added by the caller).
 //   Table cards, two per word: even draw: u = next(), idx = mulhi32(u, n), w = u * n; odd draw: idx = mulhi32(w, n)
 //   (n = deck length - 1: never the last card, montecarlo_python.py:188).  Bias of either <= 2401 / 2^32.
-// inv[d] = 2^20 / d + 1 makes (x * inv[d]) >> 20 == x / d exactly for x < (d + 1) * d <= 2652 (checked in the tests).
 // UNIFORM = true is the opt-in unbiased law (what montecarlo_cython.pyx:188 and
-// Montecarlo.cpp:296-312 intend): x = mulhi32(u, L (L-1)), (r1, r2) = (x / (L-1), x % (L-1)) -- every ordered pair
-// of distinct cards -- and table draws over all n = deck length cards.
+// Montecarlo.cpp:296-312 intend): a = mulhi32(u, L), c = mulhi32(u * L, d), (r1, r2) = (a, c) -- every ordered pair of
+// distinct cards -- and table draws over all n = deck length cards.
+// All draws are returned as r | 0x80 (see mcq_mulhi_p128).
 template <bool UNIFORM>
 struct McqCtrDrawsT {
     static constexpr uint32_t kTableShort = UNIFORM ? 0u : 1u; /* table draw range = deck length - kTableShort */
     McqXoshiro rng;
     uint32_t w;
-    MCQ_HDM void pair(uint32_t L, const uint32_t *inv, uint32_t &r1, uint32_t &r2) {
-        const uint32_t dd = L - 1u;
-        const uint32_t x = mcq_mulhi(rng.next(), (UNIFORM ? L : dd) * dd);
-        const uint32_t a = (x * inv[dd]) >> 20;
-        const uint32_t c = x - a * dd;
-        r1 = (!UNIFORM && a == c) ? dd : a;
+    MCQ_HDM void pair(uint32_t L, uint32_t &r1, uint32_t &r2) {
+        const uint32_t dd = L - 1u, m1 = UNIFORM ? L : dd;
+        const uint32_t u = rng.next();
+        const uint32_t a = mcq_mulhi_p128(u, m1);
+        const uint32_t c = mcq_mulhi_p128(u * m1, dd);
+        r1 = (!UNIFORM && a == c) ? dd + 128u : a;
         r2 = c;
     }
     template <int K>
@@ -227,9 +236,9 @@ struct McqCtrDrawsT {
         if ((K & 1) == 0) {
             const uint32_t u = rng.next();
             w = u * n;
-            return mcq_mulhi(u, n);
+            return mcq_mulhi_p128(u, n);
         }
-        return mcq_mulhi(w, n);
+        return mcq_mulhi_p128(w, n);
     }
 };
 typedef McqCtrDrawsT<false> McqCtrDraws;
@@ -242,7 +251,7 @@ struct McqReplayDraws {
     static constexpr uint32_t kTableShort = 1u;
     const uint8_t *p; /* &draws[iteration] */
     uint64_t stride;
-    MCQ_HDM void pair(uint32_t, const uint32_t *, uint32_t &r1, uint32_t &r2) {
+    MCQ_HDM void pair(uint32_t, uint32_t &r1, uint32_t &r2) { /* the host stores every draw as r | 0x80 */
         r1 = p[0];
         r2 = p[stride];
         p += 2 * stride;
@@ -368,7 +377,6 @@ MCQ_HD uint32_t mcq_eval_key(const McqBoard &b, const McqFlushSel &fs, const Mcq
     const uint32_t eq4 = b.eq4 | (b.ge3 & h.B) | (b.ge2 & h.P);
 
     /* lookups first: their latency overlaps the arithmetic below */
-    const uint32_t e_any = mcq_ld_u32(tops, any);
     const uint32_t e_ge2 = mcq_ld_u32(tops, ge2);
     const uint32_t e_ge3 = mcq_ld_u32(tops, ge3);
     const uint32_t d_any = mcq_ld_u32(sd, any);
@@ -387,7 +395,9 @@ MCQ_HD uint32_t mcq_eval_key(const McqBoard &b, const McqFlushSel &fs, const Mcq
                     (fh ? (uint32_t)MCQ_C_FULL << MCQ_KEY_SHIFT : (uint32_t)MCQ_C_TWOPAIR << MCQ_KEY_SHIFT);
     key2 = (H != 0 && R != 0) ? key2 : 0u;
 
-    const uint32_t key4 = eq4 != 0 ? ((e_any & 0xFFFFu) | ((uint32_t)MCQ_C_QUADS << MCQ_KEY_SHIFT)) : 0u;
+    uint32_t key4 = 0; /* quads are rare (0.17 % of hands): looked at only when some lane of the wave has them */
+    if (mcq_any(eq4 != 0))
+        key4 = eq4 != 0 ? ((mcq_ld_u32(tops, any) & 0xFFFFu) | ((uint32_t)MCQ_C_QUADS << MCQ_KEY_SHIFT)) : 0u;
 
     uint32_t k = key1 > key2 ? key1 : key2;
     k = k > key_s ? k : key_s;
@@ -517,26 +527,27 @@ MCQ_HD void mcq_hole_put(uint32_t &h, uint32_t rb7) {
     h = mcq_bfi(0x7Fu << sh, rb7, h);
 }
 
+// Draws arrive as rp = r | 0x80 (r < 64).  Returned: base position + 128 (the caller's table pointer is biased).
 // opponent draw number J (0-based; J holes precede it, all in H[0 .. (J+3)/4))
 template <int J>
-MCQ_HD uint32_t mcq_draw_opp(uint32_t r, uint32_t (&H)[5]) {
-    uint32_t k = r;
+MCQ_HD uint32_t mcq_draw_opp(uint32_t rp, uint32_t (&H)[5]) {
+    uint32_t k = rp;
     if (J > 0) {
-        const uint32_t rb = mcq_splat_byte(r | 0x80u);
+        const uint32_t rb = mcq_splat_byte(rp);
 #pragma unroll
         for (int i = 0; i < (J + 3) / 4; i++) mcq_hole_reg(rb, H[i], k);
         mcq_hole_put<J>(H[J / 4], rb);
     } else {
-        mcq_hole_put<0>(H[0], r);
+        mcq_hole_put<0>(H[0], rp);
     }
     return mcq_opaque(k); /* materialise k so that the table address is one shift-add */
 }
 
 // table draw number K (0..4): scans the opponents' holes (n_regs registers, wave-uniform) and the K earlier table holes
 template <int K>
-MCQ_HD uint32_t mcq_draw_table(uint32_t r, uint32_t (&H)[5], uint32_t &hb, uint32_t n_regs) {
-    uint32_t k = r;
-    const uint32_t rb = mcq_splat_byte(r | 0x80u);
+MCQ_HD uint32_t mcq_draw_table(uint32_t rp, uint32_t (&H)[5], uint32_t &hb, uint32_t n_regs) {
+    uint32_t k = rp;
+    const uint32_t rb = mcq_splat_byte(rp);
 #pragma unroll
     for (int i = 0; i < 5; i++)
         if ((uint32_t)i < n_regs) mcq_hole_reg(rb, H[i], k);
@@ -549,8 +560,9 @@ MCQ_HD uint32_t mcq_draw_table(uint32_t r, uint32_t (&H)[5], uint32_t &hb, uint3
 // everything below is unrolled over the opponent number) until the table is complete: the reference deals
 // ALL opponents before any table card (montecarlo_python.py:215-217).
 template <class Draws>
-MCQ_HD void mcq_iteration(const McqQueryCtx &qc, Draws &dr, const McqCard *base, const uint32_t *tf,
-                          const uint32_t *tops, const uint32_t *sd, const uint32_t *inv, McqLaneAcc &acc) {
+// base128 = (base deck table) - 128 entries: draw indices carry a bias of 128 (r | 0x80), folded into the pointer.
+MCQ_HD void mcq_iteration(const McqQueryCtx &qc, Draws &dr, const McqCard *base128, const uint32_t *tf,
+                          const uint32_t *tops, const uint32_t *sd, McqLaneAcc &acc) {
     uint32_t H[5] = {MCQ_HOLE_SENTINEL, MCQ_HOLE_SENTINEL, MCQ_HOLE_SENTINEL, MCQ_HOLE_SENTINEL, MCQ_HOLE_SENTINEL};
     uint32_t hb = MCQ_HOLE_SENTINEL;
     uint32_t L = qc.L0;
@@ -558,9 +570,9 @@ MCQ_HD void mcq_iteration(const McqQueryCtx &qc, Draws &dr, const McqCard *base,
 #define MCQ_OPP(P)                                                                                             \
     if (P < qc.n_opp) {                                                                                        \
         uint32_t r1, r2;                                                                                       \
-        dr.pair(L, inv, r1, r2); /* r1 in [0,L-1], r2 in [0,L-2], r1 != r2 (l.167-176) */                      \
-        const McqCard c1 = base[mcq_draw_opp<2 * P>(r1, H)];     /* deck.pop(r1) (l.178) */                    \
-        const McqCard c2 = base[mcq_draw_opp<2 * P + 1>(r2, H)]; /* deck.pop(r2) on the shrunk list (l.179) */ \
+        dr.pair(L, r1, r2); /* r1 in [0,L-1], r2 in [0,L-2], r1 != r2 (l.167-176), both | 0x80 */              \
+        const McqCard c1 = base128[mcq_draw_opp<2 * P>(r1, H)];     /* deck.pop(r1) (l.178) */                 \
+        const McqCard c2 = base128[mcq_draw_opp<2 * P + 1>(r2, H)]; /* deck.pop(r2), shrunk list (l.179) */    \
         opp[P].set(c1, c2);                                                                                    \
         L -= 2;                                                                                                \
     }
@@ -570,7 +582,7 @@ MCQ_HD void mcq_iteration(const McqQueryCtx &qc, Draws &dr, const McqCard *base,
     McqBoard b = qc.board;
 #define MCQ_TABLE(K)                                                                                           \
     if (K < qc.n_deal) {                                                                                       \
-        b.add(base[mcq_draw_table<K>(dr.template table<K>(L - Draws::kTableShort), H, hb, n_regs)]); /* l.188 */ \
+        b.add(base128[mcq_draw_table<K>(dr.template table<K>(L - Draws::kTableShort), H, hb, n_regs)]); /* l.188 */ \
         L -= 1;                                                                                                \
     }
     MCQ_TABLE(0) MCQ_TABLE(1) MCQ_TABLE(2) MCQ_TABLE(3) MCQ_TABLE(4)
@@ -701,11 +713,11 @@ struct McqExtCtrDraws {
     static constexpr bool kReplay = false;
     McqXoshiro rng;
     uint32_t w;
-    MCQ_HDM void pair(uint32_t L, const uint32_t *inv, uint32_t &r1, uint32_t &r2) {
+    MCQ_HDM void pair(uint32_t L, uint32_t &r1, uint32_t &r2) { /* MCQ-CTR v3, plain indices */
         const uint32_t dd = L - 1u;
-        const uint32_t x = mcq_mulhi(rng.next(), dd * dd);
-        const uint32_t a = (x * inv[dd]) >> 20;
-        const uint32_t c = x - a * dd;
+        const uint32_t u = rng.next();
+        const uint32_t a = mcq_mulhi(u, dd);
+        const uint32_t c = mcq_mulhi(u * dd, dd);
         r1 = a == c ? dd : a;
         r2 = c;
     }
@@ -722,13 +734,13 @@ struct McqExtReplayDraws { /* accepted draws from the host, all in list.pop orde
     static constexpr bool kReplay = true;
     const uint8_t *p;
     uint64_t stride;
-    MCQ_HDM void pair(uint32_t, const uint32_t *, uint32_t &r1, uint32_t &r2) {
-        r1 = p[0];
-        r2 = p[stride];
+    MCQ_HDM void pair(uint32_t, uint32_t &r1, uint32_t &r2) {
+        r1 = p[0] & 0x7Fu; /* the host stores every draw as r | 0x80 */
+        r2 = p[stride] & 0x7Fu;
         p += 2 * stride;
     }
     MCQ_HDM uint32_t table(uint32_t, uint32_t) {
-        uint32_t v = p[0];
+        uint32_t v = p[0] & 0x7Fu;
         p += stride;
         return v;
     }
@@ -740,8 +752,7 @@ struct McqExtReplayDraws { /* accepted draws from the host, all in list.pop orde
 template <class Draws>
 MCQ_HD bool mcq_iteration_ext(const McqExtCtx &qc, Draws &dr, const McqCard *cards, const uint32_t *sel8,
                               const uint32_t *hero_set, const uint32_t *opp_set, uint32_t *ids, uint32_t ids_stride,
-                              const uint32_t *tf, const uint32_t *tops, const uint32_t *sd, const uint32_t *inv,
-                              McqLaneAcc &acc) {
+                              const uint32_t *tf, const uint32_t *tops, const uint32_t *sd, McqLaneAcc &acc) {
     uint32_t dlo = qc.deck_lo, dhi = qc.deck_hi;
     bool dealt = true;
     for (uint32_t h = 0; h < qc.n_random; h++) {
@@ -749,7 +760,7 @@ MCQ_HD bool mcq_iteration_ext(const McqExtCtx &qc, Draws &dr, const McqCard *car
         const uint32_t L = mcq_popc(dlo) + mcq_popc(dhi);
         uint32_t r1 = 0, r2 = 0, c1, c2;
         if (Draws::kReplay) {
-            dr.pair(L, inv, r1, r2);
+            dr.pair(L, r1, r2);
             c1 = mcq_select_pop(dlo, dhi, r1, sel8);
             c2 = mcq_select_pop(dlo, dhi, r2, sel8);
         } else {
@@ -758,7 +769,7 @@ MCQ_HD bool mcq_iteration_ext(const McqExtCtx &qc, Draws &dr, const McqCard *car
             c1 = c2 = 0;
             for (uint32_t trial = 0; trial < MCQ_EXT_MAX_TRIALS && !ok; trial++) {
                 acc.passes++;
-                dr.pair(L, inv, r1, r2);
+                dr.pair(L, r1, r2);
                 uint32_t tl = dlo, th = dhi;
                 c1 = mcq_select_pop(tl, th, r1, sel8); /* deck[r1] */
                 tl = dlo; th = dhi;

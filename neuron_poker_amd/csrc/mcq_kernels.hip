@@ -31,7 +31,6 @@ struct LdsTables { /* per block */
     uint32_t tops[8192];
     uint32_t sd[8192];
     uint32_t sel8[256];
-    uint32_t inv[64];
 };
 static_assert(sizeof(LdsTables) == sizeof(McqTables), "table image is copied word by word");
 
@@ -204,7 +203,7 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
                 dr.rng.seed(seed, first_qid + qi, stream);
                 const uint32_t cnt = (uint32_t)min((uint64_t)MCQ_STREAM_ITERS, (uint64_t)qc.runs - it0);
                 for (uint32_t j = 0; j < cnt; j++)
-                    mcq_iteration(qc, dr, base, tab.tf, tab.tops, tab.sd, tab.inv, acc);
+                    mcq_iteration(qc, dr, base - 128, tab.tf, tab.tops, tab.sd, acc);
                 acc.passes = cnt * qc.n_opp; /* MCQ-CTR v2: one attempt per opponent, never re-drawn */
             }
         } else {
@@ -214,7 +213,7 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
                 const uint64_t it = (uint64_t)task * MCQ_TASK_ITERS + j * MCQ_WAVE + lane;
                 if (it < qc.runs) {
                     McqReplayDraws dr = {dbase + it, stride};
-                    mcq_iteration(qc, dr, base, tab.tf, tab.tops, tab.sd, tab.inv, acc);
+                    mcq_iteration(qc, dr, base - 128, tab.tf, tab.tops, tab.sd, acc);
                 }
             }
             acc.passes = 0; /* counted by the host while parsing the MT19937 stream */
@@ -353,7 +352,7 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_ext_kernel(const mcq_query
                 const uint32_t cnt = (uint32_t)min((uint64_t)MCQ_STREAM_ITERS, (uint64_t)qc.runs - it0);
                 for (uint32_t j = 0; j < cnt && !failed; j++)
                     failed = !mcq_iteration_ext(qc, dr, cards, tab.sel8, my_sets, my_sets + 6, my_ids, kMaxBlock, tab.tf,
-                                                tab.tops, tab.sd, tab.inv, acc);
+                                                tab.tops, tab.sd, acc);
             }
         } else {
             const uint64_t stride = (qc.runs + 63u) & ~63ull;
@@ -363,7 +362,7 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_ext_kernel(const mcq_query
                 if (it < qc.runs) {
                     McqExtReplayDraws dr = {dbase + it, stride};
                     mcq_iteration_ext(qc, dr, cards, tab.sel8, my_sets, my_sets + 6, my_ids, kMaxBlock, tab.tf, tab.tops,
-                                      tab.sd, tab.inv, acc);
+                                      tab.sd, acc);
                 }
             }
             acc.passes = 0;

@@ -76,13 +76,13 @@ static inline uint64_t mcq_replay_parse_stream(const mcq_query &q, McqMt19937 &g
                 r1 = mcq_np_randint(g, L);
                 r2 = mcq_np_randint(g, L - 1);
             } while (r1 == r2);
-            p[0] = (uint8_t)r1;
-            p[stride] = (uint8_t)r2;
+            p[0] = (uint8_t)(r1 | 0x80u); /* every draw travels as r | 0x80 */
+            p[stride] = (uint8_t)(r2 | 0x80u);
             p += 2 * stride;
             L -= 2;
         }
         for (uint32_t k = 0; k < n_deal; k++) {
-            p[0] = (uint8_t)mcq_np_randint(g, L - 1);
+            p[0] = (uint8_t)(mcq_np_randint(g, L - 1) | 0x80u);
             p += stride;
             L -= 1;
         }
@@ -152,8 +152,8 @@ static inline uint64_t mcq_replay_parse_ext(const mcq_query &q, const mcq_query_
                 r2 = mcq_np_randint(g, (uint32_t)d.n - 1);
                 if (r1 != r2 && mcq_ext_in_range(e.hero_range, d.c[r1], d.c[r2])) break;
             }
-            p[0] = (uint8_t)r1;
-            p[stride] = (uint8_t)(r2 - (r2 > r1 ? 1u : 0u));
+            p[0] = (uint8_t)(r1 | 0x80u);
+            p[stride] = (uint8_t)((r2 - (r2 > r1 ? 1u : 0u)) | 0x80u);
             p += 2 * stride;
             const uint8_t a = d.c[r1], b = d.c[r2];
             d.remove(a);
@@ -173,15 +173,15 @@ static inline uint64_t mcq_replay_parse_ext(const mcq_query &q, const mcq_query_
                 r2 = mcq_np_randint(g, (uint32_t)d.n - 1);
                 if (r1 != r2 && mcq_ext_in_range(e.opp_range, d.c[r1], d.c[r2])) break;
             }
-            p[0] = (uint8_t)r1;
-            p[stride] = (uint8_t)r2;
+            p[0] = (uint8_t)(r1 | 0x80u);
+            p[stride] = (uint8_t)(r2 | 0x80u);
             p += 2 * stride;
             d.pop((int)r1);
             d.pop((int)r2);
         }
         for (uint32_t k = 0; k < n_deal; k++) {
             const uint32_t idx = mcq_np_randint(g, (uint32_t)d.n - 1);
-            p[0] = (uint8_t)idx;
+            p[0] = (uint8_t)(idx | 0x80u);
             p += stride;
             d.pop((int)idx);
         }

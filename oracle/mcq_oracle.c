@@ -85,10 +85,10 @@ static uint32_t np_randint(mt_t *s, uint32_t n) {
 }
 
 /* ------------------------------------------------------- counter-based front end (product's CTR mode) */
-/* Spec (DESIGN.md "MCQ-CTR v2"): iterations are grouped in streams of 16; stream s of query id q under
+/* Spec (DESIGN.md "MCQ-CTR v3"): iterations are grouped in streams of 16; stream s of query id q under
  * seed k starts xoshiro128++ from Philox4x32-10(counter = {q_lo, q_hi, s, 'MCQ1'}, key = {k_lo, k_hi}).
- * Opponent pair on a deck of length L, ONE word u: x = mulhi32(u, (L-1)^2), a = x / (L-1), c = x % (L-1);
- * (r1, r2) = (a, c) if a != c else (L-1, a) -- a bijection onto the pairs the reference accepts
+ * Opponent pair on a deck of length L, ONE word u, d = L-1: a = mulhi32(u, d), c = mulhi32(u * d mod 2^32, d);
+ * (r1, r2) = (a, c) if a != c else (d, a) -- a bijection onto the pairs the reference accepts
  * (r1 in [0,L), r2 in [0,L-1), r1 != r2), so they are equally likely exactly as after its re-draw loop
  * (montecarlo_python.py:167-176); no re-draw happens, so `passes` counts one attempt per opponent.
  * Table cards, two per word: even draw K: u = next(), idx = mulhi32(u, n), w = u * n (mod 2^32);
@@ -344,17 +344,16 @@ static uint32_t deal_iteration(rng_t *rng, const uint8_t hero[2], const uint8_t 
     deck_remove(&d, hero[0]); /* l.154-161 */
     deck_remove(&d, hero[1]);
     for (int p = 1; p < n_players && rng->kind == 2; p++) { /* MCQ-CTR v2, UNIFORM law */
-        uint32_t dd = (uint32_t)d.n - 1;
-        uint32_t x = (uint32_t)(((uint64_t)xo_next(rng->xo) * ((dd + 1) * dd)) >> 32);
-        uint32_t r1 = x / dd, r2 = x % dd; /* every ordered pair of distinct cards equally likely */
+        uint32_t dd = (uint32_t)d.n - 1, u = xo_next(rng->xo);
+        uint32_t r1 = (uint32_t)(((uint64_t)u * (dd + 1)) >> 32);                   /* in [0, L) */
+        uint32_t r2 = (uint32_t)(((uint64_t)(uint32_t)(u * (dd + 1)) * dd) >> 32);  /* in [0, L-1): every ordered pair */
         passes++;
         hole[p][0] = deck_pop(&d, (int)r1);
         hole[p][1] = deck_pop(&d, (int)r2);
     }
     for (int p = 1; p < n_players && rng->kind == 1; p++) { /* MCQ-CTR v2 */
-        uint32_t dd = (uint32_t)d.n - 1;
-        uint32_t x = (uint32_t)(((uint64_t)xo_next(rng->xo) * (dd * dd)) >> 32);
-        uint32_t a = x / dd, c = x % dd;
+        uint32_t dd = (uint32_t)d.n - 1, u = xo_next(rng->xo);
+        uint32_t a = (uint32_t)(((uint64_t)u * dd) >> 32), c = (uint32_t)(((uint64_t)(uint32_t)(u * dd) * dd) >> 32);
         uint32_t r1 = a != c ? a : dd, r2 = a != c ? c : a;
         passes++;
         hole[p][0] = deck_pop(&d, (int)r1);
@@ -555,9 +554,8 @@ static int draw_pair(rng_t *rng, int L, uint32_t *r1, uint32_t *r2) {
         *r2 = np_randint(rng->mt, (uint32_t)L - 1);
         return *r1 != *r2;
     }
-    uint32_t dd = (uint32_t)L - 1;
-    uint32_t x = (uint32_t)(((uint64_t)xo_next(rng->xo) * (dd * dd)) >> 32);
-    uint32_t a = x / dd, c = x % dd;
+    uint32_t dd = (uint32_t)L - 1, u = xo_next(rng->xo);
+    uint32_t a = (uint32_t)(((uint64_t)u * dd) >> 32), c = (uint32_t)(((uint64_t)(uint32_t)(u * dd) * dd) >> 32);
     *r1 = a != c ? a : dd;
     *r2 = c;
     return 1;

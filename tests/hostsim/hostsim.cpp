@@ -19,8 +19,9 @@ const McqTables &luts() {
     if (!g_init) { mcq_fill_tables(&g_tab); g_init = true; }
     return g_tab;
 }
-void make_base(const McqQueryCtx &qc, const McqTables &t, McqCard *base) {
-    for (uint32_t l = 0; l < 64; l++) base[l] = mcq_base_entry(qc, l, t.sel8);
+// the iteration takes the base-deck pointer biased by -128 entries: keep 128 unused entries in front
+void make_base(const McqQueryCtx &qc, const McqTables &t, McqCard *store) {
+    for (uint32_t l = 0; l < 64; l++) store[128 + l] = mcq_base_entry(qc, l, t.sel8);
 }
 void fold(const McqLaneAcc &a, mcq_result *r) {
     uint64_t wins = 0;
@@ -71,7 +72,7 @@ static int run_ctr_t(const mcq_query *q, uint64_t seed, uint64_t qid, mcq_result
     const McqTables &t = luts();
     McqQueryCtx qc;
     mcq_query_ctx(mcq_query_words(*q), qc);
-    McqCard base[64];
+    static thread_local McqCard base[192];
     make_base(qc, t, base);
     memset(out, 0, sizeof(*out));
     out->runs = q->runs;
@@ -83,7 +84,7 @@ static int run_ctr_t(const mcq_query *q, uint64_t seed, uint64_t qid, mcq_result
         McqLaneAcc acc = {0, 0, 0};
         for (uint32_t j = 0; j < MCQ_STREAM_ITERS; j++) {
             if ((uint64_t)s * MCQ_STREAM_ITERS + j >= q->runs) break;
-            mcq_iteration(qc, dr, base, t.tf, t.tops, t.sd, t.inv, acc);
+            mcq_iteration(qc, dr, base, t.tf, t.tops, t.sd, acc);
             acc.passes += qc.n_opp; /* MCQ-CTR v2: one attempt per opponent, never re-drawn */
         }
         fold(acc, out);
@@ -106,7 +107,7 @@ int hs_run_replay(const mcq_query *q, uint32_t seed32, mcq_result *out) {
     const McqTables &t = luts();
     McqQueryCtx qc;
     mcq_query_ctx(mcq_query_words(*q), qc);
-    McqCard base[64];
+    static thread_local McqCard base[192];
     make_base(qc, t, base);
     memset(out, 0, sizeof(*out));
     out->runs = q->runs;
@@ -116,7 +117,7 @@ int hs_run_replay(const mcq_query *q, uint32_t seed32, mcq_result *out) {
     for (uint32_t it = 0; it < q->runs; it++) {
         McqReplayDraws dr = {draws.data() + it, stride};
         McqLaneAcc acc = {0, 0, 0};
-        mcq_iteration(qc, dr, base, t.tf, t.tops, t.sd, t.inv, acc);
+        mcq_iteration(qc, dr, base, t.tf, t.tops, t.sd, acc);
         acc.passes = 0;
         fold(acc, out);
     }
@@ -129,7 +130,7 @@ int hs_run_replay_stream(const mcq_query *q, uint32_t *key, uint32_t *pos, mcq_r
     const McqTables &t = luts();
     McqQueryCtx qc;
     mcq_query_ctx(mcq_query_words(*q), qc);
-    McqCard base[64];
+    static thread_local McqCard base[192];
     make_base(qc, t, base);
     memset(out, 0, sizeof(*out));
     out->runs = q->runs;
@@ -144,7 +145,7 @@ int hs_run_replay_stream(const mcq_query *q, uint32_t *key, uint32_t *pos, mcq_r
     for (uint32_t it = 0; it < q->runs; it++) {
         McqReplayDraws dr = {draws.data() + it, stride};
         McqLaneAcc acc = {0, 0, 0};
-        mcq_iteration(qc, dr, base, t.tf, t.tops, t.sd, t.inv, acc);
+        mcq_iteration(qc, dr, base, t.tf, t.tops, t.sd, acc);
         acc.passes = 0;
         fold(acc, out);
     }
@@ -186,7 +187,7 @@ extern "C" int hs_run_ext(int replay, const mcq_query *q, const mcq_query_ext *e
         for (uint32_t it = 0; it < q->runs; it++) {
             McqExtReplayDraws dr = {draws.data() + it, stride};
             McqLaneAcc acc = {0, 0, 0};
-            mcq_iteration_ext(qc, dr, cards, t.sel8, ew.w + 8, ew.w + 2, ids, 1, t.tf, t.tops, t.sd, t.inv, acc);
+            mcq_iteration_ext(qc, dr, cards, t.sel8, ew.w + 8, ew.w + 2, ids, 1, t.tf, t.tops, t.sd, acc);
             acc.passes = 0;
             fold(acc, out);
         }
@@ -200,7 +201,7 @@ extern "C" int hs_run_ext(int replay, const mcq_query *q, const mcq_query_ext *e
         McqLaneAcc acc = {0, 0, 0};
         for (uint32_t j = 0; j < MCQ_STREAM_ITERS; j++) {
             if ((uint64_t)s * MCQ_STREAM_ITERS + j >= q->runs) break;
-            if (!mcq_iteration_ext(qc, dr, cards, t.sel8, ew.w + 8, ew.w + 2, ids, 1, t.tf, t.tops, t.sd, t.inv, acc))
+            if (!mcq_iteration_ext(qc, dr, cards, t.sel8, ew.w + 8, ew.w + 2, ids, 1, t.tf, t.tops, t.sd, acc))
                 return MCQ_EINVAL;
         }
         fold(acc, out);
@@ -208,10 +209,3 @@ extern "C" int hs_run_ext(int replay, const mcq_query *q, const mcq_query_ext *e
     return MCQ_OK;
 }
 
-extern "C" int hs_check_inv(void) { /* (x * inv[d]) >> 20 == x / d for every x < d * d, d in [1, 51] */
-    const McqTables &t = luts();
-    for (uint32_t d = 1; d <= 51; d++)
-        for (uint32_t x = 0; x < (d + 1) * d; x++)
-            if (((x * t.inv[d]) >> 20) != x / d) return (int)(d * 10000 + x);
-    return 0;
-}
