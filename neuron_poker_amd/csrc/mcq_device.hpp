@@ -31,7 +31,7 @@
 #define MCQ_HDM inline
 #endif
 
-#define MCQ_STREAM_ITERS 16u /* iterations per RNG stream (MCQ-CTR v2) */
+#define MCQ_STREAM_ITERS 16u /* iterations per RNG stream (MCQ-CTR v3) */
 #define MCQ_WAVE 64u
 #define MCQ_TASK_ITERS (MCQ_STREAM_ITERS * MCQ_WAVE) /* iterations per wave task */
 #define MCQ_MAX_OPP 9
@@ -167,7 +167,7 @@ static inline void mcq_fill_tables(McqTables *t) {
     }
 }
 
-// ------------------------------------------------------------------------------------------ RNG: MCQ-CTR v2
+// ------------------------------------------------------------------------------------------ RNG: MCQ-CTR v3
 MCQ_HD void mcq_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                               uint32_t out[4]) {
 #pragma unroll

@@ -142,8 +142,8 @@ typedef struct {
 } rng_t;
 
 static uint32_t draw(rng_t *r, uint32_t n) { return r->kind == 0 ? np_randint(r->mt, n) : xo_draw(r->xo, n); }
-/* kind: 0 = MT19937 + numpy randint (the reference), 1 = MCQ-CTR v2 with the reference's dealing law,
- * 2 = MCQ-CTR v2 with the UNIFORM law (what montecarlo_cython.pyx:188 and Montecarlo.cpp:296-312 intend) */
+/* kind: 0 = MT19937 + numpy randint (the reference), 1 = MCQ-CTR v3 with the reference's dealing law,
+ * 2 = MCQ-CTR v3 with the UNIFORM law (what montecarlo_cython.pyx:188 and Montecarlo.cpp:296-312 intend) */
 
 /* ------------------------------------------------------------------------------------------ evaluator */
 enum { T_HIGH, T_PAIR, T_TWOPAIR, T_TRIPS, T_STRAIGHT, T_FLUSH, T_FULL, T_QUADS, T_SF };
@@ -343,7 +343,7 @@ static uint32_t deal_iteration(rng_t *rng, const uint8_t hero[2], const uint8_t 
     hole[0][0] = hero[0]; hole[0][1] = hero[1];
     deck_remove(&d, hero[0]); /* l.154-161 */
     deck_remove(&d, hero[1]);
-    for (int p = 1; p < n_players && rng->kind == 2; p++) { /* MCQ-CTR v2, UNIFORM law */
+    for (int p = 1; p < n_players && rng->kind == 2; p++) { /* MCQ-CTR v3, UNIFORM law */
         uint32_t dd = (uint32_t)d.n - 1, u = xo_next(rng->xo);
         uint32_t r1 = (uint32_t)(((uint64_t)u * (dd + 1)) >> 32);                   /* in [0, L) */
         uint32_t r2 = (uint32_t)(((uint64_t)(uint32_t)(u * (dd + 1)) * dd) >> 32);  /* in [0, L-1): every ordered pair */
@@ -351,7 +351,7 @@ static uint32_t deal_iteration(rng_t *rng, const uint8_t hero[2], const uint8_t 
         hole[p][0] = deck_pop(&d, (int)r1);
         hole[p][1] = deck_pop(&d, (int)r2);
     }
-    for (int p = 1; p < n_players && rng->kind == 1; p++) { /* MCQ-CTR v2 */
+    for (int p = 1; p < n_players && rng->kind == 1; p++) { /* MCQ-CTR v3 */
         uint32_t dd = (uint32_t)d.n - 1, u = xo_next(rng->xo);
         uint32_t a = (uint32_t)(((uint64_t)u * dd) >> 32), c = (uint32_t)(((uint64_t)(uint32_t)(u * dd) * dd) >> 32);
         uint32_t r1 = a != c ? a : dd, r2 = a != c ? c : a;
