@@ -460,7 +460,7 @@ int mcqo_compare(const uint8_t *a, const uint8_t *b) {
 
 int mcqo_best_hand(const uint8_t *hands, int n, int *type, int *tie) { return best_hand(hands, n, type, tie); }
 
-/* mode 0: np.random.seed((uint32)seed) then the reference loop; mode 1: MCQ-CTR v1 with query id qid.
+/* mode 0: np.random.seed((uint32)seed) then the reference loop; mode 1: MCQ-CTR v3 with query id qid.
  * trace (optional): first `keep` iterations' hands [keep][n_players][7]; words (optional, mode 0): MT words
  * per kept iteration; total_words (optional). Returns 0, or -1 on invalid input. */
 int mcqo_run(int mode, const uint8_t *hero, const uint8_t *board, int nb, int n_players, uint32_t runs,
