@@ -8,6 +8,8 @@
 #include <string.h>
 
 #include <atomic>
+#include <exception>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -31,11 +33,21 @@ int fail(int code, const char *what, const char *detail = nullptr) {
     return code;
 }
 
-#define HIP_TRY(expr)                                                        \
-    do {                                                                     \
-        hipError_t e_ = (expr);                                              \
-        if (e_ != hipSuccess) return fail(MCQ_EDEVICE, #expr, hipGetErrorString(e_)); \
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return fail(e_ == hipErrorOutOfMemory ? MCQ_ENOMEM : MCQ_EDEVICE, #expr, hipGetErrorString(e_)); \
     } while (0)
+
+/* No C++ exception may cross the C ABI (std::bad_alloc from the staging vectors, std::system_error from thread
+ * creation): every entry point body runs inside this guard. */
+#define ABI_GUARD_BEGIN try {
+#define ABI_GUARD_END(who)                                                     \
+    }                                                                          \
+    catch (const std::bad_alloc &) { return fail(MCQ_ENOMEM, who, "out of host memory"); } \
+    catch (const std::exception &ex) { return fail(MCQ_EDEVICE, who, ex.what()); }          \
+    catch (...) { return fail(MCQ_EDEVICE, who, "unexpected exception"); }
 
 struct DevBuf {
     void *p = nullptr;
@@ -354,6 +366,7 @@ float mcq_last_kernel_ms(mcq_ctx *c) {
 
 int mcq_eval_batch_device(mcq_ctx *c, const void *d_queries, size_t n, uint64_t seed, uint64_t first_query_id,
                           void *d_results, void *hip_stream) {
+    ABI_GUARD_BEGIN
     if (!c) return fail(MCQ_EINVAL, "mcq_eval_batch_device: null context");
     if (n == 0) return MCQ_OK;
     if (!d_queries || !d_results) return fail(MCQ_EINVAL, "mcq_eval_batch_device: null buffer");
@@ -364,10 +377,12 @@ int mcq_eval_batch_device(mcq_ctx *c, const void *d_queries, size_t n, uint64_t 
     c->last_ms = 0.f;
     return run_slice(c, MCQ_MODE_PHILOX, (const mcq_query *)d_queries, (uint32_t)n, (mcq_result *)d_results, seed,
                      first_query_id, 0, nullptr, nullptr, s, true);
+    ABI_GUARD_END("mcq_eval_batch_device")
 }
 
 int mcq_eval_batch(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed, uint64_t first_query_id, int mode,
                    mcq_result *out) {
+    ABI_GUARD_BEGIN
     if (mode != MCQ_MODE_PHILOX && mode != MCQ_MODE_REPLAY_MT19937) return fail(MCQ_EINVAL, "mcq_eval_batch: bad mode");
     if (n == 0) return MCQ_OK;
     int rc = stage_queries(c, q, n, out, "mcq_eval_batch");
@@ -387,6 +402,7 @@ int mcq_eval_batch(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed, uint
     }
 
     return replay_batch(c, q, n, seed, first_query_id, nullptr, out);
+    ABI_GUARD_END("mcq_eval_batch")
 }
 
 int mcq_eval_one(mcq_ctx *c, const mcq_query *q, uint64_t seed, int mode, mcq_result *out) {
@@ -395,6 +411,7 @@ int mcq_eval_one(mcq_ctx *c, const mcq_query *q, uint64_t seed, int mode, mcq_re
 
 int mcq_eval_batch_ext(mcq_ctx *c, const mcq_query *q, const mcq_query_ext *ext, size_t n, uint64_t seed,
                        uint64_t first_query_id, int mode, mcq_result *out) {
+    ABI_GUARD_BEGIN
     if (mode != MCQ_MODE_PHILOX && mode != MCQ_MODE_REPLAY_MT19937) return fail(MCQ_EINVAL, "mcq_eval_batch_ext: bad mode");
     if (n == 0) return MCQ_OK;
     if (!c) return fail(MCQ_EINVAL, "mcq_eval_batch_ext: null context");
@@ -483,10 +500,12 @@ int mcq_eval_batch_ext(mcq_ctx *c, const mcq_query *q, const mcq_query_ext *ext,
     if (mode == MCQ_MODE_REPLAY_MT19937)
         for (size_t i = 0; i < n; i++) out[i].passes = passes[i];
     return MCQ_OK;
+    ABI_GUARD_END("mcq_eval_batch_ext")
 }
 
 int mcq_eval_batch_numpy_stream(mcq_ctx *c, const mcq_query *q, size_t n, uint32_t *mt_key, uint32_t *mt_pos,
                                 mcq_result *out) {
+    ABI_GUARD_BEGIN
     if (n == 0) return MCQ_OK;
     if (!mt_key || !mt_pos || *mt_pos > 624) return fail(MCQ_EINVAL, "mcq_eval_batch_numpy_stream: bad MT19937 state");
     int rc = stage_queries(c, q, n, out, "mcq_eval_batch_numpy_stream");
@@ -499,10 +518,12 @@ int mcq_eval_batch_numpy_stream(mcq_ctx *c, const mcq_query *q, size_t n, uint32
     memcpy(mt_key, g.mt, sizeof g.mt);
     *mt_pos = g.pos;
     return MCQ_OK;
+    ABI_GUARD_END("mcq_eval_batch_numpy_stream")
 }
 
 int mcq_showdown(mcq_ctx *c, const uint8_t *hands, size_t n_tables, int n_players, uint8_t *winner,
                  uint8_t *winner_type, uint32_t *keys) {
+    ABI_GUARD_BEGIN
     if (!c) return fail(MCQ_EINVAL, "mcq_showdown: null context");
     if (n_tables == 0) return MCQ_OK;
     if (!hands || !winner || !winner_type) return fail(MCQ_EINVAL, "mcq_showdown: null buffer");
@@ -537,6 +558,7 @@ int mcq_showdown(mcq_ctx *c, const uint8_t *hands, size_t n_tables, int n_player
     memcpy(winner_type, ht, n_tables);
     if (keys) HIP_TRY(hipMemcpy(keys, c->d_keys.p, nh * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return MCQ_OK;
+    ABI_GUARD_END("mcq_showdown")
 }
 
 }  // extern "C"

@@ -69,7 +69,7 @@ class _Cycle:
         self.steps_for_blind_betting = 2
         self.idx = 0
         self.dealer_idx = -1                                     # env.py:161
-        self.alive = np.ones(n, bool)
+        self.alive = [True] * n
         self.max_raises = max_raises
         self.checkers = 0
         self.max_remaining_steps_without_raising = n
@@ -91,10 +91,13 @@ class _Cycle:
         self.last_raiser = None
 
     def update_alive(self):                                      # cycle.py:155-158
-        self.alive = np.array(self.can_move) | np.array(self.out_of_cash)
+        self.alive = [a or b for a, b in zip(self.can_move, self.out_of_cash)]
+
+    def n_alive(self):
+        return sum(self.alive)
 
     def next_player(self):                                       # cycle.py:58-101; None = the round is over
-        if int((np.array(self.can_move) | np.array(self.out_of_cash)).sum()) < 2:
+        if sum(1 for a, b in zip(self.can_move, self.out_of_cash) if a or b) < 2:
             return None
         self.idx += 1
         self.step_counter += 1
@@ -109,7 +112,7 @@ class _Cycle:
         elif self.max_steps_after_raiser and \
                 self.step_counter > self.max_steps_after_big_blind + self.steps_for_blind_betting:
             return None
-        if self.checkers == int(np.sum(self.alive)):
+        if self.checkers == sum(self.alive):
             return None
         while not self.can_move[self.idx]:
             self.idx += 1
@@ -136,7 +139,7 @@ class _Cycle:
         self.max_steps_total = self.step_counter + self.n * self.max_raises + 2
 
     def potential_winners(self):                                 # cycle.py:160-167
-        return (np.array(self.can_move) | np.array(self.out_of_cash)) & ~np.array(self.folder)
+        return [(a or b) and not f for a, b, f in zip(self.can_move, self.out_of_cash, self.folder)]
 
 
 class TableSim:
@@ -201,7 +204,7 @@ class TableSim:
             self.current = self.winner_ix
         self.queries += 1
         hole = list(self.cards[self.current])
-        alive = int(np.sum(self.cycle.alive))
+        alive = self.cycle.n_alive()
         equity = yield (hole, list(self.table_cards), alive)
         if self.log is not None:
             self.log.append(["q", sorted(hole), sorted(self.table_cards), alive, 1000, equity])
@@ -262,7 +265,7 @@ class TableSim:
     def _next_player(self):                                      # env.py:611-628
         self.current = self.cycle.next_player()
         if self.current is None:
-            if int(np.sum(self.cycle.alive)) < 2:
+            if self.cycle.n_alive() < 2:
                 self.stage = END_HIDDEN
             else:
                 self._end_round()
