@@ -219,7 +219,7 @@ def main():
                      "hbm": {"algorithmic_bytes_per_launch": B * 120,
                              "achieved_GBps": B * 120 / (kernel_ms * 1e-3) / 1e9, "peak_GBps": HBM_PEAK_GBPS}},
     }
-    if not args.no_extras:
+    if world == 1 and not args.no_extras:  # single-GPU side measurements; never delay the other ranks' teardown
         extras = {}
         # BASELINE configs[1]: single query AhKh heads-up 100k iterations (latency-bound: 98 wave tasks)
         q1 = npa.pack_queries([[npa.card_id("AH"), npa.card_id("KH")]], [[255] * 5], 2, 100000)
