@@ -463,11 +463,12 @@ MCQ_HD void mcq_query_ctx(const McqQueryWords &q, McqQueryCtx &c) {
     c.runs = q.runs();
 }
 
-// Scheduling weight of one wave task of a query (~ VALU instructions per iteration, measured): used only to cut
-// the task list into equally expensive contiguous slices, never for results.
+// Scheduling weight of one wave task of a query, in units of 0.01 ns of measured kernel time per task
+// (tools/weights_probe.py on MI355X: fit within 6 % over n_players 1..10, n_board 0/3/4/5).  Used only to cut the
+// task list into equally expensive contiguous slices, never for results.
 MCQ_HD uint32_t mcq_task_weight(const McqQueryWords &q) {
     const uint32_t n = q.n_players(), deal = 5u - q.n_board();
-    return 45u * n + 65u * (n - 1u) + 40u * deal + 60u;
+    return 160u + 200u * n + 10u * n * n + deal * (162u - 9u * n);
 }
 MCQ_HD uint32_t mcq_task_count(const McqQueryWords &q) { /* no overflow for runs up to 2^32 - 1 */
     return q.runs() / MCQ_TASK_ITERS + (q.runs() % MCQ_TASK_ITERS != 0u ? 1u : 0u);
