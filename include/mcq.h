@@ -152,6 +152,41 @@ MCQ_API int mcq_set_dealing_law(mcq_ctx *ctx, int law);
 MCQ_API int mcq_kernel_times(mcq_ctx *ctx, float *ms, int max_n);
 MCQ_API float mcq_last_kernel_ms(mcq_ctx *ctx);
 
+/* ---- Lock-step table driver (BASELINE configs[4]; replaces the loop gym_env/env.py:170-200 + 224-262 runs per
+ * table: observe -> get_equity -> agent -> step).  T tables of n_seats seats play No-Limit Hold'em with the
+ * reference's table rules (gym_env/env.py, gym_env/cycle.py); every table always has exactly one pending equity
+ * query, finished episodes restart at once.  mcq_tables_begin writes the n_tables pending queries (table i ->
+ * q[i]) and returns n_tables; mcq_tables_resume takes their equities ((win + tie) / runs) and advances every
+ * table to its next query.  mcq_tables_run does `lock_steps` rounds of begin -> ONE mcq_eval_batch
+ * (MCQ_MODE_PHILOX, seed cfg.seed, query ids counting up across calls) -> resume, and needs a context.
+ * begin/resume alone need no GPU (ctx may be NULL): that is how the CPU tests pin the rules.
+ * seat_kind: 0 = equity agent (agents/agent_consider_equity.py:25-56 with min_call_equity / min_bet_equity of
+ * the seat), 1 = random agent (agents/agent_random.py:21-29, drawing from the table's own generator).
+ * Dealing and random seats draw from one xoshiro128++ per table, seeded by Philox4x32-10(counter = {table, 0, 0,
+ * 'TBL1'}, key = seed); a bounded draw is mulhi32(next(), bound). */
+typedef struct mcq_tables mcq_tables;
+typedef struct mcq_tables_config {
+    uint32_t n_tables, n_seats;     /* 2..10 seats */
+    uint32_t runs;                  /* iterations per equity query (the reference uses 1000, env.py:261) */
+    uint32_t max_raises;            /* per seat and street (env.py:92: 2) */
+    double initial_stacks, small_blind, big_blind;
+    uint64_t seed;
+    uint8_t seat_kind[10];
+    uint8_t reserved[6];
+    double min_call_equity[10], min_bet_equity[10];
+} mcq_tables_config;
+
+MCQ_API mcq_tables *mcq_tables_create(mcq_ctx *ctx, const mcq_tables_config *cfg); /* NULL + mcq_last_error */
+MCQ_API void mcq_tables_destroy(mcq_tables *t);
+MCQ_API size_t mcq_tables_begin(mcq_tables *t, mcq_query *q);
+MCQ_API int mcq_tables_resume(mcq_tables *t, const double *equity);
+MCQ_API int mcq_tables_run(mcq_tables *t, uint32_t lock_steps, uint64_t stats[3]);
+/* stats: agent actions executed (env steps), equity queries issued, episodes finished -- totals since create */
+MCQ_API void mcq_tables_stats(const mcq_tables *t, uint64_t stats[3]);
+/* one table: stacks[n_seats]; info[8] = stage, seat to act, last winner, episodes, env steps, queries,
+ * legal-move bit mask (bit = gym_env/enums.py Action value), driver phase */
+MCQ_API int mcq_tables_state(const mcq_tables *t, uint32_t table, double *stacks, int32_t info[8]);
+
 MCQ_API const char *mcq_last_error(void);
 MCQ_API void mcq_version(int *major, int *minor, int *patch);
 

@@ -21,6 +21,11 @@ RESULT_DTYPE = np.dtype([("runs", "<u8"), ("passes", "<u8"), ("win", "<u8"), ("t
                          ("by_type", "<u8", (9,))])
 QUERY_EXT_DTYPE = np.dtype([("ghost", "u1", (2,)), ("known2", "u1", (2,)), ("hero_is_range", "u1"), ("reserved", "u1", (3,)),
                             ("opp_range", "<u4", (6,)), ("hero_range", "<u4", (6,)), ("pad", "<u4", (2,))])
+TABLES_CONFIG_DTYPE = np.dtype([("n_tables", "<u4"), ("n_seats", "<u4"), ("runs", "<u4"), ("max_raises", "<u4"),
+                                ("initial_stacks", "<f8"), ("small_blind", "<f8"), ("big_blind", "<f8"),
+                                ("seed", "<u8"), ("seat_kind", "u1", (10,)), ("reserved", "u1", (6,)),
+                                ("min_call_equity", "<f8", (10,)), ("min_bet_equity", "<f8", (10,))])
+assert TABLES_CONFIG_DTYPE.itemsize == 224
 assert QUERY_DTYPE.itemsize == 16 and RESULT_DTYPE.itemsize == 104 and QUERY_EXT_DTYPE.itemsize == 64
 ALL_CLASSES = np.array([0xFFFFFFFF] * 5 + [0x1FF], np.uint32)  # 169 bits
 
@@ -93,6 +98,20 @@ def load_library():
         L.mcq_kernel_times.restype = C.c_int
         L.mcq_last_kernel_ms.argtypes = [vp]
         L.mcq_last_kernel_ms.restype = C.c_float
+        L.mcq_tables_create.argtypes = [vp, vp]
+        L.mcq_tables_create.restype = vp
+        L.mcq_tables_destroy.argtypes = [vp]
+        L.mcq_tables_destroy.restype = None
+        L.mcq_tables_begin.argtypes = [vp, vp]
+        L.mcq_tables_begin.restype = sz
+        L.mcq_tables_resume.argtypes = [vp, vp]
+        L.mcq_tables_resume.restype = C.c_int
+        L.mcq_tables_run.argtypes = [vp, C.c_uint32, vp]
+        L.mcq_tables_run.restype = C.c_int
+        L.mcq_tables_stats.argtypes = [vp, vp]
+        L.mcq_tables_stats.restype = None
+        L.mcq_tables_state.argtypes = [vp, C.c_uint32, vp, vp]
+        L.mcq_tables_state.restype = C.c_int
         L.mcq_last_error.argtypes = []
         L.mcq_last_error.restype = C.c_char_p
         L.mcq_version.argtypes = [C.POINTER(C.c_int)] * 3
@@ -277,6 +296,84 @@ class Engine:
     @property
     def last_kernel_ms(self):
         return float(self._lib.mcq_last_kernel_ms(self._ctx))
+
+
+class Tables:
+    """mcq_tables: T Hold'em tables advanced in lock-step by the native driver (include/mcq.h, BASELINE configs[4]).
+
+    seats: one entry per seat -- ("equity", min_call_equity, min_bet_equity) or ("random",).
+    engine=None gives a driver without GPU: only begin()/resume() work (used to pin the rules on the CPU)."""
+
+    def __init__(self, engine, n_tables, seats, runs=1000, initial_stacks=100, small_blind=1, big_blind=2,
+                 max_raises=2, seed=0):
+        self._lib = load_library()
+        self._engine = engine
+        cfg = np.zeros(1, TABLES_CONFIG_DTYPE)
+        cfg["n_tables"], cfg["n_seats"], cfg["runs"], cfg["max_raises"] = n_tables, len(seats), runs, max_raises
+        cfg["initial_stacks"], cfg["small_blind"], cfg["big_blind"] = initial_stacks, small_blind, big_blind
+        cfg["seed"] = int(seed) & (2 ** 64 - 1)
+        if len(seats) > 10:
+            raise ValueError("at most 10 seats")
+        for i, s in enumerate(seats):
+            if s[0] == "equity":
+                cfg["min_call_equity"][0, i], cfg["min_bet_equity"][0, i] = s[1], s[2]
+            elif s[0] == "random":
+                cfg["seat_kind"][0, i] = 1
+            else:
+                raise ValueError("seat kind must be 'equity' or 'random'")
+        self.n_tables, self.n_seats = int(n_tables), len(seats)
+        self._t = self._lib.mcq_tables_create(engine._ctx if engine is not None else None, cfg.ctypes.data)
+        if not self._t:
+            raise ValueError((self._lib.mcq_last_error() or b"").decode("utf-8", "replace"))
+
+    def close(self):
+        if getattr(self, "_t", None):
+            self._lib.mcq_tables_destroy(self._t)
+            self._t = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def begin(self):
+        """-> the pending query of every table (QUERY_DTYPE[n_tables])."""
+        q = np.zeros(self.n_tables, QUERY_DTYPE)
+        self._lib.mcq_tables_begin(self._t, q.ctypes.data)
+        return q
+
+    def resume(self, equity):
+        e = np.ascontiguousarray(equity, np.float64)
+        if e.shape != (self.n_tables,):
+            raise ValueError("one equity per table")
+        rc = self._lib.mcq_tables_resume(self._t, e.ctypes.data)
+        if rc:
+            _raise(rc)
+
+    def run(self, lock_steps):
+        """lock_steps rounds of (queries of all tables -> ONE GPU batch -> every table acts).  -> stats()."""
+        st = np.zeros(3, np.uint64)
+        rc = self._lib.mcq_tables_run(self._t, int(lock_steps), st.ctypes.data)
+        if rc:
+            _raise(rc)
+        return {"env_steps": int(st[0]), "queries": int(st[1]), "episodes": int(st[2])}
+
+    def stats(self):
+        st = np.zeros(3, np.uint64)
+        self._lib.mcq_tables_stats(self._t, st.ctypes.data)
+        return {"env_steps": int(st[0]), "queries": int(st[1]), "episodes": int(st[2])}
+
+    def state(self, table):
+        stacks = np.zeros(self.n_seats, np.float64)
+        info = np.zeros(8, np.int32)
+        rc = self._lib.mcq_tables_state(self._t, int(table), stacks.ctypes.data, info.ctypes.data)
+        if rc:
+            _raise(rc)
+        keys = ["stage", "current", "winner", "episodes", "env_steps", "queries", "legal", "phase"]
+        d = dict(zip(keys, (int(x) for x in info)))
+        d["stacks"] = stacks
+        return d
 
 
 _default = None

@@ -261,6 +261,8 @@ extern "C" {
 
 const char *mcq_last_error(void) { return g_err.c_str(); }
 
+int mcq_tables_set_error(const char *msg) { return fail(MCQ_EINVAL, msg); } /* for mcq_tables.cpp; not exported */
+
 void mcq_version(int *major, int *minor, int *patch) {
     if (major) *major = MCQ_VERSION_MAJOR;
     if (minor) *minor = MCQ_VERSION_MINOR;

@@ -1,0 +1,502 @@
+// mcq_tables.cpp -- native lock-step driver for many Hold'em tables on the GPU equity (BASELINE configs[4]).
+//
+// The same table rules as neuron_poker_amd/table_driver.py (which is pinned, event by event, to seeded episodes
+// of the reference's own gym_env/env.py + gym_env/cycle.py), as an explicit state machine per table instead of a
+// Python generator: every table always has ONE pending equity query; mcq_tables_begin() collects them,
+// mcq_tables_resume() feeds the equities back and advances every table to its next query (finished episodes
+// restart at once).  mcq_tables_run() = begin -> mcq_eval_batch (ONE call per lock-step) -> resume.
+// tests/test_table_driver.py drives begin/resume with a deterministic equity function and checks that every
+// table follows the Python driver step by step (same per-table xoshiro128++ stream for dealing and for the
+// random seats).
+//
+// Reference lines (paths relative to /root/reference): gym_env/env.py:138-688, gym_env/cycle.py:10-167,
+// agents/agent_consider_equity.py:25-56, agents/agent_random.py:21-29; showdowns use this library's own
+// evaluator (mcq_eval_key compiled for the host) = tools/hand_evaluator.py:9-24.
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "mcq_device.hpp"
+
+namespace {
+
+enum { FOLD, CHECK, CALL, RAISE_3BB, RAISE_HALF_POT, RAISE_POT, RAISE_2POT, ALL_IN, SMALL_BLIND, BIG_BLIND };
+enum { PREFLOP, FLOP, TURN, RIVER, END_HIDDEN, SHOWDOWN };
+enum { PH_FIRST, PH_A, PH_B };
+constexpr int kMaxSeats = 10;
+
+const McqTables &host_tables() {
+    static McqTables *t = [] {
+        McqTables *p = new McqTables();
+        mcq_fill_tables(p);
+        return p;
+    }();
+    return *t;
+}
+
+uint32_t hand_key(const uint8_t *hole, const uint8_t *table5) {
+    const McqTables &t = host_tables();
+    McqBoard b;
+    b.clear();
+    for (int k = 0; k < 5; k++) b.add(mcq_card(table5[k]));
+    McqHole h;
+    h.set(mcq_card(hole[0]), mcq_card(hole[1]));
+    McqFlushSel fs;
+    fs.from_board(b);
+    return mcq_eval_key(b, fs, h, t.tf, t.tops, t.sd);
+}
+
+struct Table {
+    // configuration (shared values copied for locality)
+    int n;
+    double initial_stacks, small_blind, big_blind;
+    int max_raises;
+    const uint8_t *seat_kind;
+    const double *min_call_eq, *min_bet_eq;
+    McqXoshiro rng;
+
+    // cycle (gym_env/cycle.py)
+    int idx, dealer_idx, step_counter, max_steps_total, max_steps_after_raiser, max_steps_after_big_blind;
+    int last_raiser, checkers, max_remaining_steps_without_raising;
+    bool can_move[kMaxSeats], out_of_cash[kMaxSeats], folder[kMaxSeats], alive[kMaxSeats];
+
+    // table (gym_env/env.py)
+    double stacks[kMaxSeats], player_pots[kMaxSeats], player_max_win[kMaxSeats];
+    double community_pot, current_round_pot, min_call;
+    int num_raises[kMaxSeats][4];
+    uint8_t cards[kMaxSeats][2];
+    int n_cards[kMaxSeats];
+    uint8_t table_cards[5];
+    int n_table;
+    uint8_t deck[52];
+    int n_deck;
+    int stage, current, winner_ix;
+    bool done;
+    uint32_t legal; /* bit mask over actions */
+    int phase;
+    // statistics
+    uint64_t env_steps, queries, episodes;
+    uint64_t ep_env_steps, ep_queries; /* of the running episode */
+
+    uint32_t draw(uint32_t bound) { return mcq_mulhi(rng.next(), bound); }
+
+    int n_alive() const {
+        int s = 0;
+        for (int i = 0; i < n; i++) s += alive[i];
+        return s;
+    }
+    void update_alive() {
+        for (int i = 0; i < n; i++) alive[i] = can_move[i] || out_of_cash[i];
+    }
+
+    // ---- cycle.py
+    void new_hand_reset() {
+        idx = 0;
+        for (int i = 0; i < n; i++) { can_move[i] = true; out_of_cash[i] = false; folder[i] = false; }
+        step_counter = 0;
+    }
+    void new_street_reset() {
+        step_counter = 0;
+        idx = dealer_idx;
+        checkers = 0;
+        max_remaining_steps_without_raising = n - 1;
+        last_raiser = 0;
+    }
+    int next_player() { /* -1 = the round is over (cycle.py:58-101) */
+        int movers = 0;
+        for (int i = 0; i < n; i++) movers += can_move[i] || out_of_cash[i];
+        if (movers < 2) return -1;
+        idx += 1;
+        step_counter += 1;
+        idx %= n;
+        if (max_steps_total && step_counter > max_steps_total) return -1;
+        if (last_raiser) {
+            if (step_counter > last_raiser + max_remaining_steps_without_raising) return -1;
+            if (max_steps_after_raiser && step_counter > max_steps_after_raiser + last_raiser) return -1;
+        } else if (max_steps_after_raiser && step_counter > max_steps_after_big_blind + 2) {
+            return -1;
+        }
+        if (checkers == n_alive()) return -1;
+        while (!can_move[idx]) {
+            idx += 1;
+            step_counter += 1;
+            idx %= n;
+            if (max_steps_total && step_counter >= max_steps_total) return -1;
+        }
+        update_alive();
+        return idx;
+    }
+    void next_dealer() {
+        dealer_idx = ((dealer_idx + 1) % n + n) % n;
+        while (!can_move[dealer_idx]) dealer_idx = (dealer_idx + 1) % n;
+    }
+
+    // ---- env.py
+    uint8_t deck_pop(int i) {
+        uint8_t v = deck[i];
+        memmove(deck + i, deck + i + 1, (size_t)(n_deck - i - 1));
+        n_deck--;
+        return v;
+    }
+    void reset_episode() { /* env.py:138-168 */
+        done = false;
+        for (int i = 0; i < n; i++) {
+            stacks[i] = initial_stacks;
+            n_cards[i] = 0;
+            player_pots[i] = player_max_win[i] = 0;
+            alive[i] = true;
+            for (int s = 0; s < 4; s++) num_raises[i][s] = 0;
+        }
+        n_table = 0;
+        stage = PREFLOP;
+        winner_ix = -1;
+        current = -1;
+        community_pot = 0;
+        current_round_pot = 9;
+        min_call = 0;
+        legal = 0;
+        max_steps_total = 0;
+        max_steps_after_raiser = (max_raises - 1) * n - 1;
+        max_steps_after_big_blind = n;
+        last_raiser = 0;
+        step_counter = 0;
+        idx = 0;
+        dealer_idx = -1;
+        checkers = 0;
+        max_remaining_steps_without_raising = n;
+        new_hand_reset();
+        ep_env_steps = ep_queries = 0;
+        start_new_hand();
+        phase = PH_FIRST;
+    }
+    bool check_game_over() {
+        new_hand_reset();
+        int live = 0;
+        for (int s = 0; s < n; s++) {
+            if (stacks[s] > 0) live++;
+            else can_move[s] = false;
+        }
+        if (live < 2 || stacks[0] == 0) { done = true; return true; }
+        return false;
+    }
+    void start_new_hand() {
+        for (int i = 0; i < n; i++)
+            for (int s = 0; s < 4; s++) num_raises[i][s] = 0;
+        if (check_game_over()) return;
+        n_table = 0;
+        for (int i = 0; i < 52; i++) deck[i] = (uint8_t)i;
+        n_deck = 52;
+        stage = PREFLOP;
+        community_pot = 0;
+        current_round_pot = 0;
+        for (int i = 0; i < n; i++) { player_pots[i] = player_max_win[i] = 0; n_cards[i] = 0; }
+        next_dealer();
+        for (int s = 0; s < n; s++) {
+            if (stacks[s] <= 0) continue;
+            for (int k = 0; k < 2; k++) cards[s][n_cards[s]++] = deck_pop((int)draw((uint32_t)n_deck));
+        }
+        initiate_round();
+    }
+    void initiate_round() {
+        min_call = 0;
+        new_street_reset();
+        if (stage != PREFLOP && n == 2) idx += 1;
+        if (stage == PREFLOP) {
+            max_steps_total = n * max_raises + 2;
+            go_next_player();
+            process_decision(SMALL_BLIND);
+            go_next_player();
+            process_decision(BIG_BLIND);
+            go_next_player();
+        } else if (stage == FLOP || stage == TURN || stage == RIVER) {
+            max_steps_total = n * max_raises;
+            go_next_player();
+        }
+    }
+    void go_next_player() {
+        current = next_player();
+        if (current < 0) {
+            if (n_alive() < 2) stage = END_HIDDEN;
+            else {
+                end_round();
+                initiate_round();
+            }
+        }
+    }
+    void clean_up_pots() {
+        community_pot += current_round_pot;
+        current_round_pot = 0;
+        for (int i = 0; i < n; i++) player_pots[i] = 0;
+    }
+    void deal_table(int k) {
+        for (int i = 0; i < k; i++) table_cards[n_table++] = deck_pop((int)draw((uint32_t)n_deck));
+    }
+    void end_round() {
+        double s = 0;
+        for (int i = 0; i < n; i++) { s += player_pots[i]; player_pots[i] = 0; }
+        community_pot += s;
+        if (stage == PREFLOP) { stage = FLOP; deal_table(3); }
+        else if (stage == FLOP) { stage = TURN; deal_table(1); }
+        else if (stage == TURN) { stage = RIVER; deal_table(1); }
+        else if (stage == RIVER) stage = SHOWDOWN;
+        clean_up_pots();
+    }
+    void end_hand() {
+        clean_up_pots();
+        int idxs[kMaxSeats], m = 0;
+        for (int i = 0; i < n; i++)
+            if ((can_move[i] || out_of_cash[i]) && !folder[i]) idxs[m++] = i;
+        int w = m ? idxs[0] : 0;
+        if (m > 1) {
+            uint32_t best = 0;
+            for (int k = 0; k < m; k++) {
+                uint32_t key = hand_key(cards[idxs[k]], table_cards);
+                if (key > best) { best = key; w = idxs[k]; } /* first of equals (hand_evaluator.py:23) */
+            }
+        }
+        const double cap = player_max_win[w];
+        double total = 0, sum = 0;
+        for (int i = 0; i < n; i++) { total += player_max_win[i] < cap ? player_max_win[i] : cap; sum += player_max_win[i]; }
+        stacks[w] += total;
+        winner_ix = w;
+        if (total < sum)
+            for (int i = 0; i < n; i++) stacks[i] += player_max_win[i] > cap ? player_max_win[i] - cap : 0.0;
+    }
+    void process_decision(int action) {
+        const int seat = current;
+        if (action == FOLD) {
+            can_move[idx] = false;
+            folder[idx] = true;
+        } else {
+            const double pot = community_pot + current_round_pot;
+            double contribution = 0;
+            switch (action) {
+                case CALL: contribution = min_call - player_pots[seat] < stacks[seat] ? min_call - player_pots[seat] : stacks[seat]; break;
+                case CHECK: contribution = 0; checkers += 1; break;
+                case RAISE_3BB: contribution = 3 * big_blind - player_pots[seat]; break;
+                case RAISE_HALF_POT: contribution = pot / 2; break;
+                case RAISE_POT: contribution = pot; break;
+                case RAISE_2POT: contribution = pot * 2; break;
+                case ALL_IN: contribution = stacks[seat]; break;
+                case SMALL_BLIND: contribution = small_blind < stacks[seat] ? small_blind : stacks[seat]; break;
+                case BIG_BLIND:
+                    contribution = big_blind < stacks[seat] ? big_blind : stacks[seat];
+                    max_steps_total = step_counter + n * max_raises + 2; /* mark_bb */
+                    break;
+            }
+            if (action >= RAISE_3BB && action <= ALL_IN) num_raises[seat][stage] += 1;
+            if (contribution > min_call && action != SMALL_BLIND && action != BIG_BLIND) last_raiser = step_counter;
+            stacks[seat] -= contribution;
+            player_pots[seat] += contribution;
+            current_round_pot += contribution;
+            if (stacks[seat] == 0 && contribution > 0) { /* mark_out_of_cash_but_contributed */
+                out_of_cash[idx] = true;
+                can_move[idx] = false;
+            }
+            if (contribution > min_call) min_call = contribution;
+            player_max_win[seat] += contribution;
+        }
+        update_alive();
+    }
+    void legal_moves() {
+        legal = 0;
+        if (stage == SHOWDOWN) return;
+        const int seat = current;
+        double mx = 0;
+        for (int i = 0; i < n; i++) mx = player_pots[i] > mx ? player_pots[i] : mx;
+        if (player_pots[seat] == mx) legal |= 1u << CHECK;
+        else legal |= (1u << CALL) | (1u << FOLD);
+        if (num_raises[seat][stage < 3 ? stage : 3] < max_raises) {
+            const double pot = community_pot + current_round_pot, stack = stacks[seat];
+            if (stack >= 3 * big_blind - player_pots[seat]) legal |= 1u << RAISE_3BB;
+            if (stack >= pot / 2 && pot / 2 >= min_call) legal |= 1u << RAISE_HALF_POT;
+            if (stack >= pot && pot >= min_call) legal |= 1u << RAISE_POT;
+            if (stack >= pot * 2 && pot * 2 >= min_call) legal |= 1u << RAISE_2POT;
+            if (stack > 0) legal |= 1u << ALL_IN;
+        }
+    }
+
+    // ---- observation = one equity query (env.py:224-281)
+    void observe(mcq_query &q, uint32_t runs) {
+        if (!done) legal_moves();
+        if (current < 0) current = winner_ix;
+        queries++;
+        ep_queries++;
+        memset(&q, 0, sizeof q);
+        q.hole[0] = cards[current][0];
+        q.hole[1] = cards[current][1];
+        for (int i = 0; i < n_table; i++) q.board[i] = table_cards[i];
+        q.n_board = (uint8_t)n_table;
+        q.n_players = (uint8_t)n_alive();
+        q.runs = runs;
+    }
+    int policy(double equity) {
+        const int seat = current;
+        auto has = [&](int a) { return (legal >> a) & 1u; };
+        if (seat_kind[seat] == 0) { /* agents/agent_consider_equity.py:25-56 */
+            const double call = min_call_eq[seat], bet = min_bet_eq[seat];
+            if (equity > bet + 0.2 && has(ALL_IN)) return ALL_IN;
+            if (equity > bet + 0.1 && has(RAISE_2POT)) return RAISE_2POT;
+            if (equity > bet && has(RAISE_POT)) return RAISE_POT;
+            if (equity > bet - 0.1 && has(RAISE_HALF_POT)) return RAISE_HALF_POT;
+            if (equity > call && has(CALL)) return CALL;
+            if (has(CHECK)) return CHECK;
+            return FOLD;
+        }
+        /* agents/agent_random.py:21-29: uniform over its move set intersected with the legal moves */
+        const uint32_t moves = legal & ((1u << FOLD) | (1u << CHECK) | (1u << CALL) | (1u << RAISE_POT) |
+                                        (1u << RAISE_HALF_POT) | (1u << RAISE_2POT));
+        uint32_t k = draw(mcq_popc(moves));
+        for (int a = 0; a < 10; a++)
+            if ((moves >> a) & 1u) {
+                if (k == 0) return a;
+                k--;
+            }
+        return FOLD;
+    }
+    // advance after the pending query was answered; afterwards the next query is pending (or the episode ended)
+    void resume(double equity) {
+        legal_moves(); /* second half of _get_environment (env.py:272) */
+        if (phase == PH_FIRST || phase == PH_B) {
+            if (done) { finish_episode(); return; }
+            phase = PH_A;
+            return;
+        }
+        /* PH_A: the agent acts on this equity */
+        const int action = policy(equity);
+        if (!((legal >> action) & 1u)) return; /* illegal move: observe again (env.py:183-184) */
+        env_steps++;
+        ep_env_steps++;
+        process_decision(action);
+        go_next_player();
+        if (stage == END_HIDDEN || stage == SHOWDOWN) {
+            end_hand();
+            start_new_hand();
+        }
+        phase = PH_B;
+    }
+    void finish_episode() {
+        episodes++;
+        reset_episode();
+    }
+};
+
+}  // namespace
+
+struct mcq_tables {
+    mcq_ctx *ctx;
+    mcq_tables_config cfg;
+    double min_call[kMaxSeats], min_bet[kMaxSeats];
+    uint8_t kind[kMaxSeats];
+    std::vector<Table> tables;
+    std::vector<mcq_query> q;
+    std::vector<mcq_result> r;
+    std::vector<double> eq;
+    uint64_t calls;
+};
+
+extern "C" {
+
+int mcq_tables_set_error(const char *msg); /* mcq_host.cpp */
+
+mcq_tables *mcq_tables_create(mcq_ctx *ctx, const mcq_tables_config *cfg) {
+    if (!cfg || cfg->n_tables == 0 || cfg->n_seats < 2 || cfg->n_seats > kMaxSeats || cfg->runs == 0 ||
+        cfg->max_raises == 0) {
+        mcq_tables_set_error("mcq_tables_create: bad configuration (2..10 seats, runs > 0)");
+        return nullptr;
+    }
+    mcq_tables *t = new (std::nothrow) mcq_tables();
+    if (!t) { mcq_tables_set_error("mcq_tables_create: out of memory"); return nullptr; }
+    try {
+        t->ctx = ctx;
+        t->cfg = *cfg;
+        t->calls = 0;
+        for (uint32_t s = 0; s < cfg->n_seats; s++) {
+            t->min_call[s] = cfg->min_call_equity[s];
+            t->min_bet[s] = cfg->min_bet_equity[s];
+            t->kind[s] = cfg->seat_kind[s];
+        }
+        t->tables.resize(cfg->n_tables);
+        t->q.resize(cfg->n_tables);
+        t->r.resize(cfg->n_tables);
+        t->eq.resize(cfg->n_tables);
+        for (uint32_t i = 0; i < cfg->n_tables; i++) {
+            Table &tb = t->tables[i];
+            memset(&tb, 0, sizeof tb);
+            tb.n = (int)cfg->n_seats;
+            tb.initial_stacks = cfg->initial_stacks;
+            tb.small_blind = cfg->small_blind;
+            tb.big_blind = cfg->big_blind;
+            tb.max_raises = (int)cfg->max_raises;
+            tb.seat_kind = t->kind;
+            tb.min_call_eq = t->min_call;
+            tb.min_bet_eq = t->min_bet;
+            uint32_t o[4];
+            mcq_philox4x32_10(i, 0, 0, 0x54424C31u /* 'TBL1' */, (uint32_t)cfg->seed, (uint32_t)(cfg->seed >> 32), o);
+            tb.rng.s0 = o[0]; tb.rng.s1 = o[1]; tb.rng.s2 = o[2]; tb.rng.s3 = o[3];
+            if ((o[0] | o[1] | o[2] | o[3]) == 0) tb.rng.s0 = 1;
+            tb.reset_episode();
+        }
+    } catch (...) {
+        delete t;
+        mcq_tables_set_error("mcq_tables_create: out of memory");
+        return nullptr;
+    }
+    return t;
+}
+
+void mcq_tables_destroy(mcq_tables *t) { delete t; }
+
+size_t mcq_tables_begin(mcq_tables *t, mcq_query *q) {
+    if (!t || !q) return 0;
+    for (size_t i = 0; i < t->tables.size(); i++) t->tables[i].observe(q[i], t->cfg.runs);
+    return t->tables.size();
+}
+
+int mcq_tables_resume(mcq_tables *t, const double *equity) {
+    if (!t || !equity) return mcq_tables_set_error("mcq_tables_resume: null argument");
+    for (size_t i = 0; i < t->tables.size(); i++) t->tables[i].resume(equity[i]);
+    return MCQ_OK;
+}
+
+int mcq_tables_run(mcq_tables *t, uint32_t lock_steps, uint64_t *stats) {
+    if (!t || !t->ctx) return mcq_tables_set_error("mcq_tables_run: needs a context");
+    const size_t n = t->tables.size();
+    for (uint32_t s = 0; s < lock_steps; s++) {
+        mcq_tables_begin(t, t->q.data());
+        int rc = mcq_eval_batch(t->ctx, t->q.data(), n, t->cfg.seed, t->calls, MCQ_MODE_PHILOX, t->r.data());
+        if (rc) return rc;
+        t->calls += n;
+        for (size_t i = 0; i < n; i++)
+            t->eq[i] = (double)(t->r[i].win + t->r[i].tie) / (double)t->r[i].runs;
+        mcq_tables_resume(t, t->eq.data());
+    }
+    if (stats) mcq_tables_stats(t, stats);
+    return MCQ_OK;
+}
+
+void mcq_tables_stats(const mcq_tables *t, uint64_t *stats) {
+    uint64_t env = 0, qs = 0, ep = 0;
+    for (const Table &tb : t->tables) { env += tb.env_steps; qs += tb.queries; ep += tb.episodes; }
+    stats[0] = env;
+    stats[1] = qs;
+    stats[2] = ep;
+}
+
+int mcq_tables_state(const mcq_tables *t, uint32_t table, double *stacks, int32_t *info) {
+    if (!t || table >= t->tables.size()) return mcq_tables_set_error("mcq_tables_state: bad table index");
+    const Table &tb = t->tables[table];
+    for (int i = 0; i < tb.n; i++) stacks[i] = tb.stacks[i];
+    info[0] = tb.stage;
+    info[1] = tb.current;
+    info[2] = tb.winner_ix;
+    info[3] = (int32_t)tb.episodes;
+    info[4] = (int32_t)tb.env_steps;
+    info[5] = (int32_t)tb.queries;
+    info[6] = (int32_t)tb.legal;
+    info[7] = tb.phase;
+    return MCQ_OK;
+}
+
+}  // extern "C"

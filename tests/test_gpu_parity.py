@@ -428,3 +428,29 @@ def test_gate_b_production_rng_vs_reference_stream_at_1e9_iterations(eng):
     assert abs(e_mt - 0.659) < 2e-3  # the biased law's value, not the uniform 0.680
     # per hand type as well: shares of hero's winning types agree to 1e-4
     assert np.all(np.abs(mt[:, 4:].sum(0) / n - ph[:, 4:].sum(0) / n) <= 1e-4)
+
+
+def test_native_table_driver_on_gpu_equals_stepwise_batches(eng):
+    """mcq_tables_run (native lock-step driver, BASELINE configs[4]) == the same tables stepped from Python with
+    begin() -> eval_batch(seed, query ids counting up) -> resume(): same stacks, counts and pending queries; and the
+    equities it acts on are the oracle's for the same (seed, query id)."""
+    from neuron_poker_amd import _lib
+    seats = [("equity", .5, -.5), ("equity", .8, -.8), ("equity", .3, .5), ("equity", .2, .75), ("random",), ("random",)]
+    T, steps, seed = 96, 300, 77
+    a = _lib.Tables(eng, T, seats, runs=1000, seed=seed)
+    b = _lib.Tables(None, T, seats, runs=1000, seed=seed)
+    st = a.run(steps)
+    calls = 0
+    for s in range(steps):
+        q = b.begin()
+        r = eng.eval_batch(q, seed, first_query_id=calls)
+        if s % 100 == 0:
+            o = O.run_batch(O.MODE_CTR, q.view(np.uint8).reshape(-1, 16), seed, first_qid=calls, threads=8)
+            assert np.array_equal(o, r.view(np.uint64).reshape(-1, 13))
+        calls += T
+        b.resume((r["win"] + r["tie"]).astype(np.float64) / r["runs"].astype(np.float64))
+    assert st == b.stats() and st["queries"] == T * steps and st["env_steps"] > 0 and st["episodes"] > 0
+    for t in range(T):
+        sa, sb = a.state(t), b.state(t)
+        assert np.array_equal(sa.pop("stacks"), sb.pop("stacks")) and sa == sb
+    assert np.array_equal(a.begin(), b.begin())

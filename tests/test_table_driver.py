@@ -88,3 +88,111 @@ def test_batch_lock_step_equals_sequential_tables():
     got = [(t.winner_ix, [float(x) for x in t.stacks], t.queries, t.env_steps) for t in batch.tables]
     assert got == solo
     assert all(abs(sum(s) - 400) < 1e-9 for _, s, _, _ in got)  # chips are conserved
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The native driver (mcq_tables_* in include/mcq.h, csrc/mcq_tables.cpp) against the Python driver above, which
+# the reference's own episodes pin: same per-table generator for dealing and random seats, same deterministic
+# stand-in for the equity, so every table must issue the same query at every lock-step and end with the same
+# stacks.  begin()/resume() need no GPU.
+M32 = 0xFFFFFFFF
+
+
+def _philox(c, k):
+    c, k = list(c), list(k)
+    for _ in range(10):
+        p0, p1 = 0xD2511F53 * c[0], 0xCD9E8D57 * c[2]
+        c = [(p1 >> 32) ^ c[1] ^ k[0], p1 & M32, (p0 >> 32) ^ c[3] ^ k[1], p0 & M32]
+        k = [(k[0] + 0x9E3779B9) & M32, (k[1] + 0xBB67AE85) & M32]
+    return c
+
+
+class _Xoshiro:
+    def __init__(self, seed, table):
+        self.s = _philox([table, 0, 0, 0x54424C31], [seed & M32, seed >> 32])
+
+    def next(self):
+        s = self.s
+        rotl = lambda x, k: ((x << k) | (x >> (32 - k))) & M32  # noqa: E731
+        result = (rotl((s[0] + s[3]) & M32, 7) + s[0]) & M32
+        t = (s[1] << 9) & M32
+        s[2] ^= s[0]
+        s[3] ^= s[1]
+        s[1] ^= s[2]
+        s[0] ^= s[3]
+        s[2] ^= t
+        s[3] = rotl(s[3], 11)
+        return result
+
+    def randint(self, n):
+        return (self.next() * n) >> 32
+
+    def integers(self, lo, hi):
+        return lo + self.randint(hi - lo)
+
+
+def _fake_equity(hole, board, alive):
+    x = (int(hole[0]) * 131 + int(hole[1]) * 31 + sum(int(b) for b in board) * 7 + alive * 13 + len(board) * 3) % 101
+    return x / 100.0
+
+
+def _host_showdown(hands):
+    keys = H.eval7(np.array(hands, np.uint8))
+    return int(np.argmax(keys))          # first of equals
+
+
+@pytest.mark.parametrize("seats,stacks,steps", [
+    ([("equity", .3, .5), ("equity", .45, .6), ("random",), ("equity", .2, .75), ("random",), ("equity", .5, .9)], 100, 1500),
+    ([("equity", .5, -.5), ("equity", .8, -.8), ("equity", .7, -.7), ("equity", .2, -.3), ("random",), ("random",)], 100, 600),
+    ([("equity", .35, .55), ("random",)], 60, 800),
+    ([("random",)] * 3, 40, 800),
+    ([("equity", .25, .65)] * 9 + [("random",)], 250.5, 800),
+])
+def test_native_tables_follow_the_python_driver(seats, stacks, steps):
+    from neuron_poker_amd import _lib
+    T, seed = 12, 0xC0FFEE12345
+    nat = _lib.Tables(None, T, seats, runs=1000, initial_stacks=stacks, seed=seed)
+    sims, gens, pend, episodes = [], [], [], [0] * T
+    for t in range(T):
+        rng = _Xoshiro(seed, t)
+        pol = [td.equity_policy(s[1], s[2]) if s[0] == "equity" else td.random_policy(rng) for s in seats]
+        sim = td.TableSim(pol, initial_stacks=stacks, showdown=_host_showdown, randint=rng.randint)
+        sims.append(sim)
+        gens.append(sim.episode())
+        pend.append(next(gens[-1]))
+    for step in range(steps):
+        q = nat.begin()
+        eq = np.zeros(T)
+        for t in range(T):
+            hole, board, alive = pend[t]
+            assert list(q["hole"][t]) == hole, (step, t)
+            assert q["n_board"][t] == len(board) and list(q["board"][t][:len(board)]) == board, (step, t)
+            assert q["n_players"][t] == alive and q["runs"][t] == 1000, (step, t)
+            eq[t] = _fake_equity(hole, board, alive)
+        nat.resume(eq)
+        for t in range(T):
+            try:
+                pend[t] = gens[t].send(eq[t])
+            except StopIteration:
+                episodes[t] += 1
+                gens[t] = sims[t].episode()
+                pend[t] = next(gens[t])
+    tot_steps = 0
+    for t in range(T):
+        st = nat.state(t)
+        assert st["episodes"] == episodes[t]
+        assert list(st["stacks"]) == [float(s) for s in sims[t].stacks], t
+        tot_steps += st["env_steps"]
+    assert nat.stats()["queries"] == T * steps
+    assert nat.stats()["env_steps"] == sum(s.env_steps for s in sims) == tot_steps
+    assert tot_steps > 0 and sum(episodes) > 0
+
+
+def test_native_tables_reject_bad_configuration():
+    from neuron_poker_amd import _lib
+    with pytest.raises(ValueError):
+        _lib.Tables(None, 4, [("random",)])
+    with pytest.raises(ValueError):
+        _lib.Tables(None, 0, [("random",)] * 2)
+    with pytest.raises(ValueError):
+        _lib.Tables(None, 4, [("random",)] * 2, runs=0)

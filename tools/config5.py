@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--lock-steps", type=int, default=10000)
     ap.add_argument("--runs", type=int, default=1000)
     ap.add_argument("--seed", type=int, default=5)
+    ap.add_argument("--driver", choices=["native", "python"], default="native",
+                    help="native: mcq_tables_* (csrc/mcq_tables.cpp); python: neuron_poker_amd/table_driver.py")
     args = ap.parse_args()
 
     import neuron_poker_amd as npa
@@ -37,6 +39,32 @@ def main():
     eng = npa.Engine(int(os.environ.get("LOCAL_RANK", "0")))
     rng = np.random.default_rng(args.seed)
     pairs = [(.5, -.5), (.8, -.8), (.7, -.7), (.2, -.3)]  # main.py:142-145
+
+    if args.driver == "native":
+        from neuron_poker_amd import _lib
+        seats = [("equity", c, b) for c, b in pairs] + [("random",), ("random",)]
+        tb = _lib.Tables(eng, args.tables, seats, runs=args.runs, seed=args.seed)
+        tb.run(20)  # warm-up (first launch, buffers)
+        s0 = tb.stats()
+        t0 = time.perf_counter()
+        done, k_ms = 0, 0.0
+        while done < args.lock_steps:
+            k = min(500, args.lock_steps - done)
+            tb.run(k)
+            k_ms += eng.last_kernel_ms
+            done += k
+        wall = time.perf_counter() - t0
+        s1 = tb.stats()
+        d = {k: s1[k] - s0[k] for k in s1}
+        print(json.dumps({"workload": "configs[4]: %d tables x 6 seats, %d lock-steps, %d runs per query" %
+                                      (args.tables, args.lock_steps, args.runs), "driver": "native (mcq_tables_run)",
+                          "env_steps": d["env_steps"], "episodes_finished": d["episodes"],
+                          "equity_queries": d["queries"], "wall_s": wall, "env_steps_per_s": d["env_steps"] / wall,
+                          "lock_steps_per_s": args.lock_steps / wall,
+                          "equity_queries_per_s": d["queries"] / wall,
+                          "ms_per_lock_step": 1e3 * wall / args.lock_steps,
+                          "kernel_ms_last_lock_step_avg": k_ms / max(1, (args.lock_steps + 499) // 500)}))
+        return
 
     def showdown(hands):
         w, _ = eng.showdown(np.array([hands], np.uint8))
@@ -75,7 +103,7 @@ def main():
     wall = time.perf_counter() - t0
     env_steps += sum(t.env_steps for t in batch.tables)
     print(json.dumps({"workload": "configs[4]: %d tables x 6 seats, %d lock-steps, %d runs per query" %
-                                  (args.tables, args.lock_steps, args.runs),
+                                  (args.tables, args.lock_steps, args.runs), "driver": "python (table_driver.py)",
                       "env_steps": env_steps, "episodes_finished": episodes, "equity_queries": queries,
                       "wall_s": wall, "env_steps_per_s": env_steps / wall, "lock_steps_per_s": args.lock_steps / wall,
                       "equity_call_share": t_eq / wall, "equity_ms_per_lock_step": 1e3 * t_eq / args.lock_steps,
