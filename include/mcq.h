@@ -172,7 +172,7 @@ typedef struct mcq_tables_config {
     double initial_stacks, small_blind, big_blind;
     uint64_t seed;
     uint8_t seat_kind[10];
-    uint8_t reserved[6];
+    uint8_t reserved[6];            /* [0]: host threads stepping the tables (0 = automatic); rest 0 */
     double min_call_equity[10], min_bet_equity[10];
 } mcq_tables_config;
 

@@ -302,16 +302,18 @@ class Tables:
     """mcq_tables: T Hold'em tables advanced in lock-step by the native driver (include/mcq.h, BASELINE configs[4]).
 
     seats: one entry per seat -- ("equity", min_call_equity, min_bet_equity) or ("random",).
-    engine=None gives a driver without GPU: only begin()/resume() work (used to pin the rules on the CPU)."""
+    engine=None gives a driver without GPU: only begin()/resume() work (used to pin the rules on the CPU).
+    The tables are independent (own generator each): results do not depend on `threads`."""
 
     def __init__(self, engine, n_tables, seats, runs=1000, initial_stacks=100, small_blind=1, big_blind=2,
-                 max_raises=2, seed=0):
+                 max_raises=2, seed=0, threads=0):
         self._lib = load_library()
         self._engine = engine
         cfg = np.zeros(1, TABLES_CONFIG_DTYPE)
         cfg["n_tables"], cfg["n_seats"], cfg["runs"], cfg["max_raises"] = n_tables, len(seats), runs, max_raises
         cfg["initial_stacks"], cfg["small_blind"], cfg["big_blind"] = initial_stacks, small_blind, big_blind
         cfg["seed"] = int(seed) & (2 ** 64 - 1)
+        cfg["reserved"][0, 0] = threads          # host threads stepping the tables; 0 = automatic
         if len(seats) > 10:
             raise ValueError("at most 10 seats")
         for i, s in enumerate(seats):

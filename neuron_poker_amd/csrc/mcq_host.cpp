@@ -5,6 +5,7 @@
 // without a HIP device mcq_create fails and every other entry point needs a context.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -99,6 +100,7 @@ struct mcq_ctx {
     int n_cu = 0;
     int occ[3] = {1, 1, 1}; /* resident kBlock-thread blocks per CU of the eval kernels (by internal mode) */
     int law = MCQ_LAW_REFERENCE;
+    uint32_t split_max = 4; /* finest cut of a task for small batches: 16 >> split_max iterations per lane */
     hipStream_t stream = nullptr;
     static constexpr int kRing = 64; /* event pairs around the most recent evaluation-kernel launches */
     hipEvent_t ev0[kRing] = {}, ev1[kRing] = {};
@@ -114,9 +116,23 @@ namespace {
 uint32_t tasks_of(const mcq_query &q) { return q.runs / MCQ_TASK_ITERS + (q.runs % MCQ_TASK_ITERS != 0u ? 1u : 0u); }
 
 /* grid/block for a launch whose total task count is known (host entry) or unknown (0) */
-void pick_geometry(const mcq_ctx *c, int mode, uint64_t total_tasks, uint32_t *grid, uint32_t *block) {
+void pick_geometry(const mcq_ctx *c, int mode, uint64_t total_tasks, uint32_t *grid, uint32_t *block,
+                   uint32_t *split = nullptr, uint64_t max_tasks = 0) {
     const uint32_t full = (uint32_t)c->n_cu * (uint32_t)c->occ[mode];
+    if (split) *split = 0;
     if (total_tasks == 0) { *block = kBlock; *grid = full; return; }
+    /* small batches: a lone wave per SIMD is bound by the latency of its dependent LDS lookups, so tasks are cut
+     * into 2^split sub-tasks as long as that leaves at most two waves per SIMD -- and at most 512 waves on one
+     * query: every (wave, query) pair ends in twelve atomics on the query's result row, and atomics on one
+     * address serialise (measured: 100k runs 31 us uncut, 18 us in 392 pieces, 29 us in 1568; profiles/README.md).
+     * The tallies do not depend on the cut. */
+    if (split) {
+        const uint64_t want = 8ull * (uint64_t)c->n_cu;
+        if (max_tasks == 0) max_tasks = total_tasks;
+        while (*split < c->split_max && (total_tasks << (*split + 1)) <= want && (max_tasks << (*split + 1)) <= 512u)
+            ++*split;
+        total_tasks <<= *split;
+    }
     /* one block per CU (the LDS tables allow no more); few tasks are spread over all CUs with fewer waves per
      * block: 98 tasks of a single 100k query -> 98 one-wave blocks, 1024 tasks -> 256 four-wave blocks */
     uint64_t wpb = (total_tasks + (uint64_t)c->n_cu - 1) / (uint64_t)c->n_cu;
@@ -130,16 +146,16 @@ void pick_geometry(const mcq_ctx *c, int mode, uint64_t total_tasks, uint32_t *g
 
 int run_slice(mcq_ctx *c, int mode, const mcq_query *d_q, uint32_t n, mcq_result *d_res, uint64_t seed,
               uint64_t first_qid, uint64_t total_tasks, const uint8_t *d_draws, const uint64_t *d_off, hipStream_t s,
-              bool timed) {
+              bool timed, uint64_t max_tasks = 0) {
     if (mode == MCQ_MODE_PHILOX && c->law == MCQ_LAW_UNIFORM) mode = MCQ_INTERNAL_MODE_UNIFORM;
     HIP_TRY(c->d_prefix.reserve(((size_t)n + 1) * sizeof(uint64_t)));
     HIP_TRY(mcq_launch_prep(d_q, n, d_res, (uint64_t *)c->d_prefix.p, s));
-    uint32_t grid, block;
-    pick_geometry(c, mode, total_tasks, &grid, &block);
+    uint32_t grid, block, split;
+    pick_geometry(c, mode, total_tasks, &grid, &block, &split, max_tasks);
     const int slot = (int)(c->n_timed % mcq_ctx::kRing);
     if (timed) HIP_TRY(hipEventRecord(c->ev0[slot], s));
     HIP_TRY(mcq_launch_eval(mode, d_q, n, (const uint64_t *)c->d_prefix.p, d_res, seed, first_qid, c->d_luts, d_draws,
-                            d_off, grid, block, s));
+                            d_off, grid, block, split, s));
     if (timed) {
         HIP_TRY(hipEventRecord(c->ev1[slot], s));
         c->n_timed++;
@@ -174,7 +190,7 @@ int replay_batch(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed, uint64
     size_t a = 0;
     while (a < n) {
         size_t b = a;
-        uint64_t bytes = 0, tasks = 0;
+        uint64_t bytes = 0, tasks = 0, max_tasks = 0;
         HIP_TRY(c->h_off.reserve((n - a < 65536 ? n - a : 65536) * sizeof(uint64_t)));
         uint64_t *off = (uint64_t *)c->h_off.p;
         while (b < n && b - a < 65536) {
@@ -184,6 +200,7 @@ int replay_batch(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed, uint64
             off[b - a] = bytes;
             bytes += need;
             tasks += tasks_of(q[b]);
+            if (tasks_of(q[b]) > max_tasks) max_tasks = tasks_of(q[b]);
             b++;
         }
         const size_t m = b - a;
@@ -219,7 +236,7 @@ int replay_batch(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed, uint64
         HIP_TRY(hipMemcpyAsync(c->d_off.p, off, m * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
         int rc = run_slice(c, MCQ_MODE_REPLAY_MT19937, (const mcq_query *)c->d_q.p + a, (uint32_t)m,
                            (mcq_result *)c->d_res.p + a, seed, first_query_id + a, tasks, (const uint8_t *)c->d_draws.p,
-                           (const uint64_t *)c->d_off.p, c->stream, true);
+                           (const uint64_t *)c->d_off.p, c->stream, true, max_tasks);
         if (rc) return rc;
         HIP_TRY(hipStreamSynchronize(c->stream)); /* staging buffers are reused by the next chunk */
         float ms = 0.f;
@@ -324,6 +341,10 @@ mcq_ctx *mcq_create(int device, int flags) {
     CREATE_TRY(hipSetDevice(device));
     CREATE_TRY(hipGetDeviceProperties(&prop, device));
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char *e = getenv("MCQ_SPLIT_MAX")) { /* tuning knob, see pick_geometry */
+        int v = atoi(e);
+        c->split_max = (uint32_t)(v < 0 ? 0 : (v > 4 ? 4 : v));
+    }
     CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (int i = 0; i < mcq_ctx::kRing; i++) {
         CREATE_TRY(hipEventCreate(&c->ev0[i]));
@@ -389,12 +410,15 @@ int mcq_eval_batch(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed, uint
     if (n == 0) return MCQ_OK;
     int rc = stage_queries(c, q, n, out, "mcq_eval_batch");
     if (rc) return rc;
-    uint64_t total_tasks = 0;
-    for (size_t i = 0; i < n; i++) total_tasks += tasks_of(q[i]);
+    uint64_t total_tasks = 0, max_tasks = 0;
+    for (size_t i = 0; i < n; i++) {
+        total_tasks += tasks_of(q[i]);
+        if (tasks_of(q[i]) > max_tasks) max_tasks = tasks_of(q[i]);
+    }
 
     if (mode == MCQ_MODE_PHILOX) {
         rc = run_slice(c, mode, (const mcq_query *)c->d_q.p, (uint32_t)n, (mcq_result *)c->d_res.p, seed,
-                       first_query_id, total_tasks, nullptr, nullptr, c->stream, true);
+                       first_query_id, total_tasks, nullptr, nullptr, c->stream, true, max_tasks);
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(c->h_res.p, c->d_res.p, n * sizeof(mcq_result), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));

@@ -132,13 +132,17 @@ struct WaveTally { /* per-lane running sums of the current (wave, query) pair */
     }
 };
 
-template <int MODE>
+template <int MODE, bool SPLIT>
 __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__restrict__ queries, uint32_t n,
                                                              const uint64_t *__restrict__ prefix,
                                                              mcq_result *__restrict__ res, uint64_t seed,
                                                              uint64_t first_qid, const McqTables *__restrict__ g_tab,
                                                              const uint8_t *__restrict__ draws,
-                                                             const uint64_t *__restrict__ draw_off) {
+                                                             const uint64_t *__restrict__ draw_off, uint32_t split_arg) {
+    const uint32_t split = SPLIT ? split_arg : 0u; /* SPLIT = false: the bulk path, compiled without the cut */
+    /* split (0..4): small batches cut every 1024-iteration task into 2^split sub-tasks of 16 >> split iterations per
+     * lane so that more waves share the work; the iterations and their random numbers stay the same (a sub-task
+     * skips ahead in its lane's stream), so the tallies do not depend on it. */
     __shared__ __attribute__((aligned(16))) LdsTables tab;
     __shared__ McqCard base_tab[kMaxBlock]; /* per wave: the query's ordered remaining deck, 64 entries x 16 B */
     load_tables(tab, g_tab);
@@ -147,7 +151,8 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
     const uint32_t waves_per_block = blockDim.x >> 6;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * waves_per_block + (threadIdx.x >> 6));
     const uint64_t n_waves = (uint64_t)gridDim.x * waves_per_block;
-    const uint64_t total = prefix[n];
+    const uint32_t chunk = MCQ_STREAM_ITERS >> split, sub_mask = (1u << split) - 1u;
+    const uint64_t total = prefix[n] << split; /* cost axis in sub-task units */
     /* this wave's slice of the cost axis; a task belongs to the slice its start position falls into */
     const uint64_t lo = total * wave / n_waves, hi = total * (wave + 1ull) / n_waves;
     if (lo >= hi) return;
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
     uint32_t a = 0, b = n; /* last query with prefix <= lo: it has a positive cost because lo < total */
     while (b - a > 1) {
         const uint32_t mid = (a + b) >> 1;
-        if (prefix[mid] <= lo) a = mid; else b = mid;
+        if ((prefix[mid] << split) <= lo) a = mid; else b = mid;
     }
     uint32_t qi = __builtin_amdgcn_readfirstlane(a);
     uint32_t task = 0, n_tasks = 0, weight = 1;
@@ -170,9 +175,9 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
             if (qi >= n) break;
             const uint4 raw = reinterpret_cast<const uint4 *>(queries)[qi];
             const McqQueryWords q = {raw.x, raw.y, raw.z, raw.w};
-            pfx = prefix[qi];
-            const bool ok = prefix[qi + 1] > pfx; /* zero cost: invalid or runs == 0 */
-            n_tasks = ok ? mcq_task_count(q) : 0u;
+            pfx = prefix[qi] << split;
+            const bool ok = (prefix[qi + 1] << split) > pfx; /* zero cost: invalid or runs == 0 */
+            n_tasks = ok ? mcq_task_count(q) << split : 0u;
             weight = mcq_task_weight(q);
             task = 0;
             if (pfx < lo) task = (uint32_t)((lo - pfx + weight - 1) / weight); /* only for the first query */
@@ -195,13 +200,15 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
 
         McqLaneAcc acc = {0, 0, 0};
         if (MODE != MCQ_MODE_REPLAY_MT19937) {
-            const uint32_t stream = task * MCQ_WAVE + lane;
-            const uint64_t it0 = (uint64_t)stream * MCQ_STREAM_ITERS;
+            const uint32_t stream = (task >> split) * MCQ_WAVE + lane, sub = task & sub_mask;
+            const uint64_t it0 = (uint64_t)stream * MCQ_STREAM_ITERS + sub * chunk;
             if (it0 < qc.runs) {
                 McqCtrDrawsT<MODE == MCQ_INTERNAL_MODE_UNIFORM> dr;
                 dr.w = 0;
                 dr.rng.seed(seed, first_qid + qi, stream);
-                const uint32_t cnt = (uint32_t)min((uint64_t)MCQ_STREAM_ITERS, (uint64_t)qc.runs - it0);
+                /* words per iteration: one per opponent, one per two table cards */
+                for (uint32_t k = sub * chunk * (qc.n_opp + ((qc.n_deal + 1u) >> 1)); k != 0; k--) dr.rng.next();
+                const uint32_t cnt = (uint32_t)min((uint64_t)chunk, (uint64_t)qc.runs - it0);
                 for (uint32_t j = 0; j < cnt; j++)
                     mcq_iteration(qc, dr, base - 128, tab.tf, tab.tops, tab.sd, acc);
                 acc.passes = cnt * qc.n_opp; /* MCQ-CTR v3: one attempt per opponent, never re-drawn */
@@ -209,8 +216,8 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
         } else {
             const uint64_t stride = (qc.runs + 63u) & ~63ull;
             const uint8_t *dbase = draws + draw_off[qi];
-            for (uint32_t j = 0; j < MCQ_STREAM_ITERS; j++) {
-                const uint64_t it = (uint64_t)task * MCQ_TASK_ITERS + j * MCQ_WAVE + lane;
+            for (uint32_t j = (task & sub_mask) * chunk, je = j + chunk; j < je; j++) {
+                const uint64_t it = (uint64_t)(task >> split) * MCQ_TASK_ITERS + j * MCQ_WAVE + lane;
                 if (it < qc.runs) {
                     McqReplayDraws dr = {dbase + it, stride};
                     mcq_iteration(qc, dr, base - 128, tab.tf, tab.tops, tab.sd, acc);
@@ -414,16 +421,21 @@ hipError_t mcq_launch_prep(const mcq_query *d_q, uint32_t n, mcq_result *d_res, 
 
 hipError_t mcq_launch_eval(int mode, const mcq_query *d_q, uint32_t n, const uint64_t *d_prefix, mcq_result *d_res,
                            uint64_t seed, uint64_t first_qid, const McqTables *d_luts, const uint8_t *d_draws,
-                           const uint64_t *d_draw_off, uint32_t grid, uint32_t block, hipStream_t s) {
-    if (mode == MCQ_MODE_PHILOX)
-        hipLaunchKernelGGL(mcq_eval_kernel<MCQ_MODE_PHILOX>, dim3(grid), dim3(block), 0, s, d_q, n, d_prefix, d_res,
-                           seed, first_qid, d_luts, d_draws, d_draw_off);
-    else if (mode == MCQ_INTERNAL_MODE_UNIFORM)
-        hipLaunchKernelGGL(mcq_eval_kernel<MCQ_INTERNAL_MODE_UNIFORM>, dim3(grid), dim3(block), 0, s, d_q, n, d_prefix,
-                           d_res, seed, first_qid, d_luts, d_draws, d_draw_off);
-    else
-        hipLaunchKernelGGL(mcq_eval_kernel<MCQ_MODE_REPLAY_MT19937>, dim3(grid), dim3(block), 0, s, d_q, n, d_prefix,
-                           d_res, seed, first_qid, d_luts, d_draws, d_draw_off);
+                           const uint64_t *d_draw_off, uint32_t grid, uint32_t block, uint32_t split, hipStream_t s) {
+    if (split > 4) return hipErrorInvalidValue;
+#define MCQ_LAUNCH_EVAL(M)                                                                                        \
+    do {                                                                                                          \
+        if (split)                                                                                                \
+            hipLaunchKernelGGL((mcq_eval_kernel<M, true>), dim3(grid), dim3(block), 0, s, d_q, n, d_prefix, d_res, \
+                               seed, first_qid, d_luts, d_draws, d_draw_off, split);                              \
+        else                                                                                                      \
+            hipLaunchKernelGGL((mcq_eval_kernel<M, false>), dim3(grid), dim3(block), 0, s, d_q, n, d_prefix, d_res, \
+                               seed, first_qid, d_luts, d_draws, d_draw_off, 0u);                                 \
+    } while (0)
+    if (mode == MCQ_MODE_PHILOX) MCQ_LAUNCH_EVAL(MCQ_MODE_PHILOX);
+    else if (mode == MCQ_INTERNAL_MODE_UNIFORM) MCQ_LAUNCH_EVAL(MCQ_INTERNAL_MODE_UNIFORM);
+    else MCQ_LAUNCH_EVAL(MCQ_MODE_REPLAY_MT19937);
+#undef MCQ_LAUNCH_EVAL
     return hipGetLastError();
 }
 
@@ -458,9 +470,9 @@ hipError_t mcq_launch_showdown(const uint8_t *d_hands, uint32_t n_tables, uint32
 
 hipError_t mcq_eval_occupancy(int mode, int block, int *blocks_per_cu) {
     if (mode == MCQ_MODE_PHILOX)
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, mcq_eval_kernel<MCQ_MODE_PHILOX>, block, 0);
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, mcq_eval_kernel<MCQ_MODE_PHILOX, false>, block, 0);
     if (mode == MCQ_INTERNAL_MODE_UNIFORM)
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, mcq_eval_kernel<MCQ_INTERNAL_MODE_UNIFORM>,
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, mcq_eval_kernel<MCQ_INTERNAL_MODE_UNIFORM, false>,
                                                             block, 0);
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, mcq_eval_kernel<MCQ_MODE_REPLAY_MT19937>, block, 0);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, mcq_eval_kernel<MCQ_MODE_REPLAY_MT19937, false>, block, 0);
 }

@@ -12,9 +12,15 @@
 // Reference lines (paths relative to /root/reference): gym_env/env.py:138-688, gym_env/cycle.py:10-167,
 // agents/agent_consider_equity.py:25-56, agents/agent_random.py:21-29; showdowns use this library's own
 // evaluator (mcq_eval_key compiled for the host) = tools/hand_evaluator.py:9-24.
+#include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "mcq_device.hpp"
@@ -75,6 +81,7 @@ struct Table {
     bool done;
     uint32_t legal; /* bit mask over actions */
     int phase;
+    bool issued; /* the pending query was handed out by begin() */
     // statistics
     uint64_t env_steps, queries, episodes;
     uint64_t ep_env_steps, ep_queries; /* of the running episode */
@@ -321,8 +328,11 @@ struct Table {
     void observe(mcq_query &q, uint32_t runs) {
         if (!done) legal_moves();
         if (current < 0) current = winner_ix;
-        queries++;
-        ep_queries++;
+        if (!issued) { /* asking again for the same pending query does not count twice */
+            queries++;
+            ep_queries++;
+            issued = true;
+        }
         memset(&q, 0, sizeof q);
         q.hole[0] = cards[current][0];
         q.hole[1] = cards[current][1];
@@ -357,6 +367,7 @@ struct Table {
     }
     // advance after the pending query was answered; afterwards the next query is pending (or the episode ended)
     void resume(double equity) {
+        issued = false;
         legal_moves(); /* second half of _get_environment (env.py:272) */
         if (phase == PH_FIRST || phase == PH_B) {
             if (done) { finish_episode(); return; }
@@ -382,6 +393,67 @@ struct Table {
     }
 };
 
+// Static-partition parallel-for over the tables for large table counts (the tables are independent and each
+// has its own generator, so the result does not depend on the thread count).  Workers sleep on a condition
+// variable between jobs; a job is a [begin, end) range function.
+class Pool {
+  public:
+    explicit Pool(unsigned n_workers) {
+        for (unsigned w = 0; w < n_workers; w++) th_.emplace_back([this, w] { loop(w); });
+    }
+    ~Pool() {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+            gen_++;
+        }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    unsigned parts() const { return (unsigned)th_.size() + 1u; }
+    void run(size_t n, const std::function<void(size_t, size_t)> &fn) {
+        const unsigned p = parts();
+        {
+            std::lock_guard<std::mutex> g(m_);
+            fn_ = &fn;
+            n_ = n;
+            left_.store((int)th_.size(), std::memory_order_relaxed);
+            gen_++;
+        }
+        cv_.notify_all();
+        fn(0, n / p); /* the caller takes part 0 */
+        while (left_.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+    }
+
+  private:
+    void loop(unsigned w) {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(size_t, size_t)> *fn;
+            size_t n;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+                fn = fn_;
+                n = n_;
+            }
+            const unsigned p = parts();
+            (*fn)(n * (w + 1) / p, n * (w + 2) / p);
+            left_.fetch_sub(1, std::memory_order_release);
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    const std::function<void(size_t, size_t)> *fn_ = nullptr;
+    size_t n_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+    std::atomic<int> left_{0};
+};
+
 }  // namespace
 
 struct mcq_tables {
@@ -394,6 +466,13 @@ struct mcq_tables {
     std::vector<mcq_result> r;
     std::vector<double> eq;
     uint64_t calls;
+    Pool *pool = nullptr;
+    ~mcq_tables() { delete pool; }
+    template <class F>
+    void for_tables(F &&f) { /* f(begin, end) */
+        if (pool) pool->run(tables.size(), std::function<void(size_t, size_t)>(f));
+        else f((size_t)0, tables.size());
+    }
 };
 
 extern "C" {
@@ -438,6 +517,19 @@ mcq_tables *mcq_tables_create(mcq_ctx *ctx, const mcq_tables_config *cfg) {
             if ((o[0] | o[1] | o[2] | o[3]) == 0) tb.rng.s0 = 1;
             tb.reset_episode();
         }
+        /* threads: cfg.reserved[0], else $MCQ_TABLES_THREADS, else one per 1024 tables up to the core count (<= 16) */
+        unsigned nt = cfg->reserved[0];
+        if (nt == 0)
+            if (const char *e = getenv("MCQ_TABLES_THREADS")) nt = (unsigned)atoi(e);
+        if (nt == 0) {
+            unsigned hw = std::thread::hardware_concurrency();
+            if (hw == 0) hw = 4;
+            if (hw > 16) hw = 16;
+            nt = cfg->n_tables / 1024u;
+            if (nt > hw) nt = hw;
+        }
+        if (nt > cfg->n_tables) nt = cfg->n_tables;
+        if (nt > 1) t->pool = new Pool(nt - 1);
     } catch (...) {
         delete t;
         mcq_tables_set_error("mcq_tables_create: out of memory");
@@ -450,27 +542,38 @@ void mcq_tables_destroy(mcq_tables *t) { delete t; }
 
 size_t mcq_tables_begin(mcq_tables *t, mcq_query *q) {
     if (!t || !q) return 0;
-    for (size_t i = 0; i < t->tables.size(); i++) t->tables[i].observe(q[i], t->cfg.runs);
+    const uint32_t runs = t->cfg.runs;
+    t->for_tables([&](size_t a, size_t b) {
+        for (size_t i = a; i < b; i++) t->tables[i].observe(q[i], runs);
+    });
     return t->tables.size();
 }
 
 int mcq_tables_resume(mcq_tables *t, const double *equity) {
     if (!t || !equity) return mcq_tables_set_error("mcq_tables_resume: null argument");
-    for (size_t i = 0; i < t->tables.size(); i++) t->tables[i].resume(equity[i]);
+    t->for_tables([&](size_t a, size_t b) {
+        for (size_t i = a; i < b; i++) t->tables[i].resume(equity[i]);
+    });
     return MCQ_OK;
 }
 
 int mcq_tables_run(mcq_tables *t, uint32_t lock_steps, uint64_t *stats) {
     if (!t || !t->ctx) return mcq_tables_set_error("mcq_tables_run: needs a context");
     const size_t n = t->tables.size();
+    const uint32_t runs = t->cfg.runs;
+    if (lock_steps) mcq_tables_begin(t, t->q.data());
     for (uint32_t s = 0; s < lock_steps; s++) {
-        mcq_tables_begin(t, t->q.data());
         int rc = mcq_eval_batch(t->ctx, t->q.data(), n, t->cfg.seed, t->calls, MCQ_MODE_PHILOX, t->r.data());
-        if (rc) return rc;
+        if (rc) return rc; /* the queries stay pending: the tables were not advanced */
         t->calls += n;
-        for (size_t i = 0; i < n; i++)
-            t->eq[i] = (double)(t->r[i].win + t->r[i].tie) / (double)t->r[i].runs;
-        mcq_tables_resume(t, t->eq.data());
+        const bool more = s + 1 < lock_steps;
+        t->for_tables([&](size_t a, size_t b) { /* answer, act, and issue the next query in one pass */
+            for (size_t i = a; i < b; i++) {
+                Table &tb = t->tables[i];
+                tb.resume((double)(t->r[i].win + t->r[i].tie) / (double)t->r[i].runs);
+                if (more) tb.observe(t->q[i], runs);
+            }
+        });
     }
     if (stats) mcq_tables_stats(t, stats);
     return MCQ_OK;

@@ -454,3 +454,40 @@ def test_native_table_driver_on_gpu_equals_stepwise_batches(eng):
         sa, sb = a.state(t), b.state(t)
         assert np.array_equal(sa.pop("stacks"), sb.pop("stacks")) and sa == sb
     assert np.array_equal(a.begin(), b.begin())
+
+
+def test_small_batch_task_split_does_not_change_tallies():
+    """Small batches cut each 1024-iteration task into 2^split sub-tasks (pick_geometry in csrc/mcq_host.cpp);
+    every setting of the cut must give the oracle's tallies, in both modes, for ragged run counts."""
+    rng = np.random.default_rng(99)
+    runs = [1000, 1, 17, 5000, 1024, 1025, 100000, 63, 64, 65, 2048, 999]
+    hole, board, npl = [], [], []
+    for i, r in enumerate(runs):
+        c = rng.permutation(52)[:7]
+        nb = [0, 3, 4, 5][i % 4]
+        hole.append(c[:2])
+        board.append(list(c[2:2 + nb]) + [255] * (5 - nb))
+        npl.append(2 + i % 9)
+    q = npa.pack_queries(hole, board, npl, runs)
+    raw = q.view(np.uint8).reshape(-1, 16)
+    want = {m: O.run_batch(om, raw, 31337, first_qid=5, threads=8)
+            for m, om in [(npa.MODE_PHILOX, O.MODE_CTR), (npa.MODE_REPLAY_MT19937, O.MODE_MT)]}
+    # the cut is limited to 512 pieces per query: the short queries alone reach the finest cut, the 100k one 2^2
+    short = np.array([r <= 2048 for r in runs])
+    old = os.environ.get("MCQ_SPLIT_MAX")
+    try:
+        for s in range(5):
+            os.environ["MCQ_SPLIT_MAX"] = str(s)
+            e = npa.Engine(0)
+            for m in want:
+                got = e.eval_batch(q, 31337, first_query_id=5, mode=m).view(np.uint64).reshape(-1, 13)
+                assert np.array_equal(got, want[m]), (s, m)
+                for i in np.nonzero(short)[0]:          # one query alone: first_query_id selects its stream
+                    got = e.eval_batch(q[i:i + 1], 31337, first_query_id=5 + int(i), mode=m)
+                    assert np.array_equal(got.view(np.uint64).reshape(-1, 13), want[m][i:i + 1]), (s, m, i)
+            e.close()
+    finally:
+        if old is None:
+            os.environ.pop("MCQ_SPLIT_MAX", None)
+        else:
+            os.environ["MCQ_SPLIT_MAX"] = old

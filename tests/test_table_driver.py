@@ -196,3 +196,23 @@ def test_native_tables_reject_bad_configuration():
         _lib.Tables(None, 0, [("random",)] * 2)
     with pytest.raises(ValueError):
         _lib.Tables(None, 4, [("random",)] * 2, runs=0)
+
+
+def test_native_tables_do_not_depend_on_the_thread_count():
+    from neuron_poker_amd import _lib
+    seats = [("equity", .3, .5), ("equity", .45, .6), ("random",), ("equity", .2, .75), ("random",), ("equity", .5, .9)]
+    T = 3000
+    a = _lib.Tables(None, T, seats, seed=9, threads=1)
+    b = _lib.Tables(None, T, seats, seed=9, threads=5)
+    for step in range(120):
+        qa, qb = a.begin(), b.begin()
+        assert np.array_equal(qa, qb), step
+        assert np.array_equal(a.begin(), qa)          # asking again returns the same pending queries, uncounted
+        eq = ((qa["hole"].astype(np.int64) * [131, 31]).sum(1) + qa["board"].astype(np.int64).sum(1) * 7
+              + qa["n_players"] * 13) % 101 / 100.0
+        a.resume(eq)
+        b.resume(eq)
+    assert a.stats() == b.stats() and a.stats()["queries"] == T * 120
+    for t in range(0, T, 97):
+        sa, sb = a.state(t), b.state(t)
+        assert np.array_equal(sa.pop("stacks"), sb.pop("stacks")) and sa == sb
