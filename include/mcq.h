@@ -141,6 +141,14 @@ MCQ_API int mcq_eval_batch_device(mcq_ctx *ctx, const void *d_queries, size_t n,
 MCQ_API int mcq_showdown(mcq_ctx *ctx, const uint8_t *hands, size_t n_tables, int n_players, uint8_t *winner,
                  uint8_t *winner_type, uint32_t *keys);
 
+/* Exact equity by exhaustive enumeration (what tools/montecarlo_cpp/Test.cpp:176-217 approximates with
+ * 1 % bands): every opponent hand and every completion of the table, weighted as the dealing law `law` (MCQ_LAW_*)
+ * deals them -- for MCQ_LAW_REFERENCE the exact distribution of tools/montecarlo_python.py:121-189, index bias
+ * included.  n_players 1..3; q[i].runs is ignored.  out[i]: runs = total weight, win / tie / by_type = weight of
+ * the outcomes (integers; equity = (win + tie) / runs exactly), passes = 0.  Preflop heads-up = 2.1e9 hand
+ * evaluations, three players preflop = 1.2e12 pair comparisons. */
+MCQ_API int mcq_exact_batch(mcq_ctx *ctx, const mcq_query *q, size_t n, int law, mcq_result *out);
+
 /* Select the dealing law used by MCQ_MODE_PHILOX on this context (MCQ_LAW_*). */
 MCQ_API int mcq_set_dealing_law(mcq_ctx *ctx, int law);
 

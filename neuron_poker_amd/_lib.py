@@ -92,6 +92,8 @@ def load_library():
         L.mcq_eval_batch_device.restype = C.c_int
         L.mcq_showdown.argtypes = [vp, vp, sz, C.c_int, vp, vp, vp]
         L.mcq_showdown.restype = C.c_int
+        L.mcq_exact_batch.argtypes = [vp, vp, sz, C.c_int, vp]
+        L.mcq_exact_batch.restype = C.c_int
         L.mcq_set_dealing_law.argtypes = [vp, C.c_int]
         L.mcq_set_dealing_law.restype = C.c_int
         L.mcq_kernel_times.argtypes = [vp, vp, C.c_int]
@@ -229,6 +231,19 @@ class Engine:
         out = np.zeros(len(q), RESULT_DTYPE)
         rc = self._lib.mcq_eval_batch(self._ctx, q.ctypes.data, len(q), int(seed) & (2 ** 64 - 1),
                                       int(first_query_id) & (2 ** 64 - 1), int(mode), out.ctypes.data)
+        if rc:
+            _raise(rc)
+        return out
+
+    def exact(self, queries, law="reference"):
+        """Exact enumeration (1..3 players; `runs` of the queries is ignored).  -> RESULT_DTYPE rows of integer
+        weights: runs = total weight, equity = (win + tie) / runs exactly."""
+        code = {"reference": 0, "uniform": 1, 0: 0, 1: 1}.get(law)
+        if code is None:
+            raise ValueError("law must be 'reference' or 'uniform'")
+        q = np.ascontiguousarray(queries, dtype=QUERY_DTYPE).reshape(-1)
+        out = np.zeros(len(q), RESULT_DTYPE)
+        rc = self._lib.mcq_exact_batch(self._ctx, q.ctypes.data, len(q), code, out.ctypes.data)
         if rc:
             _raise(rc)
         return out

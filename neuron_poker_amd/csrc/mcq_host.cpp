@@ -587,4 +587,29 @@ int mcq_showdown(mcq_ctx *c, const uint8_t *hands, size_t n_tables, int n_player
     ABI_GUARD_END("mcq_showdown")
 }
 
+int mcq_exact_batch(mcq_ctx *c, const mcq_query *q, size_t n, int law, mcq_result *out) {
+    ABI_GUARD_BEGIN
+    if (!c) return fail(MCQ_EINVAL, "mcq_exact_batch: null context");
+    if (n == 0) return MCQ_OK;
+    if (!q || !out) return fail(MCQ_EINVAL, "mcq_exact_batch: null buffer");
+    if (law != MCQ_LAW_REFERENCE && law != MCQ_LAW_UNIFORM) return fail(MCQ_EINVAL, "mcq_exact_batch: bad law");
+    if (n > 0x7fffffffu) return fail(MCQ_EINVAL, "mcq_exact_batch: n too large");
+    int rc = validate(q, n);
+    if (rc) return rc;
+    for (size_t i = 0; i < n; i++)
+        if (q[i].n_players > 3)
+            return fail(MCQ_EINVAL, "mcq_exact_batch: exact enumeration covers 1 to 3 players");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(c->d_res.reserve(n * sizeof(mcq_result)));
+    HIP_TRY(c->h_res.reserve(n * sizeof(mcq_result)));
+    HIP_TRY(hipMemsetAsync(c->d_res.p, 0, n * sizeof(mcq_result), c->stream));
+    for (size_t i = 0; i < n; i++)
+        HIP_TRY(mcq_launch_exact(&q[i], law, (mcq_result *)c->d_res.p + i, c->d_luts, (uint32_t)c->n_cu, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_res.p, c->d_res.p, n * sizeof(mcq_result), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(out, c->h_res.p, n * sizeof(mcq_result));
+    return MCQ_OK;
+    ABI_GUARD_END("mcq_exact_batch")
+}
+
 }  // extern "C"

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include "mcq_device.hpp"
+#include "mcq_exact.hpp"
 #include "mcq_internal.hpp"
 
 namespace {
@@ -411,6 +412,75 @@ __global__ __launch_bounds__(256) void mcq_showdown_kernel(const uint8_t *__rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------- exact enumeration
+// one query per launch, see mcq_exact.hpp.  Work unit = (table completion, slice of first
+// opponent hands); a wave takes units wave, wave + n_waves, ...  Per-lane 64-bit sums by role: lane 0 total
+// weight (-> runs), lane 2 strict wins, lane 3 ties, lane 4 + t hero's winning hand type t; one atomic each
+// at the end.
+template <bool TWO_OPP>
+__global__ __launch_bounds__(TWO_OPP ? 384 : 512) void mcq_exact_kernel(uint4 raw, int law, uint32_t n_boards,
+                                                                        uint32_t slices, mcq_result *__restrict__ row,
+                                                                        const McqTables *__restrict__ g_tab) {
+    constexpr uint32_t kWaves = TWO_OPP ? 6u : 8u;
+    __shared__ __attribute__((aligned(16))) LdsTables tab;
+    __shared__ uint16_t pair_xy[MCQ_EXACT_PAIRS + 2];
+    __shared__ McqCard rem_card_all[kWaves][64];
+    __shared__ uint32_t rem_pos_all[kWaves][64];
+    __shared__ uint32_t keys_all[TWO_OPP ? kWaves : 1u][TWO_OPP ? MCQ_EXACT_PAIRS + 2 : 1u];
+    __shared__ uint16_t rec_all[TWO_OPP ? kWaves : 1u][TWO_OPP ? MCQ_EXACT_PAIRS + 2 : 1u];
+    load_tables(tab, g_tab);
+    for (uint32_t i = threadIdx.x; i < MCQ_EXACT_PAIRS; i += blockDim.x) {
+        uint32_t x, y;
+        mcq_exact_pair_xy(i, x, y);
+        pair_xy[i] = (uint16_t)(x | (y << 8));
+    }
+    __syncthreads();
+
+    const McqQueryWords q = {raw.x, raw.y, raw.z, raw.w};
+    McqExactQuery e;
+    if (!mcq_exact_query(q, law, e)) return; /* the host has validated the query */
+    const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * kWaves + wib);
+    const uint32_t n_waves = gridDim.x * kWaves;
+    McqCard *rem_card = rem_card_all[wib];
+    uint32_t *rem_pos = rem_pos_all[wib];
+    uint32_t *keys = TWO_OPP ? keys_all[wib] : nullptr;
+    uint16_t *rec = TWO_OPP ? rec_all[wib] : nullptr;
+
+    unsigned long long sum = 0;
+    const uint64_t n_units = (uint64_t)n_boards * slices;
+    for (uint64_t unit = wave; unit < n_units; unit += n_waves) {
+        const uint32_t board = (uint32_t)(unit / slices), slice = (uint32_t)(unit % slices);
+        uint32_t pos[5];
+        mcq_exact_unrank(board, e.L, e.k, pos);
+        McqExactBoard bd;
+        mcq_exact_board(e, pos, tab.sel8, tab.tf, tab.tops, tab.sd, bd);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); /* the previous unit's reads are done (same wave) */
+        if (lane < MCQ_EXACT_REM) {
+            const uint32_t rp = mcq_exact_rem_pos(e, pos, lane);
+            rem_pos[lane] = rp;
+            rem_card[lane] = mcq_card(mcq_exact_card_at(e, rp, tab.sel8));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        McqExactAcc acc = {0, 0, 0};
+        mcq_exact_pass_a(e, bd, lane, pair_xy, rem_card, rem_pos, tab.tf, tab.tops, tab.sd, keys, rec, acc);
+        if (TWO_OPP) {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            mcq_exact_pass_b(e, bd, lane, MCQ_EXACT_PAIRS * slice / slices, MCQ_EXACT_PAIRS * (slice + 1u) / slices,
+                             pair_xy, keys, rec, acc);
+        }
+        const uint32_t win = wave_sum(acc.win), tie = wave_sum(acc.tie), tot = wave_sum(acc.tot);
+        const uint32_t type = mcq_key_type(bd.hero_key);
+        if (lane == 0u) sum += tot;
+        if (lane == 2u) sum += win;
+        if (lane == 3u) sum += tie;
+        if (lane == 4u + type) sum += win + tie;
+    }
+    if (lane < 13u && sum != 0ull) atomicAdd(reinterpret_cast<unsigned long long *>(row) + lane, sum);
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------- launchers
@@ -465,6 +535,26 @@ hipError_t mcq_launch_showdown(const uint8_t *d_hands, uint32_t n_tables, uint32
     if (grid == 0) grid = 1;
     hipLaunchKernelGGL(mcq_showdown_kernel, dim3(grid), dim3(256), 0, s, d_hands, n_tables, n_players, d_luts,
                        d_winner, d_wtype, d_keys);
+    return hipGetLastError();
+}
+
+hipError_t mcq_launch_exact(const mcq_query *q, int law, mcq_result *d_row, const McqTables *d_luts, uint32_t n_cu,
+                            hipStream_t s) {
+    uint4 raw;
+    __builtin_memcpy(&raw, q, 16);
+    const uint32_t L = 50u - q->n_board, k = 5u - q->n_board;
+    const uint32_t n_boards = mcq_exact_binom(L, k);
+    if (q->n_players == 3) {
+        /* few completions (turn, river): cut the first-opponent loop so that every wave has work */
+        uint32_t slices = 1;
+        while (slices < 64u && (uint64_t)n_boards * slices < 6ull * n_cu * 4ull) slices *= 2u;
+        const uint64_t units = (uint64_t)n_boards * slices;
+        const uint32_t grid = (uint32_t)((units + 5u) / 6u < n_cu ? (units + 5u) / 6u : n_cu);
+        hipLaunchKernelGGL(mcq_exact_kernel<true>, dim3(grid), dim3(384), 0, s, raw, law, n_boards, slices, d_row, d_luts);
+    } else {
+        const uint32_t grid = (n_boards + 7u) / 8u < n_cu ? (n_boards + 7u) / 8u : n_cu;
+        hipLaunchKernelGGL(mcq_exact_kernel<false>, dim3(grid), dim3(512), 0, s, raw, law, n_boards, 1u, d_row, d_luts);
+    }
     return hipGetLastError();
 }
 

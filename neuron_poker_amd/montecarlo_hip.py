@@ -33,7 +33,7 @@ import numpy as np
 from . import _lib
 from .cards import TYPES, card_id
 
-__all__ = ["get_equity", "get_equity_batch", "MonteCarlo", "seed", "configure"]
+__all__ = ["get_equity", "get_equity_batch", "get_equity_exact", "MonteCarlo", "seed", "configure"]
 
 _state = {"seed": int.from_bytes(os.urandom(8), "little"), "counter": 0, "couple_numpy": False,
           "mode": _lib.MODE_REPLAY_MT19937 if os.environ.get("MCQ_MODE", "philox").lower() == "replay"
@@ -196,3 +196,14 @@ def get_equity_batch(hole, board, n_players, runs, seed=None, first_query_id=0, 
     runs_f = np.maximum(tallies[:, 0], 1).astype(np.float64)
     equity = (tallies[:, 2] + tallies[:, 3]).astype(np.float64) / runs_f
     return equity, tallies
+
+
+def get_equity_exact(player_cards, table_cards, players, dealing="reference", engine=None):
+    """The number get_equity() converges to, by exhaustive enumeration on the GPU (1 to 3 players).
+
+    dealing='reference': the exact expectation of tools/montecarlo_python.py's dealing (index bias included);
+    'uniform': every remaining card equally likely (what montecarlo_cython.pyx / Montecarlo.cpp intend and
+    tools/montecarlo_cpp/Test.cpp:176-217 checks within 1 %).  -> (equity, result row of integer weights)."""
+    q = _query(list(player_cards), list(table_cards), players, 1)
+    res = (engine or _lib.default_engine()).exact(q, dealing)[0]
+    return (int(res["win"]) + int(res["tie"])) / int(res["runs"]), res

@@ -10,6 +10,7 @@ _SO = os.path.join(_HERE, "libmcq_hostsim.so")
 _SRCS = [os.path.join(_HERE, "hostsim.cpp"),
          os.path.join(_HERE, "..", "..", "neuron_poker_amd", "csrc", "mcq_device.hpp"),
          os.path.join(_HERE, "..", "..", "neuron_poker_amd", "csrc", "mcq_replay.hpp"),
+         os.path.join(_HERE, "..", "..", "neuron_poker_amd", "csrc", "mcq_exact.hpp"),
          os.path.join(_HERE, "..", "..", "include", "mcq.h")]
 _lib = None
 
@@ -18,7 +19,7 @@ def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in _SRCS):
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-shared", "-fPIC", "-o", _SO, _SRCS[0]])
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Wno-unknown-pragmas", "-Wno-maybe-uninitialized", "-shared", "-fPIC", "-o", _SO, _SRCS[0]])
         L = C.CDLL(_SO)
         L.hs_select_pop.restype = C.c_uint32
         _lib = L
@@ -100,6 +101,16 @@ def run_ext(replay, query16, ext64, seed, qid=0):
     lib().hs_run_ext.restype = C.c_int
     rc = lib().hs_run_ext(C.c_int(1 if replay else 0), _p(q, C.c_uint8), _p(e, C.c_uint8), C.c_uint64(seed),
                           C.c_uint64(qid), _p(out, C.c_uint64))
+    if rc:
+        raise ValueError(rc)
+    return out
+
+
+def exact(query16, uniform=False):
+    """Exact enumeration by the product's lane code (mcq_exact.hpp) -> 13 weights like a result row."""
+    q = np.ascontiguousarray(query16, np.uint8)
+    out = np.zeros(13, np.uint64)
+    rc = lib().hs_exact(_p(q, C.c_uint8), C.c_int(1 if uniform else 0), _p(out, C.c_uint64))
     if rc:
         raise ValueError(rc)
     return out

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../neuron_poker_amd/csrc/mcq_device.hpp"
+#include "../../neuron_poker_amd/csrc/mcq_exact.hpp"
 #include "../../neuron_poker_amd/csrc/mcq_replay.hpp"
 
 namespace {
@@ -209,3 +210,49 @@ extern "C" int hs_run_ext(int replay, const mcq_query *q, const mcq_query_ext *e
     return MCQ_OK;
 }
 
+
+// exact enumeration (mcq_exact.hpp) walked like mcq_exact_kernel: completion by completion, pass A then pass B,
+// the 64 lanes one after the other
+extern "C" int hs_exact(const mcq_query *q, int law, uint64_t *out13) {
+    const McqTables &t = luts();
+    McqExactQuery e;
+    if (!mcq_exact_query(mcq_query_words(*q), law, e)) return -1;
+    std::vector<uint16_t> pair_xy(MCQ_EXACT_PAIRS), rec(MCQ_EXACT_PAIRS);
+    std::vector<uint32_t> keys(MCQ_EXACT_PAIRS);
+    for (uint32_t i = 0; i < MCQ_EXACT_PAIRS; i++) {
+        uint32_t x, y;
+        mcq_exact_pair_xy(i, x, y);
+        pair_xy[i] = (uint16_t)(x | (y << 8));
+    }
+    for (int k = 0; k < 13; k++) out13[k] = 0;
+    const uint32_t n_boards = mcq_exact_binom(e.L, e.k);
+    const bool two = e.n_opp == 2;
+    for (uint32_t board = 0; board < n_boards; board++) {
+        uint32_t pos[5];
+        mcq_exact_unrank(board, e.L, e.k, pos);
+        McqExactBoard bd;
+        mcq_exact_board(e, pos, t.sel8, t.tf, t.tops, t.sd, bd);
+        McqCard rem_card[64];
+        uint32_t rem_pos[64];
+        for (uint32_t l = 0; l < MCQ_EXACT_REM; l++) {
+            rem_pos[l] = mcq_exact_rem_pos(e, pos, l);
+            rem_card[l] = mcq_card(mcq_exact_card_at(e, rem_pos[l], t.sel8));
+        }
+        uint64_t win = 0, tie = 0, tot = 0;
+        McqExactAcc acc[64];
+        for (uint32_t lane = 0; lane < 64; lane++) {
+            acc[lane] = {0, 0, 0};
+            mcq_exact_pass_a(e, bd, lane, pair_xy.data(), rem_card, rem_pos, t.tf, t.tops, t.sd,
+                             two ? keys.data() : nullptr, rec.data(), acc[lane]);
+        }
+        if (two)
+            for (uint32_t lane = 0; lane < 64; lane++)
+                mcq_exact_pass_b(e, bd, lane, 0, MCQ_EXACT_PAIRS, pair_xy.data(), keys.data(), rec.data(), acc[lane]);
+        for (uint32_t lane = 0; lane < 64; lane++) { win += acc[lane].win; tie += acc[lane].tie; tot += acc[lane].tot; }
+        out13[0] += tot;
+        out13[2] += win;
+        out13[3] += tie;
+        out13[4 + mcq_key_type(bd.hero_key)] += win + tie;
+    }
+    return 0;
+}

@@ -491,3 +491,78 @@ def test_small_batch_task_split_does_not_change_tallies():
             os.environ.pop("MCQ_SPLIT_MAX", None)
         else:
             os.environ["MCQ_SPLIT_MAX"] = old
+
+
+# ---- exact enumeration on the GPU (mcq_exact_batch)
+def _xq(hero, board, n):
+    b = [O.card_id(c) for c in board]
+    return npa.pack_queries([[O.card_id(c) for c in hero]], [b + [255] * (5 - len(b))], n, 1)
+
+
+def test_exact_enumeration_gpu_equals_host_lane_code_and_oracle(eng):
+    from tests import hostsim as H
+    from tests.test_lane_arithmetic_host import EXACT_CASES
+    cases = EXACT_CASES + [(["TC", "TH"], ["4D", "QD", "KC", "2S"], 3), (["9C", "8C"], ["7C", "6D", "2S"], 3)]
+    q = np.concatenate([_xq(*c) for c in cases])
+    for law, uniform in (("reference", False), ("uniform", True)):
+        got = eng.exact(q, law).view(np.uint64).reshape(-1, 13)
+        for i, (hero, board, n) in enumerate(cases):
+            if not (n == 3 and len(board) == 3):       # 1081 completions x 990 x 990: too slow for the host walk
+                want = H.exact(q[i:i + 1].view(np.uint8).reshape(16), uniform)
+                assert np.array_equal(got[i], want), (cases[i], law)
+            if len(board) == 5 or (n == 2 and len(board) >= 3):
+                win, tie, _ = O.exact(hero, board, n, uniform)
+                assert abs(int(got[i][2]) / int(got[i][0]) - win) < 1e-9 and abs(int(got[i][3]) / int(got[i][0]) - tie) < 1e-9
+            assert int(got[i][4:].sum()) == int(got[i][2] + got[i][3])
+
+
+def test_exact_enumeration_preflop_known_values_and_symmetry(eng):
+    """Heads-up preflop = 2.1e9 showdowns.  Uniform law: the textbook all-in equities vs a random hand (ties
+    counted half there; here ties are the hero's, so compare win + tie/2), and invariance under relabelling suits.
+    Reference law: total weight in closed form."""
+    from math import comb
+    q = np.concatenate([_xq(["AH", "KH"], [], 2), _xq(["AS", "KS"], [], 2), _xq(["AS", "AD"], [], 2),
+                        _xq(["7C", "2D"], [], 2)])
+    u = eng.exact(q, "uniform").view(np.uint64).reshape(-1, 13).astype(np.int64)
+    assert (u[:, 0] == comb(50, 5) * 990).all()
+    assert np.array_equal(u[0], u[1])                                      # AhKh == AsKs
+    half = (u[:, 2] + u[:, 3] / 2) / u[:, 0]
+    assert abs(half[0] - 0.6704) < 3e-4 and abs(half[2] - 0.8520) < 3e-4 and abs(half[3] - 0.346) < 5e-4
+    r = eng.exact(q, "reference").view(np.uint64).reshape(-1, 13).astype(np.int64)
+    assert (r[:, 0] == 49 ** 2 * comb(47, 5)).all()
+    assert not np.array_equal(r[0][2:4] * u[1][0], u[0][2:4] * r[0][0])    # the index bias is real ...
+    assert abs((r[0][2] + r[0][3]) / r[0][0] - 0.659) < 2e-3               # ... AhKh 0.659 vs 0.680 (SURVEY 8c)
+
+
+def test_production_rng_converges_to_exact_enumeration(eng):
+    """The strongest form of gate B: 1e9 iterations of the production RNG against the exact expectation of the
+    reference's dealing law (not another Monte-Carlo run): |delta| <= 1e-4 (~6.7 sigma of the MC error alone)."""
+    q = _xq(["AH", "KH"], [], 2)
+    x = eng.exact(q, "reference")[0]
+    exact = (int(x["win"]) + int(x["tie"])) / int(x["runs"])
+    qq = np.repeat(q, 250)
+    qq["runs"] = 4_000_000
+    r = eng.eval_batch(qq, seed=20261004)
+    mc = (int(r["win"].sum()) + int(r["tie"].sum())) / int(r["runs"].sum())
+    assert abs(mc - exact) <= 1e-4, (mc, exact)
+    # three players on the flop, uniform law
+    q3 = _xq(["9C", "8C"], ["7C", "6D", "2S"], 3)
+    x3 = eng.exact(q3, "uniform")[0]
+    eng.set_dealing_law("uniform")
+    try:
+        q3r = np.repeat(q3, 64)
+        q3r["runs"] = 2_000_000
+        r3 = eng.eval_batch(q3r, seed=5)
+    finally:
+        eng.set_dealing_law("reference")
+    assert abs((int(r3["win"].sum()) + int(r3["tie"].sum())) / int(r3["runs"].sum())
+               - (int(x3["win"]) + int(x3["tie"])) / int(x3["runs"])) <= 3e-4
+
+
+def test_exact_enumeration_rejects_what_it_cannot_do(eng):
+    with pytest.raises(ValueError):
+        eng.exact(_xq(["AH", "KH"], [], 4))
+    with pytest.raises(ValueError):
+        eng.exact(_xq(["AH", "KH"], ["AH", "2C", "3C"], 2))
+    eq, row = mh.get_equity_exact({"AH", "KH"}, {"2C", "7D", "9S", "JH", "QC"}, 2)
+    assert int(row["runs"]) == 44 ** 2 and 0 < eq < 1

@@ -172,3 +172,45 @@ def test_extended_queries_replay_equals_reference_and_ctr_equals_oracle():
         got = H.run_ext(False, small, ext, 99, qid=4)
         exp = O.run_ex(O.MODE_CTR, t["players"][0], t["board"], t["n_players"], 700, 99, qid=4, **kw)["tallies"]
         assert np.array_equal(got, exp), t
+
+
+# ---- exact enumeration (csrc/mcq_exact.hpp): the set-based weighting against the oracle's literal walk of the
+# dealing tree (every accepted index pair, every table draw), both laws, 1-3 players
+EXACT_CASES = [(["AH", "KH"], ["2C", "7D", "9S", "JH", "QC"], 2), (["AH", "KH"], ["2C", "7D", "9S", "JH"], 2),
+               (["AS", "KS"], ["2C", "7D", "9S", "JH"], 2),        # hero holds the deck's top card
+               (["2C", "2D"], ["AS", "KS", "QH", "3C"], 2),        # top cards on the table
+               (["AS", "AD"], ["2C", "7D", "9S"], 2), (["7C", "2D"], ["AS", "KS", "AH"], 2),
+               (["AH", "KH"], ["2C", "7D", "9S", "JH", "QC"], 3), (["2C", "2D"], ["AS", "KS", "QS", "JS", "9D"], 3),
+               (["AS", "KD"], ["2C", "7D", "9S", "JH", "QC"], 1), (["AS", "KD"], ["2C", "7D", "9S", "JH"], 1),
+               (["AS", "KD"], ["2C", "7D", "9S"], 1)]
+
+
+def _xq(hero, board, n):
+    b = [O.card_id(c) for c in board]
+    return O.pack_queries([[O.card_id(c) for c in hero]], [b + [255] * (5 - len(b))], n, 1)[0]
+
+
+@pytest.mark.parametrize("hero,board,n", EXACT_CASES)
+@pytest.mark.parametrize("uniform", [False, True])
+def test_exact_enumeration_equals_the_oracles_tree_walk(hero, board, n, uniform):
+    g = H.exact(_xq(hero, board, n), uniform)
+    win, tie, _ = O.exact(hero, board, n, uniform)
+    tot = int(g[0])
+    assert abs(int(g[2]) / tot - win) < 1e-9 and abs(int(g[3]) / tot - tie) < 1e-9   # the oracle sums doubles
+    assert int(g[4:].sum()) == int(g[2] + g[3]) and g[1] == 0
+    L, k = 50 - len(board), 5 - len(board)
+    from math import comb
+    if uniform:
+        want = comb(L, k) * [1, 990, 990 * 903][n - 1]
+    else:  # accepted index pairs per opponent x completions without the highest remaining card
+        want = [1, (L - 1) ** 2, (L - 1) ** 2 * (L - 3) ** 2][n - 1] * (comb(L - 2 * (n - 1) - 1, k) if k else 1)
+    assert tot == want
+
+
+def test_exact_enumeration_three_players_on_the_turn():
+    # 137 M leaves in the oracle's walk (most of a minute); the product's weighting visits 46 completions
+    hero, board = ["TC", "TH"], ["4D", "QD", "KC", "2S"]
+    for uniform in (False,):
+        g = H.exact(_xq(hero, board, 3), uniform)
+        win, tie, _ = O.exact(hero, board, 3, uniform)
+        assert abs(int(g[2]) / int(g[0]) - win) < 1e-9 and abs(int(g[3]) / int(g[0]) - tie) < 1e-9
