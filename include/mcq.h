@@ -141,6 +141,13 @@ MCQ_API int mcq_eval_batch_device(mcq_ctx *ctx, const void *d_queries, size_t n,
 MCQ_API int mcq_showdown(mcq_ctx *ctx, const uint8_t *hands, size_t n_tables, int n_players, uint8_t *winner,
                  uint8_t *winner_type, uint32_t *keys);
 
+/* One share of a batch whose ITERATIONS are split over several devices (few large queries).  Every query
+ * is cut at task boundaries (1024 iterations) into n_parts contiguous ranges; this call evaluates range `part` of
+ * every query under the same streams (seed, first_query_id + i) an unsplit call uses, so the rows of all parts add
+ * up -- runs included -- to exactly what mcq_eval_batch returns.  MCQ_MODE_PHILOX only. */
+MCQ_API int mcq_eval_batch_part(mcq_ctx *ctx, const mcq_query *q, size_t n, uint64_t seed, uint64_t first_query_id,
+                                uint32_t part, uint32_t n_parts, mcq_result *out);
+
 /* Exact equity by exhaustive enumeration (what tools/montecarlo_cpp/Test.cpp:176-217 approximates with
  * 1 % bands): every opponent hand and every completion of the table, weighted as the dealing law `law` (MCQ_LAW_*)
  * deals them -- for MCQ_LAW_REFERENCE the exact distribution of tools/montecarlo_python.py:121-189, index bias

@@ -82,6 +82,8 @@ def load_library():
         L.mcq_destroy.restype = None
         L.mcq_eval_batch.argtypes = [vp, vp, sz, u64, u64, C.c_int, vp]
         L.mcq_eval_batch.restype = C.c_int
+        L.mcq_eval_batch_part.argtypes = [vp, vp, sz, u64, u64, C.c_uint32, C.c_uint32, vp]
+        L.mcq_eval_batch_part.restype = C.c_int
         L.mcq_eval_one.argtypes = [vp, vp, u64, C.c_int, vp]
         L.mcq_eval_one.restype = C.c_int
         L.mcq_eval_batch_ext.argtypes = [vp, vp, vp, sz, u64, u64, C.c_int, vp]
@@ -225,12 +227,21 @@ class Engine:
         if rc:
             _raise(rc)
 
-    def eval_batch(self, queries, seed, first_query_id=0, mode=MODE_PHILOX):
-        """queries: array of QUERY_DTYPE (host).  -> array of RESULT_DTYPE."""
+    def eval_batch(self, queries, seed, first_query_id=0, mode=MODE_PHILOX, part=None):
+        """queries: array of QUERY_DTYPE (host).  -> array of RESULT_DTYPE.
+        part=(p, n): only share p of n of every query's iterations (mcq_eval_batch_part; the rows of all shares
+        add up to the unsplit result)."""
         q = np.ascontiguousarray(queries, dtype=QUERY_DTYPE).reshape(-1)
         out = np.zeros(len(q), RESULT_DTYPE)
-        rc = self._lib.mcq_eval_batch(self._ctx, q.ctypes.data, len(q), int(seed) & (2 ** 64 - 1),
-                                      int(first_query_id) & (2 ** 64 - 1), int(mode), out.ctypes.data)
+        if part is not None:
+            if mode != MODE_PHILOX:
+                raise ValueError("only the production mode can split the iterations of a query")
+            rc = self._lib.mcq_eval_batch_part(self._ctx, q.ctypes.data, len(q), int(seed) & (2 ** 64 - 1),
+                                               int(first_query_id) & (2 ** 64 - 1), int(part[0]), int(part[1]),
+                                               out.ctypes.data)
+        else:
+            rc = self._lib.mcq_eval_batch(self._ctx, q.ctypes.data, len(q), int(seed) & (2 ** 64 - 1),
+                                          int(first_query_id) & (2 ** 64 - 1), int(mode), out.ctypes.data)
         if rc:
             _raise(rc)
         return out

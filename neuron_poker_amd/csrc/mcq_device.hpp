@@ -474,6 +474,20 @@ MCQ_HD uint32_t mcq_task_count(const McqQueryWords &q) { /* no overflow for runs
     return q.runs() / MCQ_TASK_ITERS + (q.runs() % MCQ_TASK_ITERS != 0u ? 1u : 0u);
 }
 
+// Share `part` of `n_parts` of a query: tasks [t_lo, t_hi) of its `tasks` tasks and the iterations they hold.
+// The shares of all parts tile the query, so their tallies add up to the unsplit result (mcq_eval_batch_part).
+struct McqPart {
+    uint32_t t_lo, t_hi, runs;
+};
+MCQ_HD McqPart mcq_part(uint32_t tasks, uint32_t runs, uint32_t part, uint32_t n_parts) {
+    McqPart p;
+    p.t_lo = (uint32_t)((uint64_t)tasks * part / n_parts);
+    p.t_hi = (uint32_t)((uint64_t)tasks * (part + 1u) / n_parts);
+    const uint64_t a = (uint64_t)p.t_lo * MCQ_TASK_ITERS, b = (uint64_t)p.t_hi * MCQ_TASK_ITERS;
+    p.runs = (uint32_t)((b < runs ? b : runs) - (a < runs ? a : runs));
+    return p;
+}
+
 static inline McqQueryWords mcq_query_words(const mcq_query &q) { /* host side */
     McqQueryWords w;
     __builtin_memcpy(&w, &q, 16);

@@ -146,16 +146,16 @@ void pick_geometry(const mcq_ctx *c, int mode, uint64_t total_tasks, uint32_t *g
 
 int run_slice(mcq_ctx *c, int mode, const mcq_query *d_q, uint32_t n, mcq_result *d_res, uint64_t seed,
               uint64_t first_qid, uint64_t total_tasks, const uint8_t *d_draws, const uint64_t *d_off, hipStream_t s,
-              bool timed, uint64_t max_tasks = 0) {
+              bool timed, uint64_t max_tasks = 0, uint32_t part = 0, uint32_t n_parts = 1) {
     if (mode == MCQ_MODE_PHILOX && c->law == MCQ_LAW_UNIFORM) mode = MCQ_INTERNAL_MODE_UNIFORM;
     HIP_TRY(c->d_prefix.reserve(((size_t)n + 1) * sizeof(uint64_t)));
-    HIP_TRY(mcq_launch_prep(d_q, n, d_res, (uint64_t *)c->d_prefix.p, s));
+    HIP_TRY(mcq_launch_prep(d_q, n, d_res, (uint64_t *)c->d_prefix.p, part, n_parts, s));
     uint32_t grid, block, split;
     pick_geometry(c, mode, total_tasks, &grid, &block, &split, max_tasks);
     const int slot = (int)(c->n_timed % mcq_ctx::kRing);
     if (timed) HIP_TRY(hipEventRecord(c->ev0[slot], s));
     HIP_TRY(mcq_launch_eval(mode, d_q, n, (const uint64_t *)c->d_prefix.p, d_res, seed, first_qid, c->d_luts, d_draws,
-                            d_off, grid, block, split, s));
+                            d_off, grid, block, split, part, n_parts, s));
     if (timed) {
         HIP_TRY(hipEventRecord(c->ev1[slot], s));
         c->n_timed++;
@@ -403,22 +403,27 @@ int mcq_eval_batch_device(mcq_ctx *c, const void *d_queries, size_t n, uint64_t 
     ABI_GUARD_END("mcq_eval_batch_device")
 }
 
-int mcq_eval_batch(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed, uint64_t first_query_id, int mode,
-                   mcq_result *out) {
-    ABI_GUARD_BEGIN
-    if (mode != MCQ_MODE_PHILOX && mode != MCQ_MODE_REPLAY_MT19937) return fail(MCQ_EINVAL, "mcq_eval_batch: bad mode");
+static int eval_batch_impl(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed, uint64_t first_query_id, int mode,
+                           uint32_t part, uint32_t n_parts, mcq_result *out, const char *who) {
+    if (mode != MCQ_MODE_PHILOX && mode != MCQ_MODE_REPLAY_MT19937) return fail(MCQ_EINVAL, who, "bad mode");
+    if (n_parts == 0 || part >= n_parts) return fail(MCQ_EINVAL, who, "part must be < n_parts");
+    if (n_parts > 1 && mode != MCQ_MODE_PHILOX)
+        return fail(MCQ_EINVAL, who, "only MCQ_MODE_PHILOX can split the iterations of a query");
     if (n == 0) return MCQ_OK;
-    int rc = stage_queries(c, q, n, out, "mcq_eval_batch");
+    int rc = stage_queries(c, q, n, out, who);
     if (rc) return rc;
     uint64_t total_tasks = 0, max_tasks = 0;
     for (size_t i = 0; i < n; i++) {
-        total_tasks += tasks_of(q[i]);
-        if (tasks_of(q[i]) > max_tasks) max_tasks = tasks_of(q[i]);
+        const McqPart pt = mcq_part(tasks_of(q[i]), q[i].runs, part, n_parts);
+        const uint64_t t = pt.t_hi - pt.t_lo;
+        total_tasks += t;
+        if (t > max_tasks) max_tasks = t;
     }
 
     if (mode == MCQ_MODE_PHILOX) {
+        if (total_tasks == 0) total_tasks = 1; /* 0 means "unknown" to pick_geometry */
         rc = run_slice(c, mode, (const mcq_query *)c->d_q.p, (uint32_t)n, (mcq_result *)c->d_res.p, seed,
-                       first_query_id, total_tasks, nullptr, nullptr, c->stream, true, max_tasks);
+                       first_query_id, total_tasks, nullptr, nullptr, c->stream, true, max_tasks, part, n_parts);
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(c->h_res.p, c->d_res.p, n * sizeof(mcq_result), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -428,7 +433,20 @@ int mcq_eval_batch(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed, uint
     }
 
     return replay_batch(c, q, n, seed, first_query_id, nullptr, out);
+}
+
+int mcq_eval_batch(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed, uint64_t first_query_id, int mode,
+                   mcq_result *out) {
+    ABI_GUARD_BEGIN
+    return eval_batch_impl(c, q, n, seed, first_query_id, mode, 0, 1, out, "mcq_eval_batch");
     ABI_GUARD_END("mcq_eval_batch")
+}
+
+int mcq_eval_batch_part(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed, uint64_t first_query_id,
+                        uint32_t part, uint32_t n_parts, mcq_result *out) {
+    ABI_GUARD_BEGIN
+    return eval_batch_impl(c, q, n, seed, first_query_id, MCQ_MODE_PHILOX, part, n_parts, out, "mcq_eval_batch_part");
+    ABI_GUARD_END("mcq_eval_batch_part")
 }
 
 int mcq_eval_one(mcq_ctx *c, const mcq_query *q, uint64_t seed, int mode, mcq_result *out) {

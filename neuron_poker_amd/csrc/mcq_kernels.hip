@@ -56,7 +56,8 @@ __device__ __forceinline__ void load_tables(LdsTables &dst, const McqTables *__r
 // scheduling cost (tasks x weight; prefix[n] = total).  Invalid queries cost nothing and get runs = 0,
 // passes = UINT64_MAX.
 __global__ __launch_bounds__(1024) void mcq_prep_kernel(const mcq_query *__restrict__ q, uint32_t n,
-                                                        mcq_result *__restrict__ res, uint64_t *__restrict__ prefix) {
+                                                        mcq_result *__restrict__ res, uint64_t *__restrict__ prefix,
+                                                        uint32_t part_idx, uint32_t n_parts) {
     __shared__ uint64_t part[1024];
     __shared__ uint64_t carry;
     const uint32_t tid = threadIdx.x;
@@ -69,9 +70,12 @@ __global__ __launch_bounds__(1024) void mcq_prep_kernel(const mcq_query *__restr
             const uint4 raw = reinterpret_cast<const uint4 *>(q)[i];
             const McqQueryWords qq = {raw.x, raw.y, raw.z, raw.w};
             bool ok = mcq_query_valid(qq);
-            cost = ok ? (uint64_t)mcq_task_count(qq) * mcq_task_weight(qq) : 0ull;
+            /* this launch's share of the query: tasks [t_lo, t_hi) (everything unless the iterations are split
+             * over devices, mcq_eval_batch_part) */
+            const McqPart pt = mcq_part(mcq_task_count(qq), qq.runs(), part_idx, n_parts);
+            cost = ok ? (uint64_t)(pt.t_hi - pt.t_lo) * mcq_task_weight(qq) : 0ull;
             uint64_t *r = reinterpret_cast<uint64_t *>(res + i);
-            r[0] = ok ? qq.runs() : 0ull;
+            r[0] = ok ? pt.runs : 0ull;
             r[1] = ok ? 0ull : ~0ull;
 #pragma unroll
             for (int k = 2; k < 13; k++) r[k] = 0;
@@ -139,7 +143,8 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
                                                              mcq_result *__restrict__ res, uint64_t seed,
                                                              uint64_t first_qid, const McqTables *__restrict__ g_tab,
                                                              const uint8_t *__restrict__ draws,
-                                                             const uint64_t *__restrict__ draw_off, uint32_t split_arg) {
+                                                             const uint64_t *__restrict__ draw_off, uint32_t split_arg,
+                                                             uint32_t part, uint32_t n_parts) {
     const uint32_t split = SPLIT ? split_arg : 0u; /* SPLIT = false: the bulk path, compiled without the cut */
     /* split (0..4): small batches cut every 1024-iteration task into 2^split sub-tasks of 16 >> split iterations per
      * lane so that more waves share the work; the iterations and their random numbers stay the same (a sub-task
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
         if ((prefix[mid] << split) <= lo) a = mid; else b = mid;
     }
     uint32_t qi = __builtin_amdgcn_readfirstlane(a);
-    uint32_t task = 0, n_tasks = 0, weight = 1;
+    uint32_t task = 0, task0 = 0, n_tasks = 0, weight = 1; /* tasks [task0, n_tasks) of the query are this launch's */
     uint64_t pfx = 0;
     McqQueryCtx qc;
     WaveTally tally;
@@ -178,10 +183,12 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
             const McqQueryWords q = {raw.x, raw.y, raw.z, raw.w};
             pfx = prefix[qi] << split;
             const bool ok = (prefix[qi + 1] << split) > pfx; /* zero cost: invalid or runs == 0 */
-            n_tasks = ok ? mcq_task_count(q) << split : 0u;
+            const McqPart pt = mcq_part(mcq_task_count(q), q.runs(), part, n_parts);
+            task0 = pt.t_lo << split;
+            n_tasks = ok ? pt.t_hi << split : 0u;
             weight = mcq_task_weight(q);
-            task = 0;
-            if (pfx < lo) task = (uint32_t)((lo - pfx + weight - 1) / weight); /* only for the first query */
+            task = task0;
+            if (pfx < lo) task = task0 + (uint32_t)((lo - pfx + weight - 1) / weight); /* only for the first query */
             fresh = false;
             if (ok) {
                 mcq_query_ctx(q, qc);
@@ -197,7 +204,7 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
             fresh = true;
             continue;
         }
-        if (pfx + (uint64_t)task * weight >= hi) break;
+        if (pfx + (uint64_t)(task - task0) * weight >= hi) break;
 
         McqLaneAcc acc = {0, 0, 0};
         if (MODE != MCQ_MODE_REPLAY_MT19937) {
@@ -484,23 +491,26 @@ __global__ __launch_bounds__(TWO_OPP ? 384 : 512) void mcq_exact_kernel(uint4 ra
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------- launchers
-hipError_t mcq_launch_prep(const mcq_query *d_q, uint32_t n, mcq_result *d_res, uint64_t *d_prefix, hipStream_t s) {
-    hipLaunchKernelGGL(mcq_prep_kernel, dim3(1), dim3(1024), 0, s, d_q, n, d_res, d_prefix);
+hipError_t mcq_launch_prep(const mcq_query *d_q, uint32_t n, mcq_result *d_res, uint64_t *d_prefix, uint32_t part,
+                           uint32_t n_parts, hipStream_t s) {
+    if (n_parts == 0 || part >= n_parts) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mcq_prep_kernel, dim3(1), dim3(1024), 0, s, d_q, n, d_res, d_prefix, part, n_parts);
     return hipGetLastError();
 }
 
 hipError_t mcq_launch_eval(int mode, const mcq_query *d_q, uint32_t n, const uint64_t *d_prefix, mcq_result *d_res,
                            uint64_t seed, uint64_t first_qid, const McqTables *d_luts, const uint8_t *d_draws,
-                           const uint64_t *d_draw_off, uint32_t grid, uint32_t block, uint32_t split, hipStream_t s) {
-    if (split > 4) return hipErrorInvalidValue;
+                           const uint64_t *d_draw_off, uint32_t grid, uint32_t block, uint32_t split, uint32_t part,
+                           uint32_t n_parts, hipStream_t s) {
+    if (split > 4 || n_parts == 0 || part >= n_parts) return hipErrorInvalidValue;
 #define MCQ_LAUNCH_EVAL(M)                                                                                        \
     do {                                                                                                          \
         if (split)                                                                                                \
             hipLaunchKernelGGL((mcq_eval_kernel<M, true>), dim3(grid), dim3(block), 0, s, d_q, n, d_prefix, d_res, \
-                               seed, first_qid, d_luts, d_draws, d_draw_off, split);                              \
+                               seed, first_qid, d_luts, d_draws, d_draw_off, split, part, n_parts);               \
         else                                                                                                      \
             hipLaunchKernelGGL((mcq_eval_kernel<M, false>), dim3(grid), dim3(block), 0, s, d_q, n, d_prefix, d_res, \
-                               seed, first_qid, d_luts, d_draws, d_draw_off, 0u);                                 \
+                               seed, first_qid, d_luts, d_draws, d_draw_off, 0u, part, n_parts);                  \
     } while (0)
     if (mode == MCQ_MODE_PHILOX) MCQ_LAUNCH_EVAL(MCQ_MODE_PHILOX);
     else if (mode == MCQ_INTERNAL_MODE_UNIFORM) MCQ_LAUNCH_EVAL(MCQ_INTERNAL_MODE_UNIFORM);

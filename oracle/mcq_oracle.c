@@ -489,6 +489,28 @@ int mcqo_run(int mode, const uint8_t *hero, const uint8_t *board, int nb, int n_
     return 0;
 }
 
+/* Iterations [it_begin, it_end) of a CTR-mode query (mode 1 or 2): what one share of an iteration-split batch
+ * (include/mcq.h mcq_eval_batch_part) must return.  The stream of it_begin is walked from its start. */
+int mcqo_run_range(int mode, const uint8_t *hero, const uint8_t *board, int nb, int n_players, uint64_t seed,
+                   uint64_t qid, uint32_t it_begin, uint32_t it_end, uint64_t *out) {
+    if (mode < 1 || !valid_query(hero, board, nb, n_players)) return -1;
+    mt_t mt;
+    xo_t xo;
+    rng_t rng = {mode, &mt, &xo};
+    uint8_t hands[70];
+    uint64_t scratch[13];
+    memset(out, 0, 13 * sizeof(uint64_t));
+    for (uint32_t it = it_begin - it_begin % STREAM_ITERS; it < it_end; it++) {
+        if (it % STREAM_ITERS == 0) xo_seed(&xo, seed, qid, it / STREAM_ITERS);
+        uint64_t passes = deal_iteration(&rng, hero, board, nb, n_players, hands);
+        uint64_t *dst = it >= it_begin ? out : scratch;
+        dst[1] += passes;
+        dst[0]++;
+        tally(dst, hands, n_players);
+    }
+    return 0;
+}
+
 /* batch: query i = {hole[2], board[5], n_board, n_players, runs(u32 LE)} (16 bytes, the C-ABI's mcq_query);
  * MT mode seeds query i with (uint32)(seed + first_qid + i); CTR mode uses query id first_qid + i.
  * out[n][13].  threads >= 1 (pthreads, queries interleaved).  Used as the timed CPU baseline. */

@@ -62,6 +62,9 @@ def lib():
         L.mcqo_run.argtypes = [C.c_int, u8p, u8p, C.c_int, C.c_int, C.c_uint32, C.c_uint64, C.c_uint64, u64p, u8p,
                                C.c_uint32, C.POINTER(C.c_uint16), u64p]
         L.mcqo_run.restype = C.c_int
+        L.mcqo_run_range.argtypes = [C.c_int, u8p, u8p, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
+                                     u64p]
+        L.mcqo_run_range.restype = C.c_int
         L.mcqo_run_batch.argtypes = [C.c_int, u8p, C.c_size_t, C.c_uint64, C.c_uint64, u64p, C.c_int]
         L.mcqo_run_batch.restype = C.c_int
         L.mcqo_run_ex.argtypes = [C.c_int, u8p, u32p, u8p, u8p, u8p, C.c_int, C.c_int, C.c_uint32, C.c_uint64, C.c_uint64,
@@ -172,6 +175,22 @@ def run_batch(mode, queries, seed, first_qid=0, threads=1):
     rc = lib().mcqo_run_batch(mode, _p(q, C.c_uint8), len(q), seed, first_qid, _p(out, C.c_uint64), threads)
     if rc:
         raise ValueError("invalid query in batch")
+    return out
+
+
+def run_batch_part(mode, queries, seed, first_qid, part, n_parts):
+    """What mcq_eval_batch_part must return: for every query the iterations of tasks [T*part//n, T*(part+1)//n)
+    (T = ceil(runs / 1024) tasks of 1024 iterations)."""
+    q = np.ascontiguousarray(queries, np.uint8).reshape(-1, 16)
+    out = np.zeros((len(q), 13), np.uint64)
+    for i, r in enumerate(q):
+        runs = int(r[12:16].view("<u4")[0])
+        tasks = (runs + 1023) // 1024
+        a, b = min(runs, 1024 * (tasks * part // n_parts)), min(runs, 1024 * (tasks * (part + 1) // n_parts))
+        rc = lib().mcqo_run_range(mode, _p(r[0:2].copy(), C.c_uint8), _p(r[2:7].copy(), C.c_uint8), int(r[7]), int(r[8]),
+                                  seed, first_qid + i, a, b, _p(out[i], C.c_uint64))
+        if rc:
+            raise ValueError("invalid query")
     return out
 
 

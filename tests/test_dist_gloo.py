@@ -1,4 +1,5 @@
-"""The N > 1 path on CPU: world_size-2 gloo process group, queries block-sharded, one integer all-reduce.
+"""The N > 1 path on CPU: world_size-2 gloo process group, queries block-sharded or iterations split, one integer
+all-reduce.
 The per-rank evaluator here is the ORACLE (tests may use it as the checker's stand-in; the product's GPU
 evaluator is exercised with the same sharding in tests/test_gpu_parity.py::test_shard_invariance...)."""
 import os
@@ -25,12 +26,16 @@ def _batch():
         cards = g.choice(52, 2 + b, replace=False)
         hole.append(cards[:2])
         board.append(list(cards[2:]) + [255] * (5 - b))
-    return pack_queries(hole, board, 6, 700)
+    runs = [700, 5000, 1024, 3073][:] * 10
+    return pack_queries(hole, board, 6, runs[:B])
 
 
 def _oracle_eval(mode):
-    def f(q, seed, first):
-        return O.run_batch(mode, np.ascontiguousarray(q).view(np.uint8).reshape(-1, 16), seed, first)
+    def f(q, seed, first, part=None):
+        raw = np.ascontiguousarray(q).view(np.uint8).reshape(-1, 16)
+        if part is not None:
+            return O.run_batch_part(mode, raw, seed, first, part[0], part[1])
+        return O.run_batch(mode, raw, seed, first)
     return f
 
 
@@ -40,9 +45,11 @@ def _worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         q = _batch()
-        for mode in (O.MODE_CTR, O.MODE_MT):
-            t = sharding.eval_batch_sharded(q, 77, _oracle_eval(mode), first_query_id=1000)
+        for mode in (O.MODE_CTR, O.MODE_MT):   # the parity mode cannot split a query's iterations
+            t = sharding.eval_batch_sharded(q, 77, _oracle_eval(mode), first_query_id=1000, split="queries")
             np.save(os.path.join(out_dir, "t_%d_%d.npy" % (mode, rank)), t)
+        t = sharding.eval_batch_sharded(q, 77, _oracle_eval(O.MODE_CTR), first_query_id=1000)   # 37 < 2 * 256
+        np.save(os.path.join(out_dir, "t_iter_%d.npy" % rank), t)
     finally:
         dist.destroy_process_group()
 
@@ -75,6 +82,18 @@ def test_two_rank_gloo_allreduce_equals_single_rank(tmp_path):
         for r in range(world):
             got = np.load(os.path.join(str(tmp_path), "t_%d_%d.npy" % (mode, r)))
             assert np.array_equal(got, exp), (mode, r)
+    exp = _oracle_eval(O.MODE_CTR)(q, 77, 1000)
+    for r in range(world):   # iterations split over the ranks: same tallies, runs included
+        assert np.array_equal(np.load(os.path.join(str(tmp_path), "t_iter_%d.npy" % r)), exp), r
+
+
+def test_iteration_shares_tile_a_query():
+    q = _batch()[:8]
+    raw = np.ascontiguousarray(q).view(np.uint8).reshape(-1, 16)
+    whole = O.run_batch(O.MODE_CTR, raw, 5, 10)
+    for n_parts in (1, 2, 3, 8):
+        parts = [O.run_batch_part(O.MODE_CTR, raw, 5, 10, p, n_parts) for p in range(n_parts)]
+        assert np.array_equal(sum(parts), whole), n_parts
 
 
 def test_single_process_without_group():

@@ -566,3 +566,39 @@ def test_exact_enumeration_rejects_what_it_cannot_do(eng):
         eng.exact(_xq(["AH", "KH"], ["AH", "2C", "3C"], 2))
     eq, row = mh.get_equity_exact({"AH", "KH"}, {"2C", "7D", "9S", "JH", "QC"}, 2)
     assert int(row["runs"]) == 44 ** 2 and 0 < eq < 1
+
+
+def test_iteration_shares_add_up_to_the_unsplit_result(eng):
+    """SURVEY 8e, few large queries: every device takes one contiguous share of each query's iterations
+    (mcq_eval_batch_part).  Each share == the oracle's tallies of exactly those iterations; the shares of 2, 3 and
+    8 devices add up -- runs included -- to the unsplit call, bit for bit."""
+    rng = np.random.default_rng(8)
+    runs = [100000, 1, 1024, 1025, 20000, 3073, 64, 5000]
+    hole, board, npl = [], [], []
+    for i in range(len(runs)):
+        c = rng.permutation(52)[:7]
+        nb = [0, 3, 4, 5][i % 4]
+        hole.append(c[:2])
+        board.append(list(c[2:2 + nb]) + [255] * (5 - nb))
+        npl.append(2 + i % 5)
+    q = npa.pack_queries(hole, board, npl, runs)
+    raw = q.view(np.uint8).reshape(-1, 16)
+    whole = eng.eval_batch(q, 99, first_query_id=7).view(np.uint64).reshape(-1, 13)
+    assert np.array_equal(whole, O.run_batch(O.MODE_CTR, raw, 99, first_qid=7, threads=8))
+    for n_parts in (2, 3, 8):
+        total = np.zeros_like(whole)
+        for p in range(n_parts):
+            got = eng.eval_batch(q, 99, first_query_id=7, part=(p, n_parts)).view(np.uint64).reshape(-1, 13)
+            if n_parts == 3:
+                assert np.array_equal(got, O.run_batch_part(O.MODE_CTR, raw, 99, 7, p, n_parts)), p
+            total += got
+        assert np.array_equal(total, whole), n_parts
+    with pytest.raises(ValueError):
+        eng.eval_batch(q, 99, part=(2, 2))
+    with pytest.raises(ValueError):
+        eng.eval_batch(q, 99, mode=npa.MODE_REPLAY_MT19937, part=(0, 2))
+    # one query of 2e8 iterations over "8 devices": the same tallies as in one piece
+    big = npa.pack_queries([[50, 46]], [[255] * 5], 2, 200_000_000)
+    one = eng.eval_batch(big, 3).view(np.uint64).reshape(-1, 13)
+    eight = sum(eng.eval_batch(big, 3, part=(p, 8)).view(np.uint64).reshape(-1, 13) for p in range(8))
+    assert np.array_equal(one, eight)
