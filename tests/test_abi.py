@@ -61,3 +61,21 @@ def test_card_notation():
     for bad in ("ah", "1H", "AHH", "", 5):
         with pytest.raises(ValueError):
             npa.card_id(bad)
+
+
+def test_header_is_plain_c_and_layouts_match_the_binding(tmp_path):
+    """examples/equity.c (C99, -pedantic -Werror) compiles against include/mcq.h, links against the library, and
+    reports the record layouts the ctypes binding assumes."""
+    import subprocess
+    from neuron_poker_amd import build
+    build.build()
+    exe = str(tmp_path / "equity")
+    lib = npa.library_path()
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "equity.c"), "-o", exe, lib,
+                           "-Wl,-rpath," + os.path.dirname(lib)])
+    out = subprocess.check_output([exe, "--layout"]).split()
+    t = _lib.TABLES_CONFIG_DTYPE
+    assert [int(x) for x in out] == [_lib.QUERY_DTYPE.itemsize, _lib.RESULT_DTYPE.itemsize, _lib.QUERY_EXT_DTYPE.itemsize,
+                                     t.itemsize, t.fields["seed"][1], t.fields["seat_kind"][1],
+                                     t.fields["min_call_equity"][1]]

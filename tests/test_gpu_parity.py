@@ -602,3 +602,18 @@ def test_iteration_shares_add_up_to_the_unsplit_result(eng):
     one = eng.eval_batch(big, 3).view(np.uint64).reshape(-1, 13)
     eight = sum(eng.eval_batch(big, 3, part=(p, 8)).view(np.uint64).reshape(-1, 13) for p in range(8))
     assert np.array_equal(one, eight)
+
+
+def test_c_example_runs_against_the_c_abi(tmp_path):
+    """examples/equity.c: the ABI from plain C (no Python, no torch) -- Monte-Carlo, exact and the table driver."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe, lib = str(tmp_path / "equity"), npa.library_path()
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "equity.c"),
+                           "-o", exe, lib, "-Wl,-rpath," + os.path.dirname(lib)])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    assert "100000 iterations" in lines[0] and abs(float(lines[0].split("equity ")[1].split()[0]) - 0.6598) < 0.006
+    assert "0.659833" in lines[1]
+    assert lines[2].startswith("512 tables, 1000 lock-steps") and "512000 equity queries" in lines[2]
