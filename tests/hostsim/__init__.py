@@ -6,7 +6,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libmcq_hostsim.so")
+_SO = os.environ.get("MCQ_HOSTSIM_SO", os.path.join(_HERE, "libmcq_hostsim.so"))   # override: tools/sanitize_cpu.sh
 _SRCS = [os.path.join(_HERE, "hostsim.cpp"),
          os.path.join(_HERE, "..", "..", "neuron_poker_amd", "csrc", "mcq_device.hpp"),
          os.path.join(_HERE, "..", "..", "neuron_poker_amd", "csrc", "mcq_replay.hpp"),
@@ -18,7 +18,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in _SRCS):
+        if "MCQ_HOSTSIM_SO" not in os.environ and (not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in _SRCS)):
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Wno-unknown-pragmas", "-Wno-maybe-uninitialized", "-shared", "-fPIC", "-o", _SO, _SRCS[0]])
         L = C.CDLL(_SO)
         L.hs_select_pop.restype = C.c_uint32

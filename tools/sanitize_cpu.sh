@@ -1,0 +1,34 @@
+#!/bin/bash
+# AddressSanitizer + UBSan over everything that runs on the host: the oracle, the host build of the lane code
+# (tests/hostsim) and the native table driver (csrc/mcq_tables.cpp, linked against stubs of the GPU entry points).
+# GPU sanitizers are not available on this pool; this is the CPU build only.   usage: tools/sanitize_cpu.sh
+set -e
+R=$(cd "$(dirname "$0")/.." && pwd); T=${TMPDIR:-/tmp}/mcq_san; mkdir -p $T
+F="-O1 -g -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -shared -fPIC"
+python3 - "$R" "$T" <<'PY'
+import re, sys
+R, T = sys.argv[1:]
+h = open(R + "/include/mcq.h").read()
+decls = re.findall(r"MCQ_API\s+([\w\s\*]+?)\b(mcq_\w+)\s*\(([^;]*?)\)\s*;", h, re.S)
+own = {"mcq_tables_create", "mcq_tables_destroy", "mcq_tables_begin", "mcq_tables_resume", "mcq_tables_run",
+       "mcq_tables_stats", "mcq_tables_state", "mcq_last_error"}
+out = ['#include "mcq.h"', '#include <string>', 'static thread_local std::string g_err;', 'extern "C" {',
+       'const char *mcq_last_error(void) { return g_err.c_str(); }',
+       'int mcq_tables_set_error(const char *m) { g_err = m; return MCQ_EINVAL; }']
+for ret, name, args in decls:
+    if name in own:
+        continue
+    ret = ret.strip()
+    body = "" if ret == "void" else ("return 0;" if "*" in ret or ret in ("float", "size_t") or name == "mcq_device_count"
+                                     else "return MCQ_EDEVICE;")
+    out.append("%s %s(%s) { %s }" % (ret, name, " ".join(args.split()), body))
+open(T + "/stub.cpp", "w").write("\n".join(out) + "\n}\n")
+PY
+gcc $F -o $T/libmcq_oracle.so $R/oracle/mcq_oracle.c -lpthread
+g++ $F -std=c++17 -Wno-unknown-pragmas -o $T/libmcq_hostsim.so $R/tests/hostsim/hostsim.cpp
+g++ $F -std=c++17 -Wno-unknown-pragmas -I$R/include -o $T/libmcq_san.so $T/stub.cpp $R/neuron_poker_amd/csrc/mcq_tables.cpp -lpthread
+cd $R
+LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0 \
+MCQ_ORACLE_SO=$T/libmcq_oracle.so MCQ_HOSTSIM_SO=$T/libmcq_hostsim.so MCQ_LIBRARY=$T/libmcq_san.so \
+python3 -m pytest tests/test_oracle_golden.py tests/test_lane_arithmetic_host.py tests/test_table_driver.py -x -q \
+  -k "not three_players_on_the_turn" -p no:cacheprovider "$@"
