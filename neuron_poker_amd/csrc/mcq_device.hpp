@@ -79,6 +79,15 @@ MCQ_HD uint32_t mcq_opaque(uint32_t x) {
 #endif
     return x;
 }
+// The same for a wave-uniform value (device: pins it in an SGPR).  A condition computed from it is evaluated
+// where it is used (one scalar compare) instead of being carried across blocks as a lane mask, which the
+// compiler rebuilds with VALU instructions.
+MCQ_HD uint32_t mcq_opaque_uniform(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(x));
+#endif
+    return x;
+}
 MCQ_HD uint32_t mcq_bfe(uint32_t x, uint32_t off, uint32_t width) { /* (x >> off) & ((1 << width) - 1), off + width <= 32 */
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_ubfe(x, off, width);
@@ -226,7 +235,7 @@ struct McqCtrDrawsT {
     MCQ_HDM void pair(uint32_t L, uint32_t &r1, uint32_t &r2) {
         const uint32_t dd = L - 1u, m1 = UNIFORM ? L : dd;
         const uint32_t u = rng.next();
-        const uint32_t a = mcq_mulhi_p128(u, m1);
+        const uint32_t a = mcq_opaque(mcq_mulhi_p128(u, m1)); /* opaque: else a == c becomes a 64-bit compare + moves */
         const uint32_t c = mcq_mulhi_p128(u * m1, dd);
         r1 = (!UNIFORM && a == c) ? dd + 128u : a;
         r2 = c;
@@ -558,17 +567,32 @@ MCQ_HD uint32_t mcq_draw_opp(uint32_t rp, uint32_t (&H)[5]) {
     return mcq_opaque(k); /* materialise k so that the table address is one shift-add */
 }
 
-// table draw number K (0..4): scans the opponents' holes (n_regs registers, wave-uniform) and the K earlier table holes
-template <int K>
-MCQ_HD uint32_t mcq_draw_table(uint32_t rp, uint32_t (&H)[5], uint32_t &hb, uint32_t n_regs) {
+// table draw number K (0..4): scans the opponents' holes (NREGS registers) and the K earlier table holes.
+// NREGS is a template parameter: with a run-time bound the compiler scans all five registers and discards the
+// unused ones with selects (7 instructions per register instead of 0).
+template <int K, int NREGS>
+MCQ_HD uint32_t mcq_draw_table(uint32_t rp, uint32_t (&H)[5], uint32_t &hb) {
     uint32_t k = rp;
     const uint32_t rb = mcq_splat_byte(rp);
 #pragma unroll
-    for (int i = 0; i < 5; i++)
-        if ((uint32_t)i < n_regs) mcq_hole_reg(rb, H[i], k);
+    for (int i = 0; i < NREGS; i++) mcq_hole_reg(rb, H[i], k);
     if (K > 0) mcq_hole_reg(rb, hb, k);
     if (K < 4) mcq_hole_put<K>(hb, rb); /* the hole of a fifth table card is never looked at */
     return mcq_opaque(k);
+}
+
+// the missing table cards (montecarlo_python.py:185-189) after opponents whose holes fill NREGS registers
+template <int NREGS, class Draws>
+MCQ_HD void mcq_deal_table(const McqQueryCtx &qc, Draws &dr, const McqCard *base128, uint32_t (&H)[5], uint32_t L,
+                           McqBoard &b) {
+    uint32_t hb = MCQ_HOLE_SENTINEL;
+#define MCQ_TABLE(K)                                                                                            \
+    if (K < qc.n_deal) {                                                                                        \
+        b.add(base128[mcq_draw_table<K, NREGS>(dr.template table<K>(L - Draws::kTableShort), H, hb)]); /* l.188 */ \
+        L -= 1;                                                                                                 \
+    }
+    MCQ_TABLE(0) MCQ_TABLE(1) MCQ_TABLE(2) MCQ_TABLE(3) MCQ_TABLE(4)
+#undef MCQ_TABLE
 }
 
 // One Monte-Carlo iteration of one lane.  The opponents' hole cards stay in registers (statically indexed:
@@ -579,7 +603,6 @@ template <class Draws>
 MCQ_HD void mcq_iteration(const McqQueryCtx &qc, Draws &dr, const McqCard *base128, const uint32_t *tf,
                           const uint32_t *tops, const uint32_t *sd, McqLaneAcc &acc) {
     uint32_t H[5] = {MCQ_HOLE_SENTINEL, MCQ_HOLE_SENTINEL, MCQ_HOLE_SENTINEL, MCQ_HOLE_SENTINEL, MCQ_HOLE_SENTINEL};
-    uint32_t hb = MCQ_HOLE_SENTINEL;
     uint32_t L = qc.L0;
     McqHole opp[MCQ_MAX_OPP];
 #define MCQ_OPP(P)                                                                                             \
@@ -593,21 +616,22 @@ MCQ_HD void mcq_iteration(const McqQueryCtx &qc, Draws &dr, const McqCard *base1
     }
     MCQ_OPP(0) MCQ_OPP(1) MCQ_OPP(2) MCQ_OPP(3) MCQ_OPP(4) MCQ_OPP(5) MCQ_OPP(6) MCQ_OPP(7) MCQ_OPP(8)
 #undef MCQ_OPP
-    const uint32_t n_regs = (2u * qc.n_opp + 3u) / 4u;
     McqBoard b = qc.board;
-#define MCQ_TABLE(K)                                                                                           \
-    if (K < qc.n_deal) {                                                                                       \
-        b.add(base128[mcq_draw_table<K>(dr.template table<K>(L - Draws::kTableShort), H, hb, n_regs)]); /* l.188 */ \
-        L -= 1;                                                                                                \
+    switch (mcq_opaque_uniform((2u * qc.n_opp + 3u) / 4u)) { /* registers holding the opponents' holes: wave-uniform */
+        case 0: mcq_deal_table<0>(qc, dr, base128, H, L, b); break;
+        case 1: mcq_deal_table<1>(qc, dr, base128, H, L, b); break;
+        case 2: mcq_deal_table<2>(qc, dr, base128, H, L, b); break;
+        case 3: mcq_deal_table<3>(qc, dr, base128, H, L, b); break;
+        case 4: mcq_deal_table<4>(qc, dr, base128, H, L, b); break;
+        default: mcq_deal_table<5>(qc, dr, base128, H, L, b); break;
     }
-    MCQ_TABLE(0) MCQ_TABLE(1) MCQ_TABLE(2) MCQ_TABLE(3) MCQ_TABLE(4)
-#undef MCQ_TABLE
     McqFlushSel fs;
     fs.from_board(b);
     const uint32_t hk = mcq_eval_key(b, fs, qc.hero, tf, tops, sd);
     uint32_t best = 0;
+    const uint32_t n_opp_e = mcq_opaque_uniform(qc.n_opp); /* a fresh scalar compare per block, see mcq_opaque_uniform */
 #define MCQ_EVAL(P)                                                        \
-    if (P < qc.n_opp) {                                                    \
+    if (P < n_opp_e) {                                                     \
         const uint32_t k = mcq_eval_key(b, fs, opp[P], tf, tops, sd);     \
         best = k > best ? k : best;                                        \
     }
