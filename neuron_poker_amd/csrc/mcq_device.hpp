@@ -586,8 +586,9 @@ template <int NREGS, class Draws>
 MCQ_HD void mcq_deal_table(const McqQueryCtx &qc, Draws &dr, const McqCard *base128, uint32_t (&H)[5], uint32_t L,
                            McqBoard &b) {
     uint32_t hb = MCQ_HOLE_SENTINEL;
+    const uint32_t n_deal = mcq_opaque_uniform(qc.n_deal); /* scalar compares, no lane masks kept in SGPR pairs */
 #define MCQ_TABLE(K)                                                                                            \
-    if (K < qc.n_deal) {                                                                                        \
+    if (K < n_deal) {                                                                                           \
         b.add(base128[mcq_draw_table<K, NREGS>(dr.template table<K>(L - Draws::kTableShort), H, hb)]); /* l.188 */ \
         L -= 1;                                                                                                 \
     }
@@ -605,8 +606,9 @@ MCQ_HD void mcq_iteration(const McqQueryCtx &qc, Draws &dr, const McqCard *base1
     uint32_t H[5] = {MCQ_HOLE_SENTINEL, MCQ_HOLE_SENTINEL, MCQ_HOLE_SENTINEL, MCQ_HOLE_SENTINEL, MCQ_HOLE_SENTINEL};
     uint32_t L = qc.L0;
     McqHole opp[MCQ_MAX_OPP];
+    const uint32_t n_opp_d = mcq_opaque_uniform(qc.n_opp);
 #define MCQ_OPP(P)                                                                                             \
-    if (P < qc.n_opp) {                                                                                        \
+    if (P < n_opp_d) {                                                                                         \
         uint32_t r1, r2;                                                                                       \
         dr.pair(L, r1, r2); /* r1 in [0,L-1], r2 in [0,L-2], r1 != r2 (l.167-176), both | 0x80 */              \
         const McqCard c1 = base128[mcq_draw_opp<2 * P>(r1, H)];     /* deck.pop(r1) (l.178) */                 \
