@@ -214,7 +214,7 @@ def main():
                    "hand_evals_per_step": evals_per_step},
         "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_VALU_TOPS, "unit": "Tops/s (int32 lane-ops)",
                      "frac": achieved / PEAK_VALU_TOPS, "traffic": traffic,
-                     "kernel": "mcq_eval_kernel<PHILOX>", "kernel_ms": kernel_ms,
+                     "kernel": "mcq_eval_kernel<0, false>", "kernel_ms": kernel_ms,
                      "alg_ops_per_iteration": alg_ops_per_iteration(N, 0),
                      "hbm": {"algorithmic_bytes_per_launch": B * 120,
                              "achieved_GBps": B * 120 / (kernel_ms * 1e-3) / 1e9, "peak_GBps": HBM_PEAK_GBPS}},
@@ -244,7 +244,7 @@ def main():
         # BASELINE configs[4], equity side only: one lock-step of 512 six-seat tables issues <= 2 x 512 queries of 1000
         # runs (gym_env/env.py:22,261-262) in ONE call; state mix as observed in reference episodes (SURVEY 8c F5:
         # table cards 0/3/4/5 = 59/19/11/10 %, players alive 2..6 = 41/28/17/9/6 %).  The table logic itself is
-        # not part of this number (not built yet).
+        # not part of this number; the whole loop is measured below.
         g = np.random.default_rng(512)
         nb = g.choice([0, 3, 4, 5], size=1024, p=[0.59, 0.19, 0.11, 0.11])
         npl = g.choice([2, 3, 4, 5, 6], size=1024, p=[0.41, 0.28, 0.17, 0.09, 0.05])
@@ -263,6 +263,20 @@ def main():
         extras["configs[4]_equity_side_only_1024x1000"] = {"call_ms_host_buffers": 1e3 * dt, "kernel_ms": eng.last_kernel_ms,
                                                            "hand_evals_per_s": float((npl * 1000).sum()) / dt,
                                                            "lock_steps_per_s": 1.0 / dt}
+        # BASELINE configs[4], the whole loop: 512 six-seat tables (seats as main.py:142-145 + two random seats) driven
+        # by the native lock-step driver (mcq_tables_run): table rules on the host, ONE equity batch per lock-step
+        seats = [("equity", .5, -.5), ("equity", .8, -.8), ("equity", .7, -.7), ("equity", .2, -.3), ("random",), ("random",)]
+        tb = npa.Tables(eng, 512, seats, runs=1000, initial_stacks=100, small_blind=1, big_blind=2, seed=5)
+        tb.run(50)
+        s0 = tb.stats()
+        t1 = time.perf_counter()
+        tb.run(2000)
+        dt = time.perf_counter() - t1
+        s1 = tb.stats()
+        extras["configs[4]_native_driver_512_tables"] = {"lock_steps": 2000, "ms_per_lock_step": 1e3 * dt / 2000,
+                                                         "env_steps_per_s": (s1["env_steps"] - s0["env_steps"]) / dt,
+                                                         "equity_queries_per_s": (s1["queries"] - s0["queries"]) / dt}
+        tb.close()
         out["other_configs"] = extras
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(N, runs)
