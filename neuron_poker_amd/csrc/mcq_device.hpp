@@ -134,16 +134,22 @@ MCQ_HD uint32_t mcq_straight_runs(uint32_t m) {
 // All mask-indexed tables are addressed with x4-domain masks (m4 = m << 2):
 //   tops[m] (u32, byte offset m4):  top two set bits of m (x4 domain, 0 if fewer than two) | top bit << 16
 //   sd[m]   (u32, byte offset m4):  (straight ? 0x80 | top position 1..10 : 0) << 23, i.e. the complete
-//           Straight key, | m without its two lowest set bits (x4 domain; the kickers of HighCard/Pair/Trips)
+//           Straight key, | m without its two lowest set bits (x4 domain)
+//   sd[8192 + m] ("kc", byte offset 32768 + m4, folded into the read instruction's offset field): the low part of
+//           the HighCard / Pair / ThreeOfAKind key when m is the mask of the ranks held exactly once: m without
+//           its two lowest set bits (the kickers that count) | the type code << 28, which the number of kickers
+//           gives away for seven cards: 7 -> HighCard, 5 -> Pair, 4 -> ThreeOfAKind; any other count belongs to a
+//           higher type whose own candidate key wins (code 0 here)
 //   tf[m]   (u32, byte offset m4):  complete key of the SUIT mask m: StraightFlush (all ranks of the suit
 //           plus the -1 slot when it holds the ace, hand_evaluator.py:71-80,93), Flush (top five, :98-100), or 0
 //           when popcount(m) < 5
 struct McqTables {
     uint32_t tf[8192];
     uint32_t tops[8192];
-    uint32_t sd[8192];
+    uint32_t sd[16384]; /* [0, 8192) sd, [8192, 16384) kc */
     uint32_t sel8[256];
 };
+#define MCQ_KC_BYTE_OFFSET 32768u
 
 static inline void mcq_fill_tables(McqTables *t) {
     for (uint32_t v = 0; v < 256; v++) {
@@ -159,6 +165,7 @@ static inline void mcq_fill_tables(McqTables *t) {
         uint32_t d2 = m & (m - 1);
         d2 &= d2 - 1; /* m == 0 stays 0 */
         t->sd[m] = (st << 23) | (d2 << 2);
+        t->sd[8192 + m] = (d2 << 2) | ((n == 5 ? (uint32_t)MCQ_C_PAIR : n == 4 ? (uint32_t)MCQ_C_TRIPS : 0u) << MCQ_KEY_SHIFT);
         uint32_t hi1 = m ? 0x80000000u >> __builtin_clz(m) : 0, hi2 = 0;
         if (n >= 2) hi2 = hi1 | (0x80000000u >> __builtin_clz(m ^ hi1));
         t->tops[m] = (hi2 << 2) | (hi1 << 18);
@@ -389,12 +396,11 @@ MCQ_HD uint32_t mcq_eval_key(const McqBoard &b, const McqFlushSel &fs, const Mcq
     const uint32_t e_ge2 = mcq_ld_u32(tops, ge2);
     const uint32_t e_ge3 = mcq_ld_u32(tops, ge3);
     const uint32_t d_any = mcq_ld_u32(sd, any);
-    const uint32_t d_kick = mcq_ld_u32(sd, any ^ ge2);
+    const uint32_t d_kick = mcq_ld_u32(sd, (any ^ ge2) + MCQ_KC_BYTE_OFFSET); /* kickers | type code of family F1 */
     const uint32_t key_f = mcq_ld_u32(tf, fs.bfl4 | mcq_bfe(fs.use_hi ? h.his : h.los, fs.sh, 16));
 
     const uint32_t key_s = d_any & 0xFF800000u;
-    const uint32_t key1 = (ge2 << 13) | (d_kick & 0x7FFCu) | (ge2 != 0 ? 1u << MCQ_KEY_SHIFT : 0u) |
-                          (ge3 != 0 ? 2u << MCQ_KEY_SHIFT : 0u);
+    const uint32_t key1 = (ge2 << 13) | d_kick;
 
     const bool fh = ge3 != 0;
     const uint32_t H = fh ? (e_ge3 >> 16) : (e_ge2 & 0xFFFFu);

@@ -19,7 +19,8 @@
 
 namespace {
 
-constexpr int kMaxBlock = 1024; /* 16 waves = 4 per SIMD; one block per CU: tables 97 KB + 16 base decks 16 KB of the 160 KB LDS */
+constexpr int kMaxBlock = 1024; /* 16 waves = 4 per SIMD; one block per CU: tables 129 KB + 16 base decks 16 KB of the 160 KB LDS */
+constexpr int kExtBlock = 512;  /* extended queries: 20 KB of dealt card ids beside the tables */
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
@@ -30,7 +31,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 struct LdsTables { /* per block */
     uint32_t tf[8192];
     uint32_t tops[8192];
-    uint32_t sd[8192];
+    uint32_t sd[16384]; /* sd | kc, see McqTables */
     uint32_t sel8[256];
 };
 static_assert(sizeof(LdsTables) == sizeof(McqTables), "table image is copied word by word");
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(1024) void mcq_prep_ext_kernel(const mcq_query *__r
 }
 
 template <int MODE>
-__global__ __launch_bounds__(kMaxBlock) void mcq_eval_ext_kernel(const mcq_query *__restrict__ queries,
+__global__ __launch_bounds__(kExtBlock) void mcq_eval_ext_kernel(const mcq_query *__restrict__ queries,
                                                                  const mcq_query_ext *__restrict__ ext, uint32_t n,
                                                                  const uint64_t *__restrict__ prefix,
                                                                  mcq_result *__restrict__ res, uint64_t seed,
@@ -293,8 +294,8 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_ext_kernel(const mcq_query
                                                                  const uint64_t *__restrict__ draw_off) {
     __shared__ __attribute__((aligned(16))) LdsTables tab;
     __shared__ McqCard cards[64];
-    __shared__ uint32_t sets[(kMaxBlock / 64) * 12]; /* per wave: hero_range[6], opp_range[6] */
-    __shared__ uint32_t ids[(MCQ_MAX_OPP + 1) * kMaxBlock];
+    __shared__ uint32_t sets[(kExtBlock / 64) * 12]; /* per wave: hero_range[6], opp_range[6] */
+    __shared__ uint32_t ids[(MCQ_MAX_OPP + 1) * kExtBlock];
     if (threadIdx.x < 64) cards[threadIdx.x] = mcq_card(threadIdx.x < 52 ? threadIdx.x : 0u);
     load_tables(tab, g_tab);
 
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_ext_kernel(const mcq_query
                 dr.rng.seed(seed, first_qid + qi, stream);
                 const uint32_t cnt = (uint32_t)min((uint64_t)MCQ_STREAM_ITERS, (uint64_t)qc.runs - it0);
                 for (uint32_t j = 0; j < cnt && !failed; j++)
-                    failed = !mcq_iteration_ext(qc, dr, cards, tab.sel8, my_sets, my_sets + 6, my_ids, kMaxBlock, tab.tf,
+                    failed = !mcq_iteration_ext(qc, dr, cards, tab.sel8, my_sets, my_sets + 6, my_ids, kExtBlock, tab.tf,
                                                 tab.tops, tab.sd, acc);
             }
         } else {
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_ext_kernel(const mcq_query
                 const uint64_t it = (uint64_t)task * MCQ_TASK_ITERS + j * MCQ_WAVE + lane;
                 if (it < qc.runs) {
                     McqExtReplayDraws dr = {dbase + it, stride};
-                    mcq_iteration_ext(qc, dr, cards, tab.sel8, my_sets, my_sets + 6, my_ids, kMaxBlock, tab.tf, tab.tops,
+                    mcq_iteration_ext(qc, dr, cards, tab.sel8, my_sets, my_sets + 6, my_ids, kExtBlock, tab.tf, tab.tops,
                                       tab.sd, acc);
                 }
             }
@@ -425,10 +426,10 @@ __global__ __launch_bounds__(256) void mcq_showdown_kernel(const uint8_t *__rest
 // weight (-> runs), lane 2 strict wins, lane 3 ties, lane 4 + t hero's winning hand type t; one atomic each
 // at the end.
 template <bool TWO_OPP>
-__global__ __launch_bounds__(TWO_OPP ? 384 : 512) void mcq_exact_kernel(uint4 raw, int law, uint32_t n_boards,
+__global__ __launch_bounds__(TWO_OPP ? 256 : 512) void mcq_exact_kernel(uint4 raw, int law, uint32_t n_boards,
                                                                         uint32_t slices, mcq_result *__restrict__ row,
                                                                         const McqTables *__restrict__ g_tab) {
-    constexpr uint32_t kWaves = TWO_OPP ? 6u : 8u;
+    constexpr uint32_t kWaves = TWO_OPP ? 4u : 8u; /* what fits beside the 129 KB of tables */
     __shared__ __attribute__((aligned(16))) LdsTables tab;
     __shared__ uint16_t pair_xy[MCQ_EXACT_PAIRS + 2];
     __shared__ McqCard rem_card_all[kWaves][64];
@@ -557,10 +558,10 @@ hipError_t mcq_launch_exact(const mcq_query *q, int law, mcq_result *d_row, cons
     if (q->n_players == 3) {
         /* few completions (turn, river): cut the first-opponent loop so that every wave has work */
         uint32_t slices = 1;
-        while (slices < 64u && (uint64_t)n_boards * slices < 6ull * n_cu * 4ull) slices *= 2u;
+        while (slices < 64u && (uint64_t)n_boards * slices < 4ull * n_cu * 4ull) slices *= 2u;
         const uint64_t units = (uint64_t)n_boards * slices;
-        const uint32_t grid = (uint32_t)((units + 5u) / 6u < n_cu ? (units + 5u) / 6u : n_cu);
-        hipLaunchKernelGGL(mcq_exact_kernel<true>, dim3(grid), dim3(384), 0, s, raw, law, n_boards, slices, d_row, d_luts);
+        const uint32_t grid = (uint32_t)((units + 3u) / 4u < n_cu ? (units + 3u) / 4u : n_cu);
+        hipLaunchKernelGGL(mcq_exact_kernel<true>, dim3(grid), dim3(256), 0, s, raw, law, n_boards, slices, d_row, d_luts);
     } else {
         const uint32_t grid = (n_boards + 7u) / 8u < n_cu ? (n_boards + 7u) / 8u : n_cu;
         hipLaunchKernelGGL(mcq_exact_kernel<false>, dim3(grid), dim3(512), 0, s, raw, law, n_boards, 1u, d_row, d_luts);
