@@ -134,7 +134,7 @@ MCQ_HD uint32_t mcq_straight_runs(uint32_t m) {
 // All mask-indexed tables are addressed with x4-domain masks (m4 = m << 2):
 //   tops[m] (u32, byte offset m4):  top two set bits of m (x4 domain, 0 if fewer than two) | top bit << 16
 //   sd[m]   (u32, byte offset m4):  (straight ? 0x80 | top position 1..10 : 0) << 23, i.e. the complete
-//           Straight key, | m without its two lowest set bits (x4 domain)
+//           Straight key (0 without a straight)
 //   sd[8192 + m] ("kc", byte offset 32768 + m4, folded into the read instruction's offset field): the low part of
 //           the HighCard / Pair / ThreeOfAKind key when m is the mask of the ranks held exactly once: m without
 //           its two lowest set bits (the kickers that count) | the type code << 28, which the number of kickers
@@ -143,13 +143,19 @@ MCQ_HD uint32_t mcq_straight_runs(uint32_t m) {
 //   tf[m]   (u32, byte offset m4):  complete key of the SUIT mask m: StraightFlush (all ranks of the suit
 //           plus the -1 slot when it holds the ace, hand_evaluator.py:71-80,93), Flush (top five, :98-100), or 0
 //           when popcount(m) < 5
-struct McqTables {
-    uint32_t tf[8192];
+struct McqTables { /* order matters on the device: the first 64 KB are reachable through the 16-bit offset field of
+                     the LDS read, i.e. the lookups whose index comes straight out of a logic instruction (tops,
+                     sd); the indices of kc and tf are formed by an xor / or that takes the table base along */
     uint32_t tops[8192];
     uint32_t sd[16384]; /* [0, 8192) sd, [8192, 16384) kc */
+    uint32_t tf[8192];
     uint32_t sel8[256];
 };
-#define MCQ_KC_BYTE_OFFSET 32768u
+#define MCQ_KC_BYTE_OFFSET 32768u /* kc relative to sd */
+#define MCQ_TF_BYTE_OFFSET 98304u /* tf relative to tops: the flush lookup goes through the tops pointer, its index
+                                     carries this offset from McqFlushSel on (no add per lookup) */
+static_assert(__builtin_offsetof(McqTables, tops) == 0 && __builtin_offsetof(McqTables, tf) == MCQ_TF_BYTE_OFFSET,
+              "McqTables layout");
 
 static inline void mcq_fill_tables(McqTables *t) {
     for (uint32_t v = 0; v < 256; v++) {
@@ -164,7 +170,7 @@ static inline void mcq_fill_tables(McqTables *t) {
         uint32_t n = (uint32_t)__builtin_popcount(m);
         uint32_t d2 = m & (m - 1);
         d2 &= d2 - 1; /* m == 0 stays 0 */
-        t->sd[m] = (st << 23) | (d2 << 2);
+        t->sd[m] = st << 23;
         t->sd[8192 + m] = (d2 << 2) | ((n == 5 ? (uint32_t)MCQ_C_PAIR : n == 4 ? (uint32_t)MCQ_C_TRIPS : 0u) << MCQ_KEY_SHIFT);
         uint32_t hi1 = m ? 0x80000000u >> __builtin_clz(m) : 0, hi2 = 0;
         if (n >= 2) hi2 = hi1 | (0x80000000u >> __builtin_clz(m ^ hi1));
@@ -364,7 +370,7 @@ struct McqFlushSel {
         const uint32_t f = (b.cnt + 0x5555u) & 0x8888u; /* bit 4s+3 <=> suit s has >= 3 table cards */
         use_hi = (f & 0x8800u) != 0;                     /* hearts or spades */
         sh = (f & 0x8080u) != 0 ? 16u : 0u;              /* diamonds or spades: upper half-word */
-        bfl4 = mcq_bfe(use_hi ? b.his : b.los, sh, 16);
+        bfl4 = mcq_bfe(use_hi ? b.his : b.los, sh, 16) | MCQ_TF_BYTE_OFFSET; /* index < 0x8000: no common bits */
     }
 };
 
@@ -397,9 +403,10 @@ MCQ_HD uint32_t mcq_eval_key(const McqBoard &b, const McqFlushSel &fs, const Mcq
     const uint32_t e_ge3 = mcq_ld_u32(tops, ge3);
     const uint32_t d_any = mcq_ld_u32(sd, any);
     const uint32_t d_kick = mcq_ld_u32(sd, (any ^ ge2) + MCQ_KC_BYTE_OFFSET); /* kickers | type code of family F1 */
-    const uint32_t key_f = mcq_ld_u32(tf, fs.bfl4 | mcq_bfe(fs.use_hi ? h.his : h.los, fs.sh, 16));
+    (void)tf; /* = tops + MCQ_TF_BYTE_OFFSET bytes, which fs.bfl4 already carries */
+    const uint32_t key_f = mcq_ld_u32(tops, fs.bfl4 | mcq_bfe(fs.use_hi ? h.his : h.los, fs.sh, 16));
 
-    const uint32_t key_s = d_any & 0xFF800000u;
+    const uint32_t key_s = d_any;
     const uint32_t key1 = (ge2 << 13) | d_kick;
 
     const bool fh = ge3 != 0;

@@ -28,10 +28,10 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
-struct LdsTables { /* per block */
-    uint32_t tf[8192];
+struct LdsTables { /* per block; same order as McqTables (copied word by word) */
     uint32_t tops[8192];
     uint32_t sd[16384]; /* sd | kc, see McqTables */
+    uint32_t tf[8192];
     uint32_t sel8[256];
 };
 static_assert(sizeof(LdsTables) == sizeof(McqTables), "table image is copied word by word");
