@@ -10,7 +10,7 @@
 // plus a few KB of table image per block.
 //
 // Memory: 16 B in / 104 B out per QUERY; per iteration nothing touches HBM in production mode (parity mode
-// reads <= 23 draw bytes).  LDS holds the lookup tables (97 KB per block) and one 64-entry base deck per wave.
+// reads <= 23 draw bytes).  LDS holds the lookup tables (129 KB per block) and one 64-entry base deck per wave.
 #include <hip/hip_runtime.h>
 
 #include "mcq_device.hpp"

@@ -8,7 +8,7 @@ if [ "$1" = build ]; then
   for v in $VARIANTS; do
     name=${v%%:*}; flags=$(echo ${v#*:} | tr ';' ' ')
     /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -fvisibility=hidden $flags \
-       -o gpurun_in/ablate/libmcq_$name.so neuron_poker_amd/csrc/mcq_host.cpp neuron_poker_amd/csrc/mcq_kernels.hip 2>/dev/null || echo "build $name failed"
+       -o gpurun_in/ablate/libmcq_$name.so neuron_poker_amd/csrc/mcq_host.cpp neuron_poker_amd/csrc/mcq_tables.cpp neuron_poker_amd/csrc/mcq_kernels.hip 2>/dev/null || echo "build $name failed"
   done
   ls -la gpurun_in/ablate
 else

@@ -2,7 +2,7 @@
 # on the GPU box: instruction counts per launch for each ablation variant
 R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out/prof; cd /tmp; export TMPDIR=/tmp
 for name in full EVAL HOLES RNG ALL; do
-  MCQ_LIBRARY=$R/gpurun_in/ablate/libmcq_$name.so rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS --output-format csv -d $R/gpurun_out/prof/ab_$name -o ab -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras $1 > $R/gpurun_out/prof/ab_$name.log 2>&1
+  MCQ_LIBRARY=$R/gpurun_in/ablate/libmcq_$name.so rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $R/gpurun_out/prof/ab_$name -o ab -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras $1 > $R/gpurun_out/prof/ab_$name.log 2>&1
   python3 - <<PY
 import csv, collections
 rows = list(csv.DictReader(open("$R/gpurun_out/prof/ab_$name/ab_counter_collection.csv")))
