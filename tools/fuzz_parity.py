@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Randomised parity soak on the GPU box: random batches through the C ABI against the oracle, bit for bit.
+
+    python tools/fuzz_parity.py [--seconds 120] [--seed 1]
+
+Every round draws a batch of random valid queries (1-10 players, 0/3/4/5 table cards, ragged run counts incl. 1,
+task boundaries and a few long ones) and checks, against oracle/ (test infrastructure):
+  * production mode (MCQ_MODE_PHILOX), reference and uniform dealing law, random first_query_id;
+  * parity mode (MCQ_MODE_REPLAY_MT19937);
+  * shares of an iteration split (mcq_eval_batch_part) add up to the whole.
+Prints one summary line; exits non-zero on the first mismatch.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import neuron_poker_amd as npa  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+def batch(g):
+    n = int(g.integers(1, 160))
+    hole, board, npl, runs = [], [], [], []
+    for _ in range(n):
+        nb = int(g.choice([0, 3, 4, 5]))
+        c = g.permutation(52)[:2 + nb]
+        hole.append(c[:2])
+        board.append(list(c[2:]) + [255] * (5 - nb))
+        npl.append(int(g.integers(1, 11)))
+        runs.append(int(g.choice([1, 2, 63, 64, 65, 1000, 1023, 1024, 1025, 2048, int(g.integers(1, 6000)),
+                                  int(g.integers(1, 40000)) if g.random() < 0.05 else 17])))
+    return npa.pack_queries(hole, board, npl, runs)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    g = np.random.default_rng(a.seed)
+    eng = npa.Engine(0)
+    t0 = time.time()
+    rounds = queries = iters = 0
+    while time.time() - t0 < a.seconds:
+        q = batch(g)
+        raw = q.view(np.uint8).reshape(-1, 16)
+        seed, first = int(g.integers(0, 2 ** 63)), int(g.integers(0, 2 ** 40))
+        want = O.run_batch(O.MODE_CTR, raw, seed, first_qid=first, threads=16)
+        got = eng.eval_batch(q, seed, first_query_id=first).view(np.uint64).reshape(-1, 13)
+        assert np.array_equal(got, want), ("philox", rounds)
+        n_parts = int(g.integers(2, 9))
+        tot = sum(eng.eval_batch(q, seed, first_query_id=first, part=(p, n_parts)).view(np.uint64).reshape(-1, 13)
+                  for p in range(n_parts))
+        assert np.array_equal(tot, want), ("parts", rounds, n_parts)
+        eng.set_dealing_law("uniform")
+        got = eng.eval_batch(q, seed, first_query_id=first).view(np.uint64).reshape(-1, 13)
+        eng.set_dealing_law("reference")
+        assert np.array_equal(got, O.run_batch(O.MODE_CTR_UNIFORM, raw, seed, first_qid=first, threads=16)), ("uniform", rounds)
+        s32 = int(g.integers(0, 2 ** 32))
+        got = eng.eval_batch(q, s32, first_query_id=first, mode=npa.MODE_REPLAY_MT19937).view(np.uint64).reshape(-1, 13)
+        assert np.array_equal(got, O.run_batch(O.MODE_MT, raw, s32, first_qid=first, threads=16)), ("replay", rounds)
+        rounds += 1
+        queries += 4 * len(q)
+        iters += 4 * int(q["runs"].astype(np.int64).sum())
+    print("fuzz parity: %d rounds, %d query evaluations, %d iterations in 4 configurations -- all bit-exact against "
+          "the oracle (%.0f s, seed %d)" % (rounds, queries, iters, time.time() - t0, a.seed))
+
+
+if __name__ == "__main__":
+    main()
