@@ -241,6 +241,20 @@ def main():
             dt = (time.perf_counter() - t1) / 5
             extras["configs[2]_4096x3x50k"] = {"call_ms_host_buffers": 1e3 * dt, "kernel_ms": eng.last_kernel_ms,
                                                "hand_evals_per_s": 4096 * 3 * 50000 / dt}
+        # BASELINE configs[3] (the 8-GPU config) on this one GPU: 65 536 states, flop / turn tables alternating, 6 players,
+        # 20k iterations, host buffers; one rank of 8 would take an eighth of the queries
+        g3 = np.random.default_rng(65536)
+        keys = g3.random((65536, 52)).argsort(axis=1)[:, :6].astype(np.uint8)   # 6 distinct cards per state
+        b3 = np.full((65536, 5), 255, np.uint8)
+        b3[:, :3] = keys[:, 2:5]
+        b3[1::2, 3] = keys[1::2, 5]
+        q4 = npa.pack_queries(keys[:, :2], b3, 6, 20000)
+        eng.eval_batch(q4[:4096], seed=1)
+        t1 = time.perf_counter()
+        eng.eval_batch(q4, seed=2)
+        dt = time.perf_counter() - t1
+        extras["configs[3]_65536x6x20k_on_one_gpu"] = {"call_ms_host_buffers": 1e3 * dt, "kernel_ms": eng.last_kernel_ms,
+                                                       "hand_evals_per_s": 65536 * 6 * 20000 / dt}
         # BASELINE configs[4], equity side only: one lock-step of 512 six-seat tables issues <= 2 x 512 queries of 1000
         # runs (gym_env/env.py:22,261-262) in ONE call; state mix as observed in reference episodes (SURVEY 8c F5:
         # table cards 0/3/4/5 = 59/19/11/10 %, players alive 2..6 = 41/28/17/9/6 %).  The table logic itself is
