@@ -173,7 +173,10 @@ MCQ_API float mcq_last_kernel_ms(mcq_ctx *ctx);
  * query, finished episodes restart at once.  mcq_tables_begin writes the n_tables pending queries (table i ->
  * q[i]) and returns n_tables; mcq_tables_resume takes their equities ((win + tie) / runs) and advances every
  * table to its next query.  mcq_tables_run does `lock_steps` rounds of begin -> ONE mcq_eval_batch
- * (MCQ_MODE_PHILOX, seed cfg.seed, query ids counting up across calls) -> resume, and needs a context.
+ * (MCQ_MODE_PHILOX, seed cfg.seed, query ids counting up across calls) -> resume, and needs a context; when one
+ * host thread steps the tables (fewer than 2048) it runs the two halves of the tables on two streams so that the host steps one half while the
+ * other half's batch is on the GPU -- every query keeps the id it has in the one-batch schedule, so the results
+ * are the same.
  * begin/resume alone need no GPU (ctx may be NULL): that is how the CPU tests pin the rules.
  * seat_kind: 0 = equity agent (agents/agent_consider_equity.py:25-56 with min_call_equity / min_bet_equity of
  * the seat), 1 = random agent (agents/agent_random.py:21-29, drawing from the table's own generator).
@@ -187,7 +190,8 @@ typedef struct mcq_tables_config {
     double initial_stacks, small_blind, big_blind;
     uint64_t seed;
     uint8_t seat_kind[10];
-    uint8_t reserved[6];            /* [0]: host threads stepping the tables (0 = automatic); rest 0 */
+    uint8_t reserved[6];            /* [0]: host threads stepping the tables (0 = automatic); [1]: 1 = do not split
+                                     * the tables into two halves on two streams (mcq_tables_run); rest 0 */
     double min_call_equity[10], min_bet_equity[10];
 } mcq_tables_config;
 

@@ -280,6 +280,16 @@ const char *mcq_last_error(void) { return g_err.c_str(); }
 
 int mcq_tables_set_error(const char *msg) { return fail(MCQ_EINVAL, msg); } /* for mcq_tables.cpp; not exported */
 
+/* a second context like c (same device, dealing law and tuning) with its own stream and buffers; not exported */
+mcq_ctx *mcq_ctx_clone(const mcq_ctx *c) {
+    mcq_ctx *d = mcq_create(c->device, 0);
+    if (d) {
+        d->law = c->law;
+        d->split_max = c->split_max;
+    }
+    return d;
+}
+
 void mcq_version(int *major, int *minor, int *patch) {
     if (major) *major = MCQ_VERSION_MAJOR;
     if (minor) *minor = MCQ_VERSION_MINOR;

@@ -20,6 +20,7 @@
 #include <functional>
 #include <mutex>
 #include <new>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -467,7 +468,12 @@ struct mcq_tables {
     std::vector<double> eq;
     uint64_t calls;
     Pool *pool = nullptr;
-    ~mcq_tables() { delete pool; }
+    mcq_ctx *ctx2 = nullptr; /* second stream + buffers: the upper half of the tables is stepped by a helper thread
+                                while the lower half's batch is on the GPU, and vice versa (mcq_tables_run) */
+    ~mcq_tables() {
+        delete pool;
+        if (ctx2) mcq_destroy(ctx2);
+    }
     template <class F>
     void for_tables(F &&f) { /* f(begin, end) */
         if (pool) pool->run(tables.size(), std::function<void(size_t, size_t)>(f));
@@ -478,6 +484,29 @@ struct mcq_tables {
 extern "C" {
 
 int mcq_tables_set_error(const char *msg); /* mcq_host.cpp */
+mcq_ctx *mcq_ctx_clone(const mcq_ctx *c);   /* mcq_host.cpp */
+
+/* lock-steps of the tables [a, b) on context ctx: query ids are those of the whole-batch schedule (step * n + table),
+ * so the tallies do not depend on how the tables are divided */
+static int run_range(mcq_tables *t, mcq_ctx *ctx, size_t a, size_t b, uint32_t lock_steps, std::string *err) {
+    const size_t n = t->tables.size();
+    const uint32_t runs = t->cfg.runs;
+    for (uint32_t s = 0; s < lock_steps; s++) {
+        int rc = mcq_eval_batch(ctx, t->q.data() + a, b - a, t->cfg.seed, t->calls + (uint64_t)s * n + a, MCQ_MODE_PHILOX,
+                                t->r.data() + a);
+        if (rc) {
+            if (err) *err = mcq_last_error();
+            return rc;
+        }
+        const bool more = s + 1 < lock_steps;
+        for (size_t i = a; i < b; i++) {
+            Table &tb = t->tables[i];
+            tb.resume((double)(t->r[i].win + t->r[i].tie) / (double)t->r[i].runs);
+            if (more) tb.observe(t->q[i], runs);
+        }
+    }
+    return MCQ_OK;
+}
 
 mcq_tables *mcq_tables_create(mcq_ctx *ctx, const mcq_tables_config *cfg) {
     if (!cfg || cfg->n_tables == 0 || cfg->n_seats < 2 || cfg->n_seats > kMaxSeats || cfg->runs == 0 ||
@@ -562,6 +591,23 @@ int mcq_tables_run(mcq_tables *t, uint32_t lock_steps, uint64_t *stats) {
     const size_t n = t->tables.size();
     const uint32_t runs = t->cfg.runs;
     if (lock_steps) mcq_tables_begin(t, t->q.data());
+    /* Medium table counts (no thread pool): two halves on two streams.  While one half's batch is on the GPU the
+     * other half's tables are stepped on the host; per-query ids, hence all results, are as in one batch per step. */
+    if (!t->pool && n >= 64 && lock_steps >= 4 && t->cfg.reserved[1] == 0) {
+        if (!t->ctx2) t->ctx2 = mcq_ctx_clone(t->ctx);
+        if (t->ctx2) {
+            std::string err2;
+            int rc2 = MCQ_OK;
+            std::thread helper([&] { rc2 = run_range(t, t->ctx2, n / 2, n, lock_steps, &err2); });
+            int rc1 = run_range(t, t->ctx, 0, n / 2, lock_steps, nullptr);
+            helper.join();
+            if (rc1) return rc1; /* a failed half leaves its tables at the step it reached; the driver is not resumable then */
+            if (rc2) { mcq_tables_set_error(err2.c_str()); return rc2; }
+            t->calls += (uint64_t)lock_steps * n;
+            if (stats) mcq_tables_stats(t, stats);
+            return MCQ_OK;
+        }
+    }
     for (uint32_t s = 0; s < lock_steps; s++) {
         int rc = mcq_eval_batch(t->ctx, t->q.data(), n, t->cfg.seed, t->calls, MCQ_MODE_PHILOX, t->r.data());
         if (rc) return rc; /* the queries stay pending: the tables were not advanced */

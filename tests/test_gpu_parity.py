@@ -430,6 +430,16 @@ def test_gate_b_production_rng_vs_reference_stream_at_1e9_iterations(eng):
     assert np.all(np.abs(mt[:, 4:].sum(0) / n - ph[:, 4:].sum(0) / n) <= 1e-4)
 
 
+def b_run(b, eng, seed, T, done_steps, more):
+    calls = T * done_steps
+    for _ in range(more):
+        q = b.begin()
+        r = eng.eval_batch(q, seed, first_query_id=calls)
+        calls += T
+        b.resume((r["win"] + r["tie"]).astype(np.float64) / r["runs"].astype(np.float64))
+    return b.stats()
+
+
 def test_native_table_driver_on_gpu_equals_stepwise_batches(eng):
     """mcq_tables_run (native lock-step driver, BASELINE configs[4]) == the same tables stepped from Python with
     begin() -> eval_batch(seed, query ids counting up) -> resume(): same stacks, counts and pending queries; and the
@@ -450,10 +460,14 @@ def test_native_table_driver_on_gpu_equals_stepwise_batches(eng):
         calls += T
         b.resume((r["win"] + r["tie"]).astype(np.float64) / r["runs"].astype(np.float64))
     assert st == b.stats() and st["queries"] == T * steps and st["env_steps"] > 0 and st["episodes"] > 0
+    c = _lib.Tables(eng, T, seats, runs=1000, seed=seed, overlap=False)   # one batch per lock-step on one stream
+    assert c.run(steps) == st
     for t in range(T):
-        sa, sb = a.state(t), b.state(t)
+        sa, sb, sc = a.state(t), b.state(t), c.state(t)
+        assert np.array_equal(sa["stacks"], sc.pop("stacks")) and {k: v for k, v in sa.items() if k != "stacks"} == sc
         assert np.array_equal(sa.pop("stacks"), sb.pop("stacks")) and sa == sb
     assert np.array_equal(a.begin(), b.begin())
+    assert a.run(7) == b_run(b, eng, seed, T, steps, 7)   # a second run continues the query ids
 
 
 def test_small_batch_task_split_does_not_change_tallies():
