@@ -14,7 +14,8 @@ own = {"mcq_tables_create", "mcq_tables_destroy", "mcq_tables_begin", "mcq_table
        "mcq_tables_stats", "mcq_tables_state", "mcq_last_error"}
 out = ['#include "mcq.h"', '#include <string>', 'static thread_local std::string g_err;', 'extern "C" {',
        'const char *mcq_last_error(void) { return g_err.c_str(); }',
-       'int mcq_tables_set_error(const char *m) { g_err = m; return MCQ_EINVAL; }']
+       'int mcq_tables_set_error(const char *m) { g_err = m; return MCQ_EINVAL; }',
+       'mcq_ctx *mcq_ctx_clone(const mcq_ctx *) { return 0; }']
 for ret, name, args in decls:
     if name in own:
         continue
