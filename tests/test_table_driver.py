@@ -216,3 +216,31 @@ def test_native_tables_do_not_depend_on_the_thread_count():
     for t in range(0, T, 97):
         sa, sb = a.state(t), b.state(t)
         assert np.array_equal(sa.pop("stacks"), sb.pop("stacks")) and sa == sb
+
+
+@pytest.mark.skipif(os.environ.get("MCQ_SAN_STUB") != "1", reason="needs the stand-in equity of tools/sanitize_cpu.sh")
+@pytest.mark.parametrize("T,threads,overlap", [(200, 1, True), (200, 1, False), (4100, 3, True), (63, 0, True)])
+def test_native_run_loop_with_stand_in_equity(T, threads, overlap):
+    """mcq_tables_run itself (two halves on two threads, thread pool) without a GPU: tools/sanitize_cpu.sh links the
+    driver against a stand-in mcq_eval_batch that returns _fake_equity; run(k) must leave the tables where k rounds
+    of begin() -> _fake_equity -> resume() leave them."""
+    from neuron_poker_amd import _lib
+
+    class FakeEngine:
+        _ctx = 1
+
+    seats = [("equity", .3, .5), ("equity", .45, .6), ("random",), ("equity", .2, .75), ("random",), ("equity", .5, .9)]
+    a = _lib.Tables(FakeEngine(), T, seats, seed=21, threads=threads, overlap=overlap)
+    b = _lib.Tables(None, T, seats, seed=21, threads=1)
+    for chunk in (37, 5, 1, 60):
+        st = a.run(chunk)
+        for _ in range(chunk):
+            q = b.begin()
+            eq = ((q["hole"].astype(np.int64) * [131, 31]).sum(1) + q["n_players"] * 13 + q["n_board"] * 3
+                  + (q["board"].astype(np.int64) * (np.arange(5)[None, :] < q["n_board"][:, None])).sum(1) * 7) % 101 / 100.0
+            b.resume(eq)
+        assert st == b.stats()
+    for t in range(0, T, 41):
+        sa, sb = a.state(t), b.state(t)
+        assert np.array_equal(sa.pop("stacks"), sb.pop("stacks")) and sa == sb
+    assert np.array_equal(a.begin(), b.begin())

@@ -11,11 +11,18 @@ R, T = sys.argv[1:]
 h = open(R + "/include/mcq.h").read()
 decls = re.findall(r"MCQ_API\s+([\w\s\*]+?)\b(mcq_\w+)\s*\(([^;]*?)\)\s*;", h, re.S)
 own = {"mcq_tables_create", "mcq_tables_destroy", "mcq_tables_begin", "mcq_tables_resume", "mcq_tables_run",
-       "mcq_tables_stats", "mcq_tables_state", "mcq_last_error"}
+       "mcq_tables_stats", "mcq_tables_state", "mcq_last_error", "mcq_eval_batch", "mcq_destroy"}
 out = ['#include "mcq.h"', '#include <string>', 'static thread_local std::string g_err;', 'extern "C" {',
        'const char *mcq_last_error(void) { return g_err.c_str(); }',
        'int mcq_tables_set_error(const char *m) { g_err = m; return MCQ_EINVAL; }',
-       'mcq_ctx *mcq_ctx_clone(const mcq_ctx *) { return 0; }']
+       'mcq_ctx *mcq_ctx_clone(const mcq_ctx *c) { return (mcq_ctx *)c; }', 'void mcq_destroy(mcq_ctx *) {}',
+       # a stand-in equity so that mcq_tables_run (helper thread, thread pool) can run without a GPU: the same
+       # function of the query as _fake_equity in tests/test_table_driver.py
+       'int mcq_eval_batch(mcq_ctx *, const mcq_query *q, size_t n, uint64_t, uint64_t, int, mcq_result *out) {',
+       '    for (size_t i = 0; i < n; i++) { unsigned x = q[i].hole[0] * 131u + q[i].hole[1] * 31u + q[i].n_players * 13u + q[i].n_board * 3u;',
+       '        for (unsigned k = 0; k < q[i].n_board; k++) x += q[i].board[k] * 7u;',
+       '        mcq_result r = {}; r.runs = 100; r.win = x % 101u; out[i] = r; }',
+       '    return 0; }']
 for ret, name, args in decls:
     if name in own:
         continue
@@ -30,6 +37,11 @@ g++ $F -std=c++17 -Wno-unknown-pragmas -o $T/libmcq_hostsim.so $R/tests/hostsim/
 g++ $F -std=c++17 -Wno-unknown-pragmas -I$R/include -o $T/libmcq_san.so $T/stub.cpp $R/neuron_poker_amd/csrc/mcq_tables.cpp -lpthread
 cd $R
 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0 \
-MCQ_ORACLE_SO=$T/libmcq_oracle.so MCQ_HOSTSIM_SO=$T/libmcq_hostsim.so MCQ_LIBRARY=$T/libmcq_san.so \
+MCQ_ORACLE_SO=$T/libmcq_oracle.so MCQ_HOSTSIM_SO=$T/libmcq_hostsim.so MCQ_LIBRARY=$T/libmcq_san.so MCQ_SAN_STUB=1 \
 python3 -m pytest tests/test_oracle_golden.py tests/test_lane_arithmetic_host.py tests/test_table_driver.py -x -q \
   -k "not three_players_on_the_turn" -p no:cacheprovider "$@"
+# ThreadSanitizer over the driver's threads (helper thread of the two-stream schedule, thread pool)
+g++ -O1 -g -fsanitize=thread -fno-omit-frame-pointer -shared -fPIC -std=c++17 -Wno-unknown-pragmas -I$R/include \
+    -o $T/libmcq_tsan.so $T/stub.cpp $R/neuron_poker_amd/csrc/mcq_tables.cpp -lpthread
+LD_PRELOAD="$(gcc -print-file-name=libtsan.so)" TSAN_OPTIONS="report_signal_unsafe=0 exitcode=66" \
+MCQ_LIBRARY=$T/libmcq_tsan.so MCQ_SAN_STUB=1 python3 -m pytest tests/test_table_driver.py -x -q -k "stand_in or thread_count" -p no:cacheprovider
