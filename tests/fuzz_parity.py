@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity soak on the GPU box: random batches through the C ABI against the oracle, bit for bit.
 
-    python tools/fuzz_parity.py [--seconds 120] [--seed 1]
+    python tests/fuzz_parity.py [--seconds 120] [--seed 1]
 
 Every round draws a batch of random valid queries (1-10 players, 0/3/4/5 table cards, ragged run counts incl. 1,
 task boundaries and a few long ones) and checks, against oracle/ (test infrastructure):
@@ -17,7 +17,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root
 import neuron_poker_amd as npa  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
