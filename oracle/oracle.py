@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.environ.get("MCQ_ORACLE_SO", os.path.join(_HERE, "libmcq_oracle.so"))   # override: tools/sanitize_cpu.sh
+_SO = os.environ.get("MCQ_ORACLE_SO", os.path.join(_HERE, "libmcq_oracle.so"))   # override: tests/sanitize_cpu.sh
 
 TYPES = ["HighCard", "Pair", "TwoPair", "ThreeOfAKind", "Straight", "Flush", "FullHouse", "FoufOfAKind",
          "StraightFlush"]

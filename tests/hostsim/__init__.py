@@ -6,7 +6,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.environ.get("MCQ_HOSTSIM_SO", os.path.join(_HERE, "libmcq_hostsim.so"))   # override: tools/sanitize_cpu.sh
+_SO = os.environ.get("MCQ_HOSTSIM_SO", os.path.join(_HERE, "libmcq_hostsim.so"))   # override: tests/sanitize_cpu.sh
 _SRCS = [os.path.join(_HERE, "hostsim.cpp"),
          os.path.join(_HERE, "..", "..", "neuron_poker_amd", "csrc", "mcq_device.hpp"),
          os.path.join(_HERE, "..", "..", "neuron_poker_amd", "csrc", "mcq_replay.hpp"),

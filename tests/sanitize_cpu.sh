@@ -1,7 +1,7 @@
 #!/bin/bash
 # AddressSanitizer + UBSan over everything that runs on the host: the oracle, the host build of the lane code
 # (tests/hostsim) and the native table driver (csrc/mcq_tables.cpp, linked against stubs of the GPU entry points).
-# GPU sanitizers are not available on this pool; this is the CPU build only.   usage: tools/sanitize_cpu.sh
+# GPU sanitizers are not available on this pool; this is the CPU build only.   usage: tests/sanitize_cpu.sh
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd); T=${TMPDIR:-/tmp}/mcq_san; mkdir -p $T
 F="-O1 -g -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -shared -fPIC"

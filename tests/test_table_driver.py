@@ -218,10 +218,10 @@ def test_native_tables_do_not_depend_on_the_thread_count():
         assert np.array_equal(sa.pop("stacks"), sb.pop("stacks")) and sa == sb
 
 
-@pytest.mark.skipif(os.environ.get("MCQ_SAN_STUB") != "1", reason="needs the stand-in equity of tools/sanitize_cpu.sh")
+@pytest.mark.skipif(os.environ.get("MCQ_SAN_STUB") != "1", reason="needs the stand-in equity of tests/sanitize_cpu.sh")
 @pytest.mark.parametrize("T,threads,overlap", [(200, 1, True), (200, 1, False), (4100, 3, True), (63, 0, True)])
 def test_native_run_loop_with_stand_in_equity(T, threads, overlap):
-    """mcq_tables_run itself (two halves on two threads, thread pool) without a GPU: tools/sanitize_cpu.sh links the
+    """mcq_tables_run itself (two halves on two threads, thread pool) without a GPU: tests/sanitize_cpu.sh links the
     driver against a stand-in mcq_eval_batch that returns _fake_equity; run(k) must leave the tables where k rounds
     of begin() -> _fake_equity -> resume() leave them."""
     from neuron_poker_amd import _lib
