@@ -417,6 +417,10 @@ MCQ_HD uint32_t mcq_eval_key(const McqBoard &b, const McqFlushSel &fs, const Mcq
                     (fh ? (uint32_t)MCQ_C_FULL << MCQ_KEY_SHIFT : (uint32_t)MCQ_C_TWOPAIR << MCQ_KEY_SHIFT);
     key2 = (H != 0 && R != 0) ? key2 : 0u;
 
+#ifdef MCQ_ABLATE_QUADS /* diagnostic timing build: wrong results */
+    (void)eq4;
+    return (key1 > key2 ? key1 : key2) > (key_s > key_f ? key_s : key_f) ? (key1 > key2 ? key1 : key2) : (key_s > key_f ? key_s : key_f);
+#endif
     uint32_t key4 = 0; /* quads are rare (0.17 % of hands): looked at only when some lane of the wave has them */
     if (mcq_any(eq4 != 0))
         key4 = eq4 != 0 ? ((mcq_ld_u32(tops, any) & 0xFFFFu) | ((uint32_t)MCQ_C_QUADS << MCQ_KEY_SHIFT)) : 0u;

@@ -2,7 +2,7 @@
 # Diagnostic: build timing-only variants of libmcq_hip.so with parts of the iteration stubbed out.
 # usage: tools/ablate.sh build   (here)      tools/ablate.sh run   (on the GPU box)
 cd "$(dirname "$0")/.."
-VARIANTS="full:-DMCQ_NOP EVAL:-DMCQ_ABLATE_EVAL HOLES:-DMCQ_ABLATE_HOLES RNG:-DMCQ_ABLATE_RNG EVAL_HOLES:-DMCQ_ABLATE_EVAL;-DMCQ_ABLATE_HOLES ALL:-DMCQ_ABLATE_EVAL;-DMCQ_ABLATE_HOLES;-DMCQ_ABLATE_RNG"
+VARIANTS="full:-DMCQ_NOP QUADS:-DMCQ_ABLATE_QUADS EVAL:-DMCQ_ABLATE_EVAL HOLES:-DMCQ_ABLATE_HOLES RNG:-DMCQ_ABLATE_RNG EVAL_HOLES:-DMCQ_ABLATE_EVAL;-DMCQ_ABLATE_HOLES ALL:-DMCQ_ABLATE_EVAL;-DMCQ_ABLATE_HOLES;-DMCQ_ABLATE_RNG"
 if [ "$1" = build ]; then
   mkdir -p gpurun_in/ablate
   for v in $VARIANTS; do
