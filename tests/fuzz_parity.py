@@ -7,7 +7,8 @@ Every round draws a batch of random valid queries (1-10 players, 0/3/4/5 table c
 task boundaries and a few long ones) and checks, against oracle/ (test infrastructure):
   * production mode (MCQ_MODE_PHILOX), reference and uniform dealing law, random first_query_id;
   * parity mode (MCQ_MODE_REPLAY_MT19937);
-  * shares of an iteration split (mcq_eval_batch_part) add up to the whole.
+  * shares of an iteration split (mcq_eval_batch_part) add up to the whole;
+  * every fourth round a batch of extended queries (ranges, hero range, ghost cards, second known hand) in both modes.
 Prints one summary line; exits non-zero on the first mismatch.
 """
 import argparse
@@ -36,6 +37,43 @@ def batch(g):
     return npa.pack_queries(hole, board, npl, runs)
 
 
+RANKS = "23456789TJQKA"
+CLASSES = [a + a for a in RANKS] + [RANKS[i] + RANKS[j] + t for i in range(13) for j in range(i) for t in "SO"]  # 169
+
+
+def ext_round(g, eng):
+    """Extended queries (opponent range, hero range, ghost cards, second known hand), a batch per call, both modes."""
+    from neuron_poker_amd import _lib
+    n = int(g.integers(1, 40))
+    q = np.zeros(n, npa.QUERY_DTYPE)
+    e = np.zeros(n, npa.QUERY_EXT_DTYPE)
+    spec = []
+    for i in range(n):
+        nb = int(g.choice([0, 3, 4, 5]))
+        c = [int(x) for x in g.permutation(52)[:8 + nb]]
+        hero_range = sorted(g.choice(CLASSES, size=int(g.integers(25, 90)), replace=False)) if g.random() < 0.3 else None
+        opp = sorted(g.choice(CLASSES, size=int(g.integers(70, 169)), replace=False)) if g.random() < 0.6 else None
+        ghost = c[2:4] if g.random() < 0.3 else None
+        known2 = c[4:6] if g.random() < 0.3 else None
+        npl = int(g.integers(2, 7))
+        runs = int(g.choice([1, 64, 65, 300, 1024, 1100]))
+        q[i] = _lib.pack_queries([[0, 1] if hero_range else c[:2]], [c[8:] + [255] * (5 - nb)], npl, runs)[0]
+        if hero_range:
+            q["hole"][i] = 0
+        e[i] = _lib.pack_query_ext(1, ghost=ghost, known2=known2,
+                                   hero_range=_lib.range_bits(hero_range) if hero_range else None,
+                                   opp_range=_lib.range_bits(opp) if opp else None)[0]
+        spec.append((hero_range if hero_range else c[:2], c[8:], npl, runs, known2, ghost, opp))
+    seed, first = int(g.integers(0, 2 ** 31)), int(g.integers(0, 2 ** 20))
+    for mode, om in ((npa.MODE_PHILOX, O.MODE_CTR), (npa.MODE_REPLAY_MT19937, O.MODE_MT)):
+        got = eng.eval_batch_ext(q, e, seed, first_query_id=first, mode=mode).view(np.uint64).reshape(-1, 13)
+        for i, (hero, board, npl, runs, known2, ghost, opp) in enumerate(spec):
+            s_i = (seed + first + i) & 0xFFFFFFFF if om == O.MODE_MT else seed
+            want = O.run_ex(om, hero, board, npl, runs, s_i, qid=first + i, known2=known2, ghost=ghost, opp_range=opp)["tallies"]
+            assert np.array_equal(got[i], want), ("ext", mode, i, spec[i])
+    return n, int(q["runs"].astype(np.int64).sum())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
@@ -44,7 +82,7 @@ def main():
     g = np.random.default_rng(a.seed)
     eng = npa.Engine(0)
     t0 = time.time()
-    rounds = queries = iters = 0
+    rounds = queries = iters = ext_q = ext_i = 0
     while time.time() - t0 < a.seconds:
         q = batch(g)
         raw = q.view(np.uint8).reshape(-1, 16)
@@ -66,8 +104,13 @@ def main():
         rounds += 1
         queries += 4 * len(q)
         iters += 4 * int(q["runs"].astype(np.int64).sum())
-    print("fuzz parity: %d rounds, %d query evaluations, %d iterations in 4 configurations -- all bit-exact against "
-          "the oracle (%.0f s, seed %d)" % (rounds, queries, iters, time.time() - t0, a.seed))
+        if rounds % 4 == 0:
+            nq, ni = ext_round(g, eng)
+            ext_q += 2 * nq
+            ext_i += 2 * ni
+    print("fuzz parity: %d rounds, %d query evaluations, %d iterations in 4 configurations; %d extended-query "
+          "evaluations, %d iterations in both modes -- all bit-exact against the oracle (%.0f s, seed %d)"
+          % (rounds, queries, iters, ext_q, ext_i, time.time() - t0, a.seed))
 
 
 if __name__ == "__main__":
