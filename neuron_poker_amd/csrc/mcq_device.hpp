@@ -145,15 +145,17 @@ MCQ_HD uint32_t mcq_straight_runs(uint32_t m) {
 //           when popcount(m) < 5
 struct McqTables { /* order matters on the device: the first 64 KB are reachable through the 16-bit offset field of
                      the LDS read, i.e. the lookups whose index comes straight out of a logic instruction (tops,
-                     sd); the indices of kc and tf are formed by an xor / or that takes the table base along */
+                     sd); the index of kc is formed by an xor that takes the table base along.  The evaluation
+                     kernels keep tops, sd | kc (the first 96 KB) and sel8 in LDS and read tf from GLOBAL memory
+                     through the vector L1: the LDS pipe is their co-limiter and the flush lookup, whose index is
+                     the sparsest, is the one that costs least there (measured) */
     uint32_t tops[8192];
     uint32_t sd[16384]; /* [0, 8192) sd, [8192, 16384) kc */
     uint32_t tf[8192];
     uint32_t sel8[256];
 };
 #define MCQ_KC_BYTE_OFFSET 32768u /* kc relative to sd */
-#define MCQ_TF_BYTE_OFFSET 98304u /* tf relative to tops: the flush lookup goes through the tops pointer, its index
-                                     carries this offset from McqFlushSel on (no add per lookup) */
+#define MCQ_TF_BYTE_OFFSET 98304u /* tf relative to tops = size of the part the evaluation kernels keep in LDS */
 static_assert(__builtin_offsetof(McqTables, tops) == 0 && __builtin_offsetof(McqTables, tf) == MCQ_TF_BYTE_OFFSET,
               "McqTables layout");
 
@@ -370,7 +372,7 @@ struct McqFlushSel {
         const uint32_t f = (b.cnt + 0x5555u) & 0x8888u; /* bit 4s+3 <=> suit s has >= 3 table cards */
         use_hi = (f & 0x8800u) != 0;                     /* hearts or spades */
         sh = (f & 0x8080u) != 0 ? 16u : 0u;              /* diamonds or spades: upper half-word */
-        bfl4 = mcq_bfe(use_hi ? b.his : b.los, sh, 16) | MCQ_TF_BYTE_OFFSET; /* index < 0x8000: no common bits */
+        bfl4 = mcq_bfe(use_hi ? b.his : b.los, sh, 16);
     }
 };
 
@@ -403,8 +405,7 @@ MCQ_HD uint32_t mcq_eval_key(const McqBoard &b, const McqFlushSel &fs, const Mcq
     const uint32_t e_ge3 = mcq_ld_u32(tops, ge3);
     const uint32_t d_any = mcq_ld_u32(sd, any);
     const uint32_t d_kick = mcq_ld_u32(sd, (any ^ ge2) + MCQ_KC_BYTE_OFFSET); /* kickers | type code of family F1 */
-    (void)tf; /* = tops + MCQ_TF_BYTE_OFFSET bytes, which fs.bfl4 already carries */
-    const uint32_t key_f = mcq_ld_u32(tops, fs.bfl4 | mcq_bfe(fs.use_hi ? h.his : h.los, fs.sh, 16));
+    const uint32_t key_f = mcq_ld_u32(tf, fs.bfl4 | mcq_bfe(fs.use_hi ? h.his : h.los, fs.sh, 16)); /* tf: LDS or global */
 
     const uint32_t key_s = d_any;
     const uint32_t key1 = (ge2 << 13) | d_kick;

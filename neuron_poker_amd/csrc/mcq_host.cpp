@@ -139,7 +139,7 @@ void pick_geometry(const mcq_ctx *c, int mode, uint64_t total_tasks, uint32_t *g
     if (wpb < 1) wpb = 1;
     if (wpb > kBlock / 64) wpb = kBlock / 64;
     const uint64_t blocks = (total_tasks + wpb - 1) / wpb;
-    if (wpb < 4) wpb = 4; /* at least 256 threads per block: idle waves only help to load the 129 KB table image */
+    if (wpb < 4) wpb = 4; /* at least 256 threads per block: idle waves only help to load the 97 KB table image */
     *block = (uint32_t)(64 * wpb);
     *grid = (uint32_t)(blocks < (uint64_t)c->n_cu ? blocks : (wpb == kBlock / 64 ? full : (uint64_t)c->n_cu));
 }

@@ -10,7 +10,7 @@
 // plus a few KB of table image per block.
 //
 // Memory: 16 B in / 104 B out per QUERY; per iteration nothing touches HBM in production mode (parity mode
-// reads <= 23 draw bytes).  LDS holds the lookup tables (129 KB per block) and one 64-entry base deck per wave.
+// reads <= 23 draw bytes).  LDS holds the lookup tables (97 KB per block; the flush table is read from global memory) and one 64-entry base deck per wave.
 #include <hip/hip_runtime.h>
 
 #include "mcq_device.hpp"
@@ -19,7 +19,7 @@
 
 namespace {
 
-constexpr int kMaxBlock = 1024; /* 16 waves = 4 per SIMD; one block per CU: tables 129 KB + 16 base decks 16 KB of the 160 KB LDS */
+constexpr int kMaxBlock = 1024; /* 16 waves = 4 per SIMD; one block per CU: tables 97 KB + 16 base decks 16 KB of the 160 KB LDS */
 constexpr int kExtBlock = 512;  /* extended queries: 20 KB of dealt card ids beside the tables */
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -36,6 +36,13 @@ struct LdsTables { /* per block; same order as McqTables (copied word by word) *
 };
 static_assert(sizeof(LdsTables) == sizeof(McqTables), "table image is copied word by word");
 
+struct LdsTablesEval { /* the evaluation kernels: tf stays in global memory (see McqTables) */
+    uint32_t tops[8192];
+    uint32_t sd[16384];
+    uint32_t sel8[256];
+};
+static_assert(__builtin_offsetof(LdsTablesEval, sel8) == MCQ_TF_BYTE_OFFSET, "first 96 KB of McqTables");
+
 __device__ __forceinline__ void load_tables(LdsTables &dst, const McqTables *__restrict__ g) {
     const uint4 *src = reinterpret_cast<const uint4 *>(g);
     uint4 *d = reinterpret_cast<uint4 *>(&dst);
@@ -49,6 +56,23 @@ __device__ __forceinline__ void load_tables(LdsTables &dst, const McqTables *__r
         for (int k = 0; k < 8; k++) d[i + k * blockDim.x] = v[k];
     }
     for (; i < kVec; i += blockDim.x) d[i] = src[i];
+    __syncthreads();
+}
+
+__device__ __forceinline__ void load_tables(LdsTablesEval &dst, const McqTables *__restrict__ g) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(g);
+    uint4 *d = reinterpret_cast<uint4 *>(&dst);
+    constexpr uint32_t kVec = MCQ_TF_BYTE_OFFSET / 16; /* tops, sd | kc */
+    uint32_t i = threadIdx.x;
+    for (; i + 7u * blockDim.x < kVec; i += 8u * blockDim.x) { /* eight 16-byte loads in flight per lane */
+        uint4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = src[i + k * blockDim.x];
+#pragma unroll
+        for (int k = 0; k < 8; k++) d[i + k * blockDim.x] = v[k];
+    }
+    for (; i < kVec; i += blockDim.x) d[i] = src[i];
+    for (uint32_t j = threadIdx.x; j < 256u; j += blockDim.x) dst.sel8[j] = g->sel8[j];
     __syncthreads();
 }
 
@@ -150,7 +174,7 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
     /* split (0..4): small batches cut every 1024-iteration task into 2^split sub-tasks of 16 >> split iterations per
      * lane so that more waves share the work; the iterations and their random numbers stay the same (a sub-task
      * skips ahead in its lane's stream), so the tallies do not depend on it. */
-    __shared__ __attribute__((aligned(16))) LdsTables tab;
+    __shared__ __attribute__((aligned(16))) LdsTablesEval tab;
     __shared__ McqCard base_tab[kMaxBlock]; /* per wave: the query's ordered remaining deck, 64 entries x 16 B */
     load_tables(tab, g_tab);
 
@@ -219,7 +243,7 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
                 for (uint32_t k = sub * chunk * (qc.n_opp + ((qc.n_deal + 1u) >> 1)); k != 0; k--) dr.rng.next();
                 const uint32_t cnt = (uint32_t)min((uint64_t)chunk, (uint64_t)qc.runs - it0);
                 for (uint32_t j = 0; j < cnt; j++)
-                    mcq_iteration(qc, dr, base - 128, tab.tf, tab.tops, tab.sd, acc);
+                    mcq_iteration(qc, dr, base - 128, g_tab->tf, tab.tops, tab.sd, acc);
                 acc.passes = cnt * qc.n_opp; /* MCQ-CTR v3: one attempt per opponent, never re-drawn */
             }
         } else {
@@ -229,7 +253,7 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
                 const uint64_t it = (uint64_t)(task >> split) * MCQ_TASK_ITERS + j * MCQ_WAVE + lane;
                 if (it < qc.runs) {
                     McqReplayDraws dr = {dbase + it, stride};
-                    mcq_iteration(qc, dr, base - 128, tab.tf, tab.tops, tab.sd, acc);
+                    mcq_iteration(qc, dr, base - 128, g_tab->tf, tab.tops, tab.sd, acc);
                 }
             }
             acc.passes = 0; /* counted by the host while parsing the MT19937 stream */
