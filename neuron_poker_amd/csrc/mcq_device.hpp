@@ -402,7 +402,10 @@ MCQ_HD uint32_t mcq_eval_key(const McqBoard &b, const McqFlushSel &fs, const Mcq
 
     /* lookups first: their latency overlaps the arithmetic below */
     const uint32_t e_ge2 = mcq_ld_u32(tops, ge2);
-    const uint32_t e_ge3 = mcq_ld_u32(tops, ge3);
+    /* tops[ge3] from the table image tf belongs to (tf is always part of a whole McqTables image): in the
+     * evaluation kernels that is the GLOBAL copy -- the vector-memory path takes a second sparse lookup off the
+     * LDS pipe (ge3 is zero for 19 hands in 20: one cache line); measured 7.17 -> 7.04 ms, a third one loses */
+    const uint32_t e_ge3 = mcq_ld_u32(tf - MCQ_TF_BYTE_OFFSET / 4u, ge3);
     const uint32_t d_any = mcq_ld_u32(sd, any);
     const uint32_t d_kick = mcq_ld_u32(sd, (any ^ ge2) + MCQ_KC_BYTE_OFFSET); /* kickers | type code of family F1 */
     const uint32_t key_f = mcq_ld_u32(tf, fs.bfl4 | mcq_bfe(fs.use_hi ? h.his : h.los, fs.sh, 16)); /* tf: LDS or global */
