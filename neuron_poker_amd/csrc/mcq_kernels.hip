@@ -450,11 +450,11 @@ __global__ __launch_bounds__(256) void mcq_showdown_kernel(const uint8_t *__rest
 // weight (-> runs), lane 2 strict wins, lane 3 ties, lane 4 + t hero's winning hand type t; one atomic each
 // at the end.
 template <bool TWO_OPP>
-__global__ __launch_bounds__(TWO_OPP ? 256 : 512) void mcq_exact_kernel(uint4 raw, int law, uint32_t n_boards,
+__global__ __launch_bounds__(TWO_OPP ? 384 : 512) void mcq_exact_kernel(uint4 raw, int law, uint32_t n_boards,
                                                                         uint32_t slices, mcq_result *__restrict__ row,
                                                                         const McqTables *__restrict__ g_tab) {
-    constexpr uint32_t kWaves = TWO_OPP ? 4u : 8u; /* what fits beside the 129 KB of tables */
-    __shared__ __attribute__((aligned(16))) LdsTables tab;
+    constexpr uint32_t kWaves = TWO_OPP ? 6u : 8u; /* what fits beside the 97 KB of tables */
+    __shared__ __attribute__((aligned(16))) LdsTablesEval tab; /* tf from global memory, as in the evaluation kernels */
     __shared__ uint16_t pair_xy[MCQ_EXACT_PAIRS + 2];
     __shared__ McqCard rem_card_all[kWaves][64];
     __shared__ uint32_t rem_pos_all[kWaves][64];
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(TWO_OPP ? 256 : 512) void mcq_exact_kernel(uint4 ra
         uint32_t pos[5];
         mcq_exact_unrank(board, e.L, e.k, pos);
         McqExactBoard bd;
-        mcq_exact_board(e, pos, tab.sel8, tab.tf, tab.tops, tab.sd, bd);
+        mcq_exact_board(e, pos, tab.sel8, g_tab->tf, tab.tops, tab.sd, bd);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); /* the previous unit's reads are done (same wave) */
         if (lane < MCQ_EXACT_REM) {
             const uint32_t rp = mcq_exact_rem_pos(e, pos, lane);
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(TWO_OPP ? 256 : 512) void mcq_exact_kernel(uint4 ra
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
         McqExactAcc acc = {0, 0, 0};
-        mcq_exact_pass_a(e, bd, lane, pair_xy, rem_card, rem_pos, tab.tf, tab.tops, tab.sd, keys, rec, acc);
+        mcq_exact_pass_a(e, bd, lane, pair_xy, rem_card, rem_pos, g_tab->tf, tab.tops, tab.sd, keys, rec, acc);
         if (TWO_OPP) {
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -582,10 +582,10 @@ hipError_t mcq_launch_exact(const mcq_query *q, int law, mcq_result *d_row, cons
     if (q->n_players == 3) {
         /* few completions (turn, river): cut the first-opponent loop so that every wave has work */
         uint32_t slices = 1;
-        while (slices < 64u && (uint64_t)n_boards * slices < 4ull * n_cu * 4ull) slices *= 2u;
+        while (slices < 64u && (uint64_t)n_boards * slices < 6ull * n_cu * 4ull) slices *= 2u;
         const uint64_t units = (uint64_t)n_boards * slices;
-        const uint32_t grid = (uint32_t)((units + 3u) / 4u < n_cu ? (units + 3u) / 4u : n_cu);
-        hipLaunchKernelGGL(mcq_exact_kernel<true>, dim3(grid), dim3(256), 0, s, raw, law, n_boards, slices, d_row, d_luts);
+        const uint32_t grid = (uint32_t)((units + 5u) / 6u < n_cu ? (units + 5u) / 6u : n_cu);
+        hipLaunchKernelGGL(mcq_exact_kernel<true>, dim3(grid), dim3(384), 0, s, raw, law, n_boards, slices, d_row, d_luts);
     } else {
         const uint32_t grid = (n_boards + 7u) / 8u < n_cu ? (n_boards + 7u) / 8u : n_cu;
         hipLaunchKernelGGL(mcq_exact_kernel<false>, dim3(grid), dim3(512), 0, s, raw, law, n_boards, 1u, d_row, d_luts);
