@@ -450,10 +450,10 @@ __global__ __launch_bounds__(256) void mcq_showdown_kernel(const uint8_t *__rest
 // weight (-> runs), lane 2 strict wins, lane 3 ties, lane 4 + t hero's winning hand type t; one atomic each
 // at the end.
 template <bool TWO_OPP>
-__global__ __launch_bounds__(TWO_OPP ? 384 : 512) void mcq_exact_kernel(uint4 raw, int law, uint32_t n_boards,
+__global__ __launch_bounds__(TWO_OPP ? 384 : 1024) void mcq_exact_kernel(uint4 raw, int law, uint32_t n_boards,
                                                                         uint32_t slices, mcq_result *__restrict__ row,
                                                                         const McqTables *__restrict__ g_tab) {
-    constexpr uint32_t kWaves = TWO_OPP ? 6u : 8u; /* what fits beside the 97 KB of tables */
+    constexpr uint32_t kWaves = TWO_OPP ? 6u : 16u; /* what fits beside the 97 KB of tables */
     __shared__ __attribute__((aligned(16))) LdsTablesEval tab; /* tf from global memory, as in the evaluation kernels */
     __shared__ uint16_t pair_xy[MCQ_EXACT_PAIRS + 2];
     __shared__ McqCard rem_card_all[kWaves][64];
@@ -587,8 +587,8 @@ hipError_t mcq_launch_exact(const mcq_query *q, int law, mcq_result *d_row, cons
         const uint32_t grid = (uint32_t)((units + 5u) / 6u < n_cu ? (units + 5u) / 6u : n_cu);
         hipLaunchKernelGGL(mcq_exact_kernel<true>, dim3(grid), dim3(384), 0, s, raw, law, n_boards, slices, d_row, d_luts);
     } else {
-        const uint32_t grid = (n_boards + 7u) / 8u < n_cu ? (n_boards + 7u) / 8u : n_cu;
-        hipLaunchKernelGGL(mcq_exact_kernel<false>, dim3(grid), dim3(512), 0, s, raw, law, n_boards, 1u, d_row, d_luts);
+        const uint32_t grid = (n_boards + 15u) / 16u < n_cu ? (n_boards + 15u) / 16u : n_cu;
+        hipLaunchKernelGGL(mcq_exact_kernel<false>, dim3(grid), dim3(1024), 0, s, raw, law, n_boards, 1u, d_row, d_luts);
     }
     return hipGetLastError();
 }
