@@ -501,7 +501,6 @@ int mcq_eval_batch_ext(mcq_ctx *c, const mcq_query *q, const mcq_query_ext *ext,
     std::vector<uint64_t> passes;
     uint32_t grid, block;
     pick_geometry(c, mode, total_tasks, &grid, &block);
-    if (block > 512u) block = 512u; /* mcq_eval_ext_kernel: kExtBlock */
     if (mode == MCQ_MODE_REPLAY_MT19937) { /* one chunk: the extended path is a feature path, not a bulk path */
         passes.assign(n, 0);
         std::vector<uint64_t> off(n);

@@ -20,7 +20,7 @@
 namespace {
 
 constexpr int kMaxBlock = 1024; /* 16 waves = 4 per SIMD; one block per CU: tables 97 KB + 16 base decks 16 KB of the 160 KB LDS */
-constexpr int kExtBlock = 512;  /* extended queries: 20 KB of dealt card ids beside the tables */
+constexpr int kExtBlock = 1024; /* extended queries: 40 KB of dealt card ids beside the tables */
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
@@ -28,36 +28,12 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
-struct LdsTables { /* per block; same order as McqTables (copied word by word) */
-    uint32_t tops[8192];
-    uint32_t sd[16384]; /* sd | kc, see McqTables */
-    uint32_t tf[8192];
-    uint32_t sel8[256];
-};
-static_assert(sizeof(LdsTables) == sizeof(McqTables), "table image is copied word by word");
-
-struct LdsTablesEval { /* the evaluation kernels: tf stays in global memory (see McqTables) */
+struct LdsTablesEval { /* per block: what the kernels keep in LDS; tf stays in global memory (see McqTables) */
     uint32_t tops[8192];
     uint32_t sd[16384];
     uint32_t sel8[256];
 };
 static_assert(__builtin_offsetof(LdsTablesEval, sel8) == MCQ_TF_BYTE_OFFSET, "first 96 KB of McqTables");
-
-__device__ __forceinline__ void load_tables(LdsTables &dst, const McqTables *__restrict__ g) {
-    const uint4 *src = reinterpret_cast<const uint4 *>(g);
-    uint4 *d = reinterpret_cast<uint4 *>(&dst);
-    constexpr uint32_t kVec = sizeof(LdsTables) / 16;
-    uint32_t i = threadIdx.x;
-    for (; i + 7u * blockDim.x < kVec; i += 8u * blockDim.x) { /* eight 16-byte loads in flight per lane */
-        uint4 v[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = src[i + k * blockDim.x];
-#pragma unroll
-        for (int k = 0; k < 8; k++) d[i + k * blockDim.x] = v[k];
-    }
-    for (; i < kVec; i += blockDim.x) d[i] = src[i];
-    __syncthreads();
-}
 
 __device__ __forceinline__ void load_tables(LdsTablesEval &dst, const McqTables *__restrict__ g) {
     const uint4 *src = reinterpret_cast<const uint4 *>(g);
@@ -316,7 +292,7 @@ __global__ __launch_bounds__(kExtBlock) void mcq_eval_ext_kernel(const mcq_query
                                                                  uint64_t first_qid, const McqTables *__restrict__ g_tab,
                                                                  const uint8_t *__restrict__ draws,
                                                                  const uint64_t *__restrict__ draw_off) {
-    __shared__ __attribute__((aligned(16))) LdsTables tab;
+    __shared__ __attribute__((aligned(16))) LdsTablesEval tab;
     __shared__ McqCard cards[64];
     __shared__ uint32_t sets[(kExtBlock / 64) * 12]; /* per wave: hero_range[6], opp_range[6] */
     __shared__ uint32_t ids[(MCQ_MAX_OPP + 1) * kExtBlock];
@@ -391,7 +367,7 @@ __global__ __launch_bounds__(kExtBlock) void mcq_eval_ext_kernel(const mcq_query
                 dr.rng.seed(seed, first_qid + qi, stream);
                 const uint32_t cnt = (uint32_t)min((uint64_t)MCQ_STREAM_ITERS, (uint64_t)qc.runs - it0);
                 for (uint32_t j = 0; j < cnt && !failed; j++)
-                    failed = !mcq_iteration_ext(qc, dr, cards, tab.sel8, my_sets, my_sets + 6, my_ids, kExtBlock, tab.tf,
+                    failed = !mcq_iteration_ext(qc, dr, cards, tab.sel8, my_sets, my_sets + 6, my_ids, kExtBlock, g_tab->tf,
                                                 tab.tops, tab.sd, acc);
             }
         } else {
@@ -401,7 +377,7 @@ __global__ __launch_bounds__(kExtBlock) void mcq_eval_ext_kernel(const mcq_query
                 const uint64_t it = (uint64_t)task * MCQ_TASK_ITERS + j * MCQ_WAVE + lane;
                 if (it < qc.runs) {
                     McqExtReplayDraws dr = {dbase + it, stride};
-                    mcq_iteration_ext(qc, dr, cards, tab.sel8, my_sets, my_sets + 6, my_ids, kExtBlock, tab.tf, tab.tops,
+                    mcq_iteration_ext(qc, dr, cards, tab.sel8, my_sets, my_sets + 6, my_ids, kExtBlock, g_tab->tf, tab.tops,
                                       tab.sd, acc);
                 }
             }
@@ -421,7 +397,7 @@ __global__ __launch_bounds__(256) void mcq_showdown_kernel(const uint8_t *__rest
                                                            uint32_t n_players, const McqTables *__restrict__ g_tab,
                                                            uint8_t *__restrict__ winner, uint8_t *__restrict__ wtype,
                                                            uint32_t *__restrict__ keys) {
-    __shared__ __attribute__((aligned(16))) LdsTables tab;
+    __shared__ __attribute__((aligned(16))) LdsTablesEval tab;
     load_tables(tab, g_tab);
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_tables; t += gridDim.x * blockDim.x) {
         uint32_t best = 0, w = 0;
@@ -435,7 +411,7 @@ __global__ __launch_bounds__(256) void mcq_showdown_kernel(const uint8_t *__rest
             hole.set(mcq_card(h[0] < 52 ? h[0] : 0), mcq_card(h[1] < 52 ? h[1] : 0));
             McqFlushSel fs;
             fs.from_board(b);
-            const uint32_t key = mcq_eval_key(b, fs, hole, tab.tf, tab.tops, tab.sd);
+            const uint32_t key = mcq_eval_key(b, fs, hole, g_tab->tf, tab.tops, tab.sd);
             if (keys) keys[(size_t)t * n_players + p] = key;
             if (key > best) { best = key; w = p; } /* strict: the first of equal hands stays (hand_evaluator.py:23) */
         }
