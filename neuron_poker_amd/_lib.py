@@ -6,6 +6,7 @@ missing, or no HIP device can be opened, this module raises -- it never falls ba
 import ctypes as C
 import importlib.util
 import os
+import struct
 import sys
 import threading
 
@@ -155,6 +156,19 @@ def pack_queries(hole, board, n_players, runs):
         raise ValueError("runs out of range")
     q["runs"] = r.astype(np.uint32)
     return q
+
+
+def pack_query_one(hole, board, n_players, runs):
+    """One mcq_query record without the numpy machinery of pack_queries (the per-call path of get_equity):
+    hole = two card ids, board = up to five card ids (left-packed as given)."""
+    nb = len(board)
+    if len(hole) != 2 or nb > 5:
+        raise ValueError("two hole cards and at most five table cards")
+    try:
+        raw = struct.pack("<2B5BBB3xI", hole[0], hole[1], *(list(board) + [0] * (5 - nb)), nb, n_players, runs)
+    except struct.error as e:
+        raise ValueError("card id, n_players or runs out of range: %s" % e)
+    return np.frombuffer(bytearray(raw), QUERY_DTYPE)  # writable
 
 
 def class_bit(name):

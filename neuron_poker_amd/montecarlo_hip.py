@@ -110,7 +110,7 @@ def _query(player_cards, table_cards, players, runs):
     runs = int(runs)
     if runs < 1:
         raise ValueError("runs must be >= 1")
-    return _lib.pack_queries([hole], [board + [255] * (5 - len(board))], players, runs)
+    return _lib.pack_query_one(hole, board, players, runs)
 
 
 class MonteCarlo(object):
