@@ -631,3 +631,27 @@ def test_c_example_runs_against_the_c_abi(tmp_path):
     assert "100000 iterations" in lines[0] and abs(float(lines[0].split("equity ")[1].split()[0]) - 0.6598) < 0.006
     assert "0.659833" in lines[1]
     assert lines[2].startswith("512 tables, 1000 lock-steps") and "512000 equity queries" in lines[2]
+
+
+def test_bench_two_rank_rehearsal_on_one_gpu():
+    """bench.py's N > 1 control flow (one process per rank, tallies all-reduced, max-over-ranks timing, one JSON line
+    from rank 0) with two ranks sharing this GPU and gloo carrying the collective; the real runs use RCCL."""
+    import json as _json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--states", "256", "--iters", "3000",
+                          "--backend", "gloo", "--single-device"], capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [x for x in out.stdout.splitlines() if x.startswith("{")]
+    assert len(line) == 1, out.stdout
+    d = _json.loads(line[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["hand_evals_per_step"] == 2 * 256 * 3000 * 6
