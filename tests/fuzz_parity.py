@@ -8,7 +8,8 @@ task boundaries and a few long ones) and checks, against oracle/ (test infrastru
   * production mode (MCQ_MODE_PHILOX), reference and uniform dealing law, random first_query_id;
   * parity mode (MCQ_MODE_REPLAY_MT19937);
   * shares of an iteration split (mcq_eval_batch_part) add up to the whole;
-  * every fourth round a batch of extended queries (ranges, hero range, ghost cards, second known hand) in both modes.
+  * every fourth round a batch of extended queries (ranges, hero range, ghost cards, second known hand) in both modes;
+  * every 64th round exact enumerations (1-3 players, river / turn / flop) against tests/hostsim, both laws.
 Prints one summary line; exits non-zero on the first mismatch.
 """
 import argparse
@@ -74,6 +75,25 @@ def ext_round(g, eng):
     return n, int(q["runs"].astype(np.int64).sum())
 
 
+def exact_round(g, eng):
+    """Exact enumeration on the GPU against the host build of the same lane code (tests/hostsim), integers."""
+    from tests import hostsim as H
+    n = 6
+    hole, board, npl = [], [], []
+    for i in range(n):
+        nb, players = [(5, 1), (5, 2), (4, 2), (3, 2), (5, 3), (4, 1)][i]
+        c = g.permutation(52)[:2 + nb]
+        hole.append(c[:2])
+        board.append(list(c[2:]) + [255] * (5 - nb))
+        npl.append(players)
+    q = npa.pack_queries(hole, board, npl, 1)
+    for law, uni in (("reference", False), ("uniform", True)):
+        got = eng.exact(q, law).view(np.uint64).reshape(-1, 13)
+        for i in range(n):
+            assert np.array_equal(got[i], H.exact(q[i:i + 1].view(np.uint8).reshape(16), uni)), ("exact", law, i)
+    return 2 * n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
@@ -82,7 +102,7 @@ def main():
     g = np.random.default_rng(a.seed)
     eng = npa.Engine(0)
     t0 = time.time()
-    rounds = queries = iters = ext_q = ext_i = 0
+    rounds = queries = iters = ext_q = ext_i = exact_n = 0
     while time.time() - t0 < a.seconds:
         q = batch(g)
         raw = q.view(np.uint8).reshape(-1, 16)
@@ -108,9 +128,12 @@ def main():
             nq, ni = ext_round(g, eng)
             ext_q += 2 * nq
             ext_i += 2 * ni
+        if rounds % 64 == 0:
+            exact_n += exact_round(g, eng)
     print("fuzz parity: %d rounds, %d query evaluations, %d iterations in 4 configurations; %d extended-query "
-          "evaluations, %d iterations in both modes -- all bit-exact against the oracle (%.0f s, seed %d)"
-          % (rounds, queries, iters, ext_q, ext_i, time.time() - t0, a.seed))
+          "evaluations, %d iterations in both modes -- all bit-exact against the oracle; %d exact enumerations equal "
+          "to the host build of the lane code (%.0f s, seed %d)"
+          % (rounds, queries, iters, ext_q, ext_i, exact_n, time.time() - t0, a.seed))
 
 
 if __name__ == "__main__":
