@@ -151,7 +151,8 @@ struct McqTables { /* order matters on the device: the first 64 KB are reachable
                      the sparsest, is the one that costs least there (measured) */
     uint32_t tops[8192];
     uint32_t sd[16384]; /* [0, 8192) sd, [8192, 16384) kc */
-    uint32_t tf[8192];
+    uint32_t tf[16384]; /* [0, 8192) tf, [8192, 16384) a second copy of tops for the lookup that goes through
+                           global memory with tf (tops[ge3], see mcq_eval_key) */
     uint32_t sel8[256];
 };
 #define MCQ_KC_BYTE_OFFSET 32768u /* kc relative to sd */
@@ -177,6 +178,7 @@ static inline void mcq_fill_tables(McqTables *t) {
         uint32_t hi1 = m ? 0x80000000u >> __builtin_clz(m) : 0, hi2 = 0;
         if (n >= 2) hi2 = hi1 | (0x80000000u >> __builtin_clz(m ^ hi1));
         t->tops[m] = (hi2 << 2) | (hi1 << 18);
+        t->tf[8192 + m] = t->tops[m];
         uint32_t key = 0;
         if (n >= 5) {
             if (runs) {
@@ -402,10 +404,10 @@ MCQ_HD uint32_t mcq_eval_key(const McqBoard &b, const McqFlushSel &fs, const Mcq
 
     /* lookups first: their latency overlaps the arithmetic below */
     const uint32_t e_ge2 = mcq_ld_u32(tops, ge2);
-    /* tops[ge3] from the table image tf belongs to (tf is always part of a whole McqTables image): in the
-     * evaluation kernels that is the GLOBAL copy -- the vector-memory path takes a second sparse lookup off the
-     * LDS pipe (ge3 is zero for 19 hands in 20: one cache line); measured 7.17 -> 7.04 ms, a third one loses */
-    const uint32_t e_ge3 = mcq_ld_u32(tf - MCQ_TF_BYTE_OFFSET / 4u, ge3);
+    /* tops[ge3] from the copy of tops behind tf: in the kernels tf is the GLOBAL image, and the vector-memory
+     * path takes this second sparse lookup off the LDS pipe as well (ge3 is zero for 19 hands in 20: one cache
+     * line); measured 7.17 -> 7.04 ms, a third lookup there loses */
+    const uint32_t e_ge3 = mcq_ld_u32(tf + 8192, ge3);
     const uint32_t d_any = mcq_ld_u32(sd, any);
     const uint32_t d_kick = mcq_ld_u32(sd, (any ^ ge2) + MCQ_KC_BYTE_OFFSET); /* kickers | type code of family F1 */
     const uint32_t key_f = mcq_ld_u32(tf, fs.bfl4 | mcq_bfe(fs.use_hi ? h.his : h.los, fs.sh, 16)); /* tf: LDS or global */
