@@ -655,3 +655,31 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
     d = _json.loads(line[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["hand_evals_per_step"] == 2 * 256 * 3000 * 6
+
+
+def test_device_entry_inside_a_hip_graph(eng):
+    """mcq_eval_batch_device launches only asynchronous work on the caller's stream, so it can be captured into a
+    HIP graph (here through torch.cuda.CUDAGraph) and replayed: a launch-bound small batch then costs one graph
+    launch.  The replay must give the host entry's tallies."""
+    import torch
+    dev = torch.device("cuda", 0)
+    g = np.random.default_rng(12)
+    B = 384
+    hole = np.array([g.permutation(52)[:2] for _ in range(B)], np.uint8)
+    q = npa.pack_queries(hole, np.full((B, 5), 255, np.uint8), 4, 1500)
+    want = eng.eval_batch(q, 424242, first_query_id=9).view(np.uint64).reshape(-1, 13)
+    d_q = torch.from_numpy(q.view(np.uint8).reshape(B, 16).copy()).to(dev)
+    out = torch.zeros((B, 13), dtype=torch.int64, device=dev)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):       # warm-up on the side stream: sizes the engine's prefix buffer before capture
+        eng.eval_batch_device(d_q.data_ptr(), B, 1, out.data_ptr(), first_query_id=0, stream=s.cuda_stream)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        eng.eval_batch_device(d_q.data_ptr(), B, 424242, out.data_ptr(), first_query_id=9,
+                              stream=torch.cuda.current_stream().cuda_stream)
+    for _ in range(3):
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), want)
