@@ -117,7 +117,7 @@ MCQ_HD void mcq_exact_board(const McqExactQuery &e, const uint32_t pos[5], const
 }
 
 // l-th (l < 45) card left after the completion: its R-position
-MCQ_HD uint32_t mcq_exact_rem_pos(const McqExactQuery &e, const uint32_t pos[5], uint32_t l) {
+MCQ_HD uint32_t mcq_exact_rem_pos(const uint32_t pos[5], uint32_t l) {
     uint32_t p = l;
 #pragma unroll
     for (uint32_t i = 0; i < 5; i++) p += p >= pos[i] ? 1u : 0u; /* unused entries are 255 */

@@ -465,7 +465,7 @@ __global__ __launch_bounds__(TWO_OPP ? 384 : 1024) void mcq_exact_kernel(uint4 r
         mcq_exact_board(e, pos, tab.sel8, g_tab->tf, tab.tops, tab.sd, bd);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); /* the previous unit's reads are done (same wave) */
         if (lane < MCQ_EXACT_REM) {
-            const uint32_t rp = mcq_exact_rem_pos(e, pos, lane);
+            const uint32_t rp = mcq_exact_rem_pos(pos, lane);
             rem_pos[lane] = rp;
             rem_card[lane] = mcq_card(mcq_exact_card_at(e, rp, tab.sel8));
         }

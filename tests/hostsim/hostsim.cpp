@@ -235,7 +235,7 @@ extern "C" int hs_exact(const mcq_query *q, int law, uint64_t *out13) {
         McqCard rem_card[64];
         uint32_t rem_pos[64];
         for (uint32_t l = 0; l < MCQ_EXACT_REM; l++) {
-            rem_pos[l] = mcq_exact_rem_pos(e, pos, l);
+            rem_pos[l] = mcq_exact_rem_pos(pos, l);
             rem_card[l] = mcq_card(mcq_exact_card_at(e, rem_pos[l], t.sel8));
         }
         uint64_t win = 0, tie = 0, tot = 0;
