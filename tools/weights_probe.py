@@ -3,7 +3,6 @@
 Feeds mcq_task_weight() in csrc/mcq_device.hpp (scheduling only)."""
 import os
 import sys
-import time
 
 import numpy as np
 
