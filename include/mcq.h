@@ -173,8 +173,8 @@ MCQ_API float mcq_last_kernel_ms(mcq_ctx *ctx);
  * query, finished episodes restart at once.  mcq_tables_begin writes the n_tables pending queries (table i ->
  * q[i]) and returns n_tables; mcq_tables_resume takes their equities ((win + tie) / runs) and advances every
  * table to its next query.  mcq_tables_run does `lock_steps` rounds of begin -> ONE mcq_eval_batch
- * (MCQ_MODE_PHILOX, seed cfg.seed, query ids counting up across calls) -> resume, and needs a context; when one
- * host thread steps the tables (fewer than 2048) it runs the two halves of the tables on two streams so that the host steps one half while the
+ * (MCQ_MODE_PHILOX, seed cfg.seed, query ids counting up across calls) -> resume, and needs a context; it
+ * runs the two halves of the tables on two streams so that the host steps one half while the
  * other half's batch is on the GPU -- every query keeps the id it has in the one-batch schedule, so the results
  * are the same.
  * begin/resume alone need no GPU (ctx may be NULL): that is how the CPU tests pin the rules.

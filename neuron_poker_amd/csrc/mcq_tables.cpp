@@ -468,10 +468,12 @@ struct mcq_tables {
     std::vector<double> eq;
     uint64_t calls;
     Pool *pool = nullptr;
+    Pool *pool2 = nullptr; /* the helper thread's pool in the two-stream schedule */
     mcq_ctx *ctx2 = nullptr; /* second stream + buffers: the upper half of the tables is stepped by a helper thread
                                 while the lower half's batch is on the GPU, and vice versa (mcq_tables_run) */
     ~mcq_tables() {
         delete pool;
+        delete pool2;
         if (ctx2) mcq_destroy(ctx2);
     }
     template <class F>
@@ -488,7 +490,7 @@ mcq_ctx *mcq_ctx_clone(const mcq_ctx *c);   /* mcq_host.cpp */
 
 /* lock-steps of the tables [a, b) on context ctx: query ids are those of the whole-batch schedule (step * n + table),
  * so the tallies do not depend on how the tables are divided */
-static int run_range(mcq_tables *t, mcq_ctx *ctx, size_t a, size_t b, uint32_t lock_steps, std::string *err) {
+static int run_range(mcq_tables *t, mcq_ctx *ctx, Pool *pool, size_t a, size_t b, uint32_t lock_steps, std::string *err) {
     const size_t n = t->tables.size();
     const uint32_t runs = t->cfg.runs;
     for (uint32_t s = 0; s < lock_steps; s++) {
@@ -499,11 +501,15 @@ static int run_range(mcq_tables *t, mcq_ctx *ctx, size_t a, size_t b, uint32_t l
             return rc;
         }
         const bool more = s + 1 < lock_steps;
-        for (size_t i = a; i < b; i++) {
-            Table &tb = t->tables[i];
-            tb.resume((double)(t->r[i].win + t->r[i].tie) / (double)t->r[i].runs);
-            if (more) tb.observe(t->q[i], runs);
-        }
+        auto step = [&](size_t x, size_t y) { /* answer, act, and issue the next query in one pass */
+            for (size_t i = a + x; i < a + y; i++) {
+                Table &tb = t->tables[i];
+                tb.resume((double)(t->r[i].win + t->r[i].tie) / (double)t->r[i].runs);
+                if (more) tb.observe(t->q[i], runs);
+            }
+        };
+        if (pool) pool->run(b - a, std::function<void(size_t, size_t)>(step));
+        else step(0, b - a);
     }
     return MCQ_OK;
 }
@@ -591,15 +597,17 @@ int mcq_tables_run(mcq_tables *t, uint32_t lock_steps, uint64_t *stats) {
     const size_t n = t->tables.size();
     const uint32_t runs = t->cfg.runs;
     if (lock_steps) mcq_tables_begin(t, t->q.data());
-    /* Medium table counts (no thread pool): two halves on two streams.  While one half's batch is on the GPU the
-     * other half's tables are stepped on the host; per-query ids, hence all results, are as in one batch per step. */
-    if (!t->pool && n >= 64 && lock_steps >= 4 && t->cfg.reserved[1] == 0) {
+    /* Two halves on two streams.  While one half's batch is on the GPU the other half's tables are stepped on the
+     * host (by its own thread pool when the table count is large); per-query ids, hence all results, are as in
+     * one batch per step. */
+    if (n >= 64 && lock_steps >= 4 && t->cfg.reserved[1] == 0) {
         if (!t->ctx2) t->ctx2 = mcq_ctx_clone(t->ctx);
-        if (t->ctx2) {
+        if (t->ctx2 && t->pool && !t->pool2) t->pool2 = new (std::nothrow) Pool(t->pool->parts() - 1u);
+        if (t->ctx2 && (!t->pool || t->pool2)) {
             std::string err2;
             int rc2 = MCQ_OK;
-            std::thread helper([&] { rc2 = run_range(t, t->ctx2, n / 2, n, lock_steps, &err2); });
-            int rc1 = run_range(t, t->ctx, 0, n / 2, lock_steps, nullptr);
+            std::thread helper([&] { rc2 = run_range(t, t->ctx2, t->pool2, n / 2, n, lock_steps, &err2); });
+            int rc1 = run_range(t, t->ctx, t->pool, 0, n / 2, lock_steps, nullptr);
             helper.join();
             if (rc1) return rc1; /* a failed half leaves its tables at the step it reached; the driver is not resumable then */
             if (rc2) { mcq_tables_set_error(err2.c_str()); return rc2; }
