@@ -520,6 +520,19 @@ MCQ_HD McqPart mcq_part(uint32_t tasks, uint32_t runs, uint32_t part, uint32_t n
     return p;
 }
 
+// Small batches: how finely the 1024-iteration tasks are cut (2^split sub-tasks each).  A lone wave per SIMD is bound
+// by the latency of its dependent LDS lookups, so tasks are cut while that leaves at most two waves per SIMD -- and
+// at most 512 waves on one query: every (wave, query) pair ends in twelve atomics on the query's result row, and
+// atomics on one address serialise (100k runs: 31 us uncut, 18 us in 392 pieces, 29 us in 1568).  The tallies do not
+// depend on the cut.  Decided on the host when it sees the queries, by the prep kernel when they live in HBM.
+#define MCQ_SPLIT_FROM_PREP 0xFFFFFFFFu /* evaluation kernel argument: read the cut the prep kernel chose */
+MCQ_HD uint32_t mcq_pick_split(uint64_t total_tasks, uint64_t max_tasks, uint32_t n_cu, uint32_t split_max) {
+    const uint64_t want = 8ull * n_cu;
+    uint32_t s = 0;
+    while (s < split_max && (total_tasks << (s + 1u)) <= want && (max_tasks << (s + 1u)) <= 512u) s++;
+    return s;
+}
+
 static inline McqQueryWords mcq_query_words(const mcq_query &q) { /* host side */
     McqQueryWords w;
     __builtin_memcpy(&w, &q, 16);

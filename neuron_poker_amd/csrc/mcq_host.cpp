@@ -121,16 +121,8 @@ void pick_geometry(const mcq_ctx *c, int mode, uint64_t total_tasks, uint32_t *g
     const uint32_t full = (uint32_t)c->n_cu * (uint32_t)c->occ[mode];
     if (split) *split = 0;
     if (total_tasks == 0) { *block = kBlock; *grid = full; return; }
-    /* small batches: a lone wave per SIMD is bound by the latency of its dependent LDS lookups, so tasks are cut
-     * into 2^split sub-tasks as long as that leaves at most two waves per SIMD -- and at most 512 waves on one
-     * query: every (wave, query) pair ends in twelve atomics on the query's result row, and atomics on one
-     * address serialise (measured: 100k runs 31 us uncut, 18 us in 392 pieces, 29 us in 1568; profiles/README.md).
-     * The tallies do not depend on the cut. */
-    if (split) {
-        const uint64_t want = 8ull * (uint64_t)c->n_cu;
-        if (max_tasks == 0) max_tasks = total_tasks;
-        while (*split < c->split_max && (total_tasks << (*split + 1)) <= want && (max_tasks << (*split + 1)) <= 512u)
-            ++*split;
+    if (split) { /* small batches are cut finer, see mcq_pick_split */
+        *split = mcq_pick_split(total_tasks, max_tasks ? max_tasks : total_tasks, (uint32_t)c->n_cu, c->split_max);
         total_tasks <<= *split;
     }
     /* one block per CU (the LDS tables allow no more); few tasks are spread over all CUs with fewer waves per
@@ -148,10 +140,13 @@ int run_slice(mcq_ctx *c, int mode, const mcq_query *d_q, uint32_t n, mcq_result
               uint64_t first_qid, uint64_t total_tasks, const uint8_t *d_draws, const uint64_t *d_off, hipStream_t s,
               bool timed, uint64_t max_tasks = 0, uint32_t part = 0, uint32_t n_parts = 1) {
     if (mode == MCQ_MODE_PHILOX && c->law == MCQ_LAW_UNIFORM) mode = MCQ_INTERNAL_MODE_UNIFORM;
-    HIP_TRY(c->d_prefix.reserve(((size_t)n + 1) * sizeof(uint64_t)));
-    HIP_TRY(mcq_launch_prep(d_q, n, d_res, (uint64_t *)c->d_prefix.p, part, n_parts, s));
+    HIP_TRY(c->d_prefix.reserve(((size_t)n + 2) * sizeof(uint64_t)));
+    HIP_TRY(mcq_launch_prep(d_q, n, d_res, (uint64_t *)c->d_prefix.p, part, n_parts, (uint32_t)c->n_cu, c->split_max, s));
     uint32_t grid, block, split;
     pick_geometry(c, mode, total_tasks, &grid, &block, &split, max_tasks);
+    /* queries in HBM (the host has not seen them): up to 1024 of them may be a small batch -- the prep kernel
+     * decides the cut and the evaluation kernel reads it; more queries are at least as many tasks: never cut */
+    if (total_tasks == 0 && n <= 1024u) split = MCQ_SPLIT_FROM_PREP;
     const int slot = (int)(c->n_timed % mcq_ctx::kRing);
     if (timed) HIP_TRY(hipEventRecord(c->ev0[slot], s));
     HIP_TRY(mcq_launch_eval(mode, d_q, n, (const uint64_t *)c->d_prefix.p, d_res, seed, first_qid, c->d_luts, d_draws,

@@ -10,7 +10,7 @@ struct McqTables;
 #define MCQ_INTERNAL_MODE_UNIFORM 2 /* MCQ_MODE_PHILOX with the context's dealing law set to MCQ_LAW_UNIFORM */
 
 hipError_t mcq_launch_prep(const mcq_query *d_q, uint32_t n, mcq_result *d_res, uint64_t *d_prefix, uint32_t part,
-                           uint32_t n_parts, hipStream_t s);
+                           uint32_t n_parts, uint32_t n_cu, uint32_t split_max, hipStream_t s);
 hipError_t mcq_launch_eval(int mode, const mcq_query *d_q, uint32_t n, const uint64_t *d_prefix, mcq_result *d_res,
                            uint64_t seed, uint64_t first_qid, const McqTables *d_luts, const uint8_t *d_draws,
                            const uint64_t *d_draw_off, uint32_t grid, uint32_t block, uint32_t split, uint32_t part,

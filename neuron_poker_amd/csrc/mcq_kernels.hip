@@ -58,15 +58,23 @@ __device__ __forceinline__ void load_tables(LdsTablesEval &dst, const McqTables 
 // passes = UINT64_MAX.
 __global__ __launch_bounds__(1024) void mcq_prep_kernel(const mcq_query *__restrict__ q, uint32_t n,
                                                         mcq_result *__restrict__ res, uint64_t *__restrict__ prefix,
-                                                        uint32_t part_idx, uint32_t n_parts) {
+                                                        uint32_t part_idx, uint32_t n_parts, uint32_t n_cu,
+                                                        uint32_t split_max) {
     __shared__ uint64_t part[1024];
     __shared__ uint64_t carry;
+    __shared__ unsigned long long sum_tasks;
+    __shared__ uint32_t max_tasks;
     const uint32_t tid = threadIdx.x;
-    if (tid == 0) carry = 0;
+    if (tid == 0) {
+        carry = 0;
+        sum_tasks = 0;
+        max_tasks = 0;
+    }
     __syncthreads();
     for (uint32_t base = 0; base < n; base += 1024) {
         uint32_t i = base + tid;
         uint64_t cost = 0;
+        uint32_t my_tasks = 0;
         if (i < n) {
             const uint4 raw = reinterpret_cast<const uint4 *>(q)[i];
             const McqQueryWords qq = {raw.x, raw.y, raw.z, raw.w};
@@ -75,11 +83,25 @@ __global__ __launch_bounds__(1024) void mcq_prep_kernel(const mcq_query *__restr
              * over devices, mcq_eval_batch_part) */
             const McqPart pt = mcq_part(mcq_task_count(qq), qq.runs(), part_idx, n_parts);
             cost = ok ? (uint64_t)(pt.t_hi - pt.t_lo) * mcq_task_weight(qq) : 0ull;
+            my_tasks = ok ? pt.t_hi - pt.t_lo : 0u;
             uint64_t *r = reinterpret_cast<uint64_t *>(res + i);
             r[0] = ok ? pt.runs : 0ull;
             r[1] = ok ? 0ull : ~0ull;
 #pragma unroll
             for (int k = 2; k < 13; k++) r[k] = 0;
+        }
+        if (n <= 1024u) { /* a possible small batch: what mcq_pick_split needs (below); one atomic per wave */
+            const uint32_t ws = wave_sum(my_tasks);
+            uint32_t wm = my_tasks;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const uint32_t o = __shfl_xor(wm, off, 64);
+                wm = o > wm ? o : wm;
+            }
+            if ((tid & 63u) == 0u && ws) {
+                atomicAdd(&sum_tasks, (unsigned long long)ws);
+                atomicMax(&max_tasks, wm);
+            }
         }
         part[tid] = cost;
         __syncthreads();
@@ -94,7 +116,11 @@ __global__ __launch_bounds__(1024) void mcq_prep_kernel(const mcq_query *__restr
         if (tid == 1023) carry += part[1023];
         __syncthreads();
     }
-    if (tid == 0) prefix[n] = carry;
+    if (tid == 0) {
+        prefix[n] = carry;
+        /* the cut for MCQ_SPLIT_FROM_PREP launches (queries resident in HBM, at most 1024 of them) */
+        prefix[n + 1] = n <= 1024u && sum_tasks ? mcq_pick_split(sum_tasks, max_tasks, n_cu, split_max) : 0u;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- eval
@@ -146,7 +172,10 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
                                                              const uint8_t *__restrict__ draws,
                                                              const uint64_t *__restrict__ draw_off, uint32_t split_arg,
                                                              uint32_t part, uint32_t n_parts) {
-    const uint32_t split = SPLIT ? split_arg : 0u; /* SPLIT = false: the bulk path, compiled without the cut */
+    /* SPLIT = false: the bulk path, compiled without the cut */
+    const uint32_t split = !SPLIT ? 0u
+                           : split_arg == MCQ_SPLIT_FROM_PREP ? (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)prefix[n + 1])
+                                                              : split_arg;
     /* split (0..4): small batches cut every 1024-iteration task into 2^split sub-tasks of 16 >> split iterations per
      * lane so that more waves share the work; the iterations and their random numbers stay the same (a sub-task
      * skips ahead in its lane's stream), so the tallies do not depend on it. */
@@ -493,9 +522,9 @@ __global__ __launch_bounds__(TWO_OPP ? 384 : 1024) void mcq_exact_kernel(uint4 r
 
 // ---------------------------------------------------------------------------------------------- launchers
 hipError_t mcq_launch_prep(const mcq_query *d_q, uint32_t n, mcq_result *d_res, uint64_t *d_prefix, uint32_t part,
-                           uint32_t n_parts, hipStream_t s) {
+                           uint32_t n_parts, uint32_t n_cu, uint32_t split_max, hipStream_t s) {
     if (n_parts == 0 || part >= n_parts) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(mcq_prep_kernel, dim3(1), dim3(1024), 0, s, d_q, n, d_res, d_prefix, part, n_parts);
+    hipLaunchKernelGGL(mcq_prep_kernel, dim3(1), dim3(1024), 0, s, d_q, n, d_res, d_prefix, part, n_parts, n_cu, split_max);
     return hipGetLastError();
 }
 
@@ -503,7 +532,7 @@ hipError_t mcq_launch_eval(int mode, const mcq_query *d_q, uint32_t n, const uin
                            uint64_t seed, uint64_t first_qid, const McqTables *d_luts, const uint8_t *d_draws,
                            const uint64_t *d_draw_off, uint32_t grid, uint32_t block, uint32_t split, uint32_t part,
                            uint32_t n_parts, hipStream_t s) {
-    if (split > 4 || n_parts == 0 || part >= n_parts) return hipErrorInvalidValue;
+    if ((split > 4 && split != MCQ_SPLIT_FROM_PREP) || n_parts == 0 || part >= n_parts) return hipErrorInvalidValue;
 #define MCQ_LAUNCH_EVAL(M)                                                                                        \
     do {                                                                                                          \
         if (split)                                                                                                \

@@ -683,3 +683,22 @@ def test_device_entry_inside_a_hip_graph(eng):
         graph.replay()
         torch.cuda.synchronize()
         assert np.array_equal(out.cpu().numpy().view(np.uint64), want)
+
+
+def test_device_entry_small_batches_are_cut_by_the_prep_kernel(eng):
+    """Queries resident in HBM: the host never sees them, so the prep kernel chooses the small-batch cut
+    (MCQ_SPLIT_FROM_PREP).  Tallies == the host entry == the oracle, for batch sizes around the 1024 limit."""
+    import torch
+    dev = torch.device("cuda", 0)
+    g = np.random.default_rng(77)
+    for B, runs in ((1, 100000), (1, 1000), (300, 1000), (1024, 1500), (1025, 700), (37, 1), (5, 1000000)):
+        hole = np.array([g.permutation(52)[:2] for _ in range(B)], np.uint8)
+        q = npa.pack_queries(hole, np.full((B, 5), 255, np.uint8), 2 + (B % 5), runs)
+        want = eng.eval_batch(q, 4711, first_query_id=3).view(np.uint64).reshape(-1, 13)
+        if B * runs <= 2_000_000:
+            assert np.array_equal(want, O.run_batch(O.MODE_CTR, q.view(np.uint8).reshape(-1, 16), 4711, first_qid=3, threads=8))
+        d_q = torch.from_numpy(q.view(np.uint8).reshape(B, 16).copy()).to(dev)
+        out = torch.zeros((B, 13), dtype=torch.int64, device=dev)
+        eng.eval_batch_device(d_q.data_ptr(), B, 4711, out.data_ptr(), first_query_id=3)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), want), (B, runs)
