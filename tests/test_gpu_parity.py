@@ -702,3 +702,31 @@ def test_device_entry_small_batches_are_cut_by_the_prep_kernel(eng):
         eng.eval_batch_device(d_q.data_ptr(), B, 4711, out.data_ptr(), first_query_id=3)
         torch.cuda.synchronize()
         assert np.array_equal(out.cpu().numpy().view(np.uint64), want), (B, runs)
+
+
+def test_torch_tensors_in_hbm_end_to_end(eng):
+    """neuron_poker_amd.torch_ops: states as CUDA tensors -> equity as a CUDA tensor, nothing through the host; the
+    numbers are those of the host entry."""
+    import torch
+    from neuron_poker_amd import torch_ops
+    dev = torch.device("cuda", 0)
+    g = np.random.default_rng(31)
+    B = 700
+    hole = np.zeros((B, 2), np.uint8)
+    board = np.full((B, 5), 255, np.uint8)
+    for i in range(B):
+        nb = [0, 3, 4, 5][i % 4]
+        c = g.permutation(52)[:2 + nb]
+        hole[i] = c[:2]
+        slots = g.permutation(5)[:nb]          # empty slots anywhere: the packing moves the cards to the left
+        board[i, slots] = c[2:]
+    npl = g.integers(1, 11, B).astype(np.uint8)
+    runs = g.choice([1, 64, 1000, 1500], B).astype(np.int32)
+    eq_ref, t_ref = mh.get_equity_batch(hole, board, npl, runs, seed=99, first_query_id=5, engine=eng)
+    eq, t = torch_ops.get_equity_batch_torch(torch.from_numpy(hole).to(dev), torch.from_numpy(board).to(dev),
+                                             torch.from_numpy(npl).to(dev), torch.from_numpy(runs).to(dev),
+                                             seed=99, first_query_id=5, engine=eng)
+    assert eq.is_cuda and t.is_cuda
+    assert np.array_equal(t.cpu().numpy().view(np.uint64), t_ref) and np.array_equal(eq.cpu().numpy(), eq_ref)
+    with pytest.raises(ValueError):
+        torch_ops.get_equity_batch_torch(torch.from_numpy(hole), torch.from_numpy(board), 2, 10)
