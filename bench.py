@@ -94,6 +94,64 @@ def cpu_reference_cpp(n_players, seconds=4.0):
                       "iterations), %.1f s; uniform dealing, so a timing reference only" % (n_players, iters, dt)}
 
 
+def launch_ranks(n, argv):
+    """Run this script as n ranks (one process per GPU) under torch.distributed.run in a child process; returns its
+    exit code.  stdout / stderr are inherited, so rank 0's JSON line is this command's JSON line."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def native_multi(args):
+    """--native-multi: the whole job in one process through mcq_multi_eval_batch (include/mcq.h)."""
+    import neuron_poker_amd as npa
+    n_dev = npa.load_library().mcq_device_count()
+    devices = [0] * args.gpus if args.single_device else list(range(args.gpus))
+    if not args.single_device and args.gpus > n_dev:
+        raise SystemExit("--gpus %d but %d devices visible" % (args.gpus, n_dev))
+    me = npa.MultiEngine(devices)
+    B, N, runs = args.states * args.gpus, args.players, args.iters
+    hole = np.concatenate([make_states(args.states, r)[0] for r in range(args.gpus)])
+    board = np.full((B, 5), 255, np.uint8)
+    q = npa.pack_queries(hole, board, N, runs)
+    seed = 20261004
+    for i in range(args.warmup):
+        me.eval_batch(q, seed + i)
+    kmax, ar = [], []
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        res = me.eval_batch(q, seed + args.warmup + i)
+        t = me.last_times_ms
+        kmax.append(t["kernel_max"])
+        ar.append(t["all_reduce"])
+    elapsed = time.perf_counter() - t0
+    t = res.view(np.uint64).reshape(-1, 13)
+    assert (t[:, 0] == runs).all() and np.array_equal(t[:, 2] + t[:, 3], t[:, 4:].sum(1))
+    evals = float(B) * runs * N
+    info = me.info
+    print(json.dumps({
+        "metric": "Monte Carlo hand evals/sec @100k iters, 6-max preflop", "value": evals * args.steps / elapsed,
+        "unit": "hand-evals/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u32", "data": "synthetic",
+        "config": {"workload": "%d random preflop states per GPU x %d players x %d iterations, ONE process, %d shards on "
+                               "devices %s via mcq_multi_eval_batch (host buffers: PCIe-inclusive), partition '%s', one "
+                               "ncclAllReduce over %d device(s)" % (args.states, N, runs, info["shards"], devices,
+                                                                    info["last_partition"], info["devices"]),
+                   "states_per_gpu": args.states, "n_players": N, "iterations": runs, "hand_evals_per_step": evals},
+        "native_multi": {"kernel_max_ms": float(np.mean(kmax)), "all_reduce_ms": float(np.mean(ar)),
+                         "rccl_version": info["rccl_version"]}}), flush=True)
+    me.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,9 +163,21 @@ def main():
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) for real runs; gloo rehearses the N > 1 control "
                     "flow (tallies all-reduced through host memory)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--native-multi", action="store_true", help="ONE process drives all --gpus devices through the C ABI's "
+                    "mcq_multi_* entry (shards + one ncclAllReduce from ncclCommInitAll) instead of one rank per GPU; "
+                    "host buffers, so the figure includes PCIe")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
+
+    if args.native_multi:
+        return native_multi(args)
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not under_launcher:
+        # `python bench.py --gpus N` as such: start the one-process-per-GPU job as a CHILD (torch.distributed.run ->
+        # N ranks) before this process has touched the GPU or imported torch, and hand its output and exit code on.
+        # (Never an exec: a process that has initialised the GPU must not be replaced.)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -117,15 +187,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                             "--master-addr 127.0.0.1 bench.py --gpus %d ..." % (args.gpus, args.gpus))
         raise SystemExit("--gpus (%d) != WORLD_SIZE (%d)" % (args.gpus, world))
     if args.single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # under the launcher the process group is formed even for one rank, so that a 1-GPU box runs the very RCCL
+    # calls (init, all-reduce, barrier) the N-GPU job makes
+    grouped = under_launcher
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -143,11 +213,11 @@ def main():
     seed = 20261004
 
     def step(i):
-        if world > 1:
+        if grouped:
             tallies.zero_()
         eng.eval_batch_device(d_q.data_ptr(), B, seed + i, mine.data_ptr(), first_query_id=rank * B,
                               stream=stream.cuda_stream)
-        if world > 1:
+        if grouped:
             if args.backend == "nccl":
                 dist.all_reduce(tallies, op=dist.ReduceOp.SUM)  # the path's one collective: integer tallies over xGMI
             else:  # rehearsal through host memory
@@ -157,7 +227,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -169,7 +239,7 @@ def main():
         step(args.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if grouped:
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
@@ -185,8 +255,7 @@ def main():
     value = evals_per_step * args.steps / elapsed
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     ops_per_launch = float(B) * runs * alg_ops_per_iteration(N, 0)
@@ -208,8 +277,8 @@ def main():
         "config": {"workload": "%d random preflop states per GPU (default_rng(4096+rank), as BASELINE configs[2]) x "
                                "%d players x %d iterations, production RNG (Philox-keyed xoshiro128++), queries and "
                                "tallies resident in HBM%s" %
-                               (B, N, runs, ", one RCCL all-reduce of the [%d,13] int64 tally matrix per step" %
-                                (world * B) if world > 1 else ""),
+                               (B, N, runs, ", one %s all-reduce of the [%d,13] int64 tally matrix per step" %
+                                ("RCCL" if args.backend == "nccl" else args.backend, world * B) if grouped else ""),
                    "states_per_gpu": B, "n_players": N, "iterations": runs, "n_board": 0,
                    "hand_evals_per_step": evals_per_step},
         "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_VALU_TOPS, "unit": "Tops/s (int32 lane-ops)",
@@ -255,6 +324,22 @@ def main():
         dt = time.perf_counter() - t1
         extras["configs[3]_65536x6x20k_on_one_gpu"] = {"call_ms_host_buffers": 1e3 * dt, "kernel_ms": eng.last_kernel_ms,
                                                        "hand_evals_per_s": 65536 * 6 * 20000 / dt}
+        # the same batch through the single-process multi-GPU entry of the C ABI (mcq_multi_*: shards -> ONE
+        # ncclAllReduce of the tally matrix): 1 shard, and the 8-way partition of configs[3] with all 8 shards on this
+        # one device (what 8 GPUs run side by side, serialised here); the communicator has one rank on a 1-GPU box
+        ref4 = eng.eval_batch(q4, seed=2)
+        for shards in (1, 8):
+            me = npa.MultiEngine([local_rank] * shards)
+            me.eval_batch(q4, seed=1)
+            t1 = time.perf_counter()
+            r4 = me.eval_batch(q4, seed=2)
+            dt = time.perf_counter() - t1
+            tm = me.last_times_ms
+            extras["configs[3]_native_multi_%d_shard%s_on_one_gpu" % (shards, "s" if shards > 1 else "")] = {
+                "call_ms_host_buffers": 1e3 * dt, "kernel_max_ms": tm["kernel_max"], "all_reduce_ms": tm["all_reduce"],
+                "hand_evals_per_s": 65536 * 6 * 20000 / dt, "rccl_version": me.info["rccl_version"],
+                "equals_single_context": bool(np.array_equal(r4, ref4))}
+            me.close()
         # BASELINE configs[4], equity side only: one lock-step of 512 six-seat tables issues <= 2 x 512 queries of 1000
         # runs (gym_env/env.py:22,261-262) in ONE call; state mix as observed in reference episodes (SURVEY 8c F5:
         # table cards 0/3/4/5 = 59/19/11/10 %, players alive 2..6 = 41/28/17/9/6 %).  The table logic itself is
@@ -297,8 +382,8 @@ def main():
         ref = cpu_reference_cpp(N)
         if ref:
             out["cpu_baseline_reference_cpp"] = ref
-    print(json.dumps(out))
-    if world > 1:
+    print(json.dumps(out), flush=True)
+    if grouped:
         dist.destroy_process_group()
 
 

@@ -206,6 +206,34 @@ MCQ_API void mcq_tables_stats(const mcq_tables *t, uint64_t stats[3]);
  * legal-move bit mask (bit = gym_env/enums.py Action value), driver phase */
 MCQ_API int mcq_tables_state(const mcq_tables *t, uint32_t table, double *stacks, int32_t info[8]);
 
+/* ---- One node, several GPUs, ONE process (the reference itself is single-device, so this has no
+ * counterpart there -- it is what a batched caller of get_equity binds when a node has more than one GPU).
+ * The batch is partitioned over n_shards SHARDS, shard s on HIP device devices[s] (devices = NULL: shard s on
+ * device s); a device may appear more than once (an 8-way partition rehearsed on one GPU, or several streams per
+ * GPU).  Each shard owns an engine context, a host worker thread and a stream.  Partition of a call:
+ *   MCQ_PARTITION_QUERIES     shard s evaluates queries [n*s/k, n*(s+1)/k) under their own query ids
+ *   MCQ_PARTITION_ITERATIONS  every shard evaluates share s of k of EVERY query's iterations (few large queries)
+ *   MCQ_PARTITION_AUTO        queries when n >= 256 * n_shards, else iterations
+ * Every shard fills its part of a zero-initialised [n, 13] uint64 tally matrix on its device; shards that share a
+ * device are added there, and ONE ncclAllReduce(ncclUint64, ncclSum) over the distinct devices (communicators
+ * from ncclCommInitAll, owned by the mcq_multi object; RCCL over xGMI) leaves the complete matrix on every device;
+ * out[0..n) is copied from the first.  The tallies are bit-identical to mcq_eval_batch on one context with the same
+ * (seed, first_query_id), whatever the partition.  MCQ_MODE_PHILOX.  RCCL is bound (dlopen) when the first
+ * mcq_multi is created; a process that never creates one never maps it. */
+#define MCQ_PARTITION_AUTO 0
+#define MCQ_PARTITION_QUERIES 1
+#define MCQ_PARTITION_ITERATIONS 2
+typedef struct mcq_multi mcq_multi;
+MCQ_API mcq_multi *mcq_multi_create(const int *devices, int n_shards, int flags); /* NULL + mcq_last_error; flags 0 */
+MCQ_API void mcq_multi_destroy(mcq_multi *m);
+MCQ_API int mcq_multi_eval_batch(mcq_multi *m, const mcq_query *q, size_t n, uint64_t seed, uint64_t first_query_id,
+                                 int partition, mcq_result *out);
+MCQ_API int mcq_multi_set_dealing_law(mcq_multi *m, int law);
+/* info: shards, distinct devices (= ranks of the all-reduce), RCCL version code, partition of the last call */
+MCQ_API int mcq_multi_info(const mcq_multi *m, int info[4]);
+/* last call, milliseconds: slowest shard's evaluation kernel, the all-reduce (device 0's stream), whole call (wall) */
+MCQ_API int mcq_multi_times(const mcq_multi *m, float ms[3]);
+
 MCQ_API const char *mcq_last_error(void);
 MCQ_API void mcq_version(int *major, int *minor, int *patch);
 

@@ -117,6 +117,18 @@ def load_library():
         L.mcq_tables_stats.restype = None
         L.mcq_tables_state.argtypes = [vp, C.c_uint32, vp, vp]
         L.mcq_tables_state.restype = C.c_int
+        L.mcq_multi_create.argtypes = [vp, C.c_int, C.c_int]
+        L.mcq_multi_create.restype = vp
+        L.mcq_multi_destroy.argtypes = [vp]
+        L.mcq_multi_destroy.restype = None
+        L.mcq_multi_eval_batch.argtypes = [vp, vp, sz, u64, u64, C.c_int, vp]
+        L.mcq_multi_eval_batch.restype = C.c_int
+        L.mcq_multi_set_dealing_law.argtypes = [vp, C.c_int]
+        L.mcq_multi_set_dealing_law.restype = C.c_int
+        L.mcq_multi_info.argtypes = [vp, vp]
+        L.mcq_multi_info.restype = C.c_int
+        L.mcq_multi_times.argtypes = [vp, vp]
+        L.mcq_multi_times.restype = C.c_int
         L.mcq_last_error.argtypes = []
         L.mcq_last_error.restype = C.c_char_p
         L.mcq_version.argtypes = [C.POINTER(C.c_int)] * 3
@@ -336,6 +348,79 @@ class Engine:
     @property
     def last_kernel_ms(self):
         return float(self._lib.mcq_last_kernel_ms(self._ctx))
+
+
+PARTITION_AUTO, PARTITION_QUERIES, PARTITION_ITERATIONS = 0, 1, 2
+_PARTITIONS = {None: 0, "auto": 0, "queries": 1, "iterations": 2, 0: 0, 1: 1, 2: 2}
+
+
+class MultiEngine:
+    """mcq_multi: one process driving several GPUs of a node (include/mcq.h).  The batch is partitioned over
+    shards, ONE RCCL all-reduce of the integer tally matrix joins them; results are bit-identical to Engine.eval_batch.
+
+    devices: one HIP device ordinal per shard (a device may repeat); None = every visible device once."""
+
+    def __init__(self, devices=None):
+        self._lib = load_library()
+        if devices is None:
+            n = self._lib.mcq_device_count()
+            if n <= 0:
+                raise McqError("no HIP device visible: " + (self._lib.mcq_last_error() or b"").decode("utf-8", "replace"))
+            devices = list(range(n))
+        devs = np.ascontiguousarray(devices, dtype=np.int32)
+        self._m = self._lib.mcq_multi_create(devs.ctypes.data, len(devs), 0)
+        if not self._m:
+            msg = (self._lib.mcq_last_error() or b"").decode("utf-8", "replace")
+            raise McqError("mcq_multi_create(%s) failed: %s" % (list(devs), msg))
+        self.devices = [int(d) for d in devs]
+
+    def close(self):
+        if getattr(self, "_m", None):
+            self._lib.mcq_multi_destroy(self._m)
+            self._m = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_dealing_law(self, law):
+        code = {"reference": 0, "uniform": 1, 0: 0, 1: 1}.get(law)
+        if code is None:
+            raise ValueError("law must be 'reference' or 'uniform'")
+        rc = self._lib.mcq_multi_set_dealing_law(self._m, code)
+        if rc:
+            _raise(rc)
+
+    def eval_batch(self, queries, seed, first_query_id=0, partition=None):
+        """queries: array of QUERY_DTYPE (host) -> array of RESULT_DTYPE; partition 'auto' | 'queries' | 'iterations'."""
+        if partition not in _PARTITIONS:
+            raise ValueError("partition must be 'auto', 'queries' or 'iterations'")
+        q = np.ascontiguousarray(queries, dtype=QUERY_DTYPE).reshape(-1)
+        out = np.zeros(len(q), RESULT_DTYPE)
+        rc = self._lib.mcq_multi_eval_batch(self._m, q.ctypes.data, len(q), int(seed) & (2 ** 64 - 1),
+                                            int(first_query_id) & (2 ** 64 - 1), _PARTITIONS[partition], out.ctypes.data)
+        if rc:
+            _raise(rc)
+        return out
+
+    @property
+    def info(self):
+        v = np.zeros(4, np.int32)
+        rc = self._lib.mcq_multi_info(self._m, v.ctypes.data)
+        if rc:
+            _raise(rc)
+        return {"shards": int(v[0]), "devices": int(v[1]), "rccl_version": int(v[2]),
+                "last_partition": {0: "auto", 1: "queries", 2: "iterations"}[int(v[3])]}
+
+    @property
+    def last_times_ms(self):
+        v = np.zeros(3, np.float32)
+        rc = self._lib.mcq_multi_times(self._m, v.ctypes.data)
+        if rc:
+            _raise(rc)
+        return {"kernel_max": float(v[0]), "all_reduce": float(v[1]), "call": float(v[2])}
 
 
 class Tables:

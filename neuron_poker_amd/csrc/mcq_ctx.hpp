@@ -1,0 +1,127 @@
+// mcq_ctx.hpp -- the engine context and the host-side helpers shared by the C-ABI translation units
+// (mcq_host.cpp, mcq_multi.cpp).  Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <exception>
+#include <new>
+#include <string>
+
+#include "../../include/mcq.h"
+
+struct McqTables;
+
+/* thread-local error text behind mcq_last_error(); returns `code` */
+int mcq_fail(int code, const char *what, const char *detail = nullptr);
+
+#define HIP_TRY(expr)                                                                                        \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess)                                                                                \
+            return mcq_fail(e_ == hipErrorOutOfMemory ? MCQ_ENOMEM : MCQ_EDEVICE, #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+/* No C++ exception may cross the C ABI (std::bad_alloc from the staging vectors, std::system_error from thread
+ * creation): every entry point body runs inside this guard. */
+#define ABI_GUARD_BEGIN try {
+#define ABI_GUARD_END(who)                                                                      \
+    }                                                                                           \
+    catch (const std::bad_alloc &) { return mcq_fail(MCQ_ENOMEM, who, "out of host memory"); } \
+    catch (const std::exception &ex) { return mcq_fail(MCQ_EDEVICE, who, ex.what()); }         \
+    catch (...) { return mcq_fail(MCQ_EDEVICE, who, "unexpected exception"); }
+
+/* Entry points select the context's device and leave the caller's current device as they found it (a host
+ * application -- or torch -- keeps its own notion of "current device"). */
+struct McqDeviceScope {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit McqDeviceScope(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) err = hipSetDevice(device);
+        else prev = -1; /* nothing to restore */
+    }
+    ~McqDeviceScope() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    McqDeviceScope(const McqDeviceScope &) = delete;
+    McqDeviceScope &operator=(const McqDeviceScope &) = delete;
+};
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct PinBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct mcq_ctx {
+    int device = 0;
+    int n_cu = 0;
+    int occ[3] = {1, 1, 1}; /* resident kBlock-thread blocks per CU of the eval kernels (by internal mode) */
+    int law = MCQ_LAW_REFERENCE;
+    uint32_t split_max = 4; /* finest cut of a task for small batches: 16 >> split_max iterations per lane */
+    hipStream_t stream = nullptr;
+    static constexpr int kRing = 64; /* event pairs around the most recent evaluation-kernel launches */
+    hipEvent_t ev0[kRing] = {}, ev1[kRing] = {};
+    uint64_t n_timed = 0;
+    float last_ms = 0.f;
+    McqTables *d_luts = nullptr;
+    /* Scheduling scratch (cost prefix + the small-batch cut) of the evaluation launches, ONE PER STREAM the context
+     * has launched on: the prep kernel of a later call must not overwrite what an evaluation kernel still running
+     * on another stream reads.  Calls on one stream are ordered by the stream.  Slot 0 belongs to the context's own
+     * stream (host entries). */
+    static constexpr int kScratch = 16;
+    struct Scratch {
+        hipStream_t stream = nullptr;
+        bool used = false, pinned = false, done_recorded = false;
+        uint64_t last_use = 0;
+        hipEvent_t done = nullptr; /* recorded after the latest evaluation kernel that reads this scratch */
+        DevBuf prefix;
+    } scratch[kScratch];
+    uint64_t scratch_clock = 0;
+    DevBuf d_q, d_res, d_draws, d_off, d_hands, d_win, d_wt, d_keys, d_ext, d_mt;
+    PinBuf h_q, h_res, h_draws, h_off, h_misc;
+};
+
+/* shared between the translation units (defined in mcq_host.cpp) */
+uint32_t mcq_tasks_of(const mcq_query &q);
+int mcq_validate_queries(const mcq_query *q, size_t n);
+/* prep + evaluation launch of n device-resident queries on stream s (asynchronous).  total_tasks = 0: unknown
+ * (queries never seen by the host). */
+int mcq_run_slice(mcq_ctx *c, int mode, const mcq_query *d_q, uint32_t n, mcq_result *d_res, uint64_t seed,
+                  uint64_t first_qid, uint64_t total_tasks, const uint8_t *d_draws, const uint64_t *d_off, hipStream_t s,
+                  bool timed, uint64_t max_tasks = 0, uint32_t part = 0, uint32_t n_parts = 1);

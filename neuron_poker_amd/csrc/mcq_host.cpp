@@ -15,6 +15,7 @@
 #include <thread>
 #include <vector>
 
+#include "mcq_ctx.hpp"
 #include "mcq_device.hpp"
 #include "mcq_internal.hpp"
 #include "mcq_replay.hpp"
@@ -25,7 +26,12 @@ namespace {
 
 thread_local std::string g_err;
 
-int fail(int code, const char *what, const char *detail = nullptr) {
+constexpr size_t kReplayChunkBytes = 256u << 20; /* draw bytes staged per launch in parity mode */
+constexpr uint32_t kBlock = 1024;                /* threads per block of the evaluation kernels */
+
+}  // namespace
+
+int mcq_fail(int code, const char *what, const char *detail) {
     g_err = what;
     if (detail) {
         g_err += ": ";
@@ -34,86 +40,7 @@ int fail(int code, const char *what, const char *detail = nullptr) {
     return code;
 }
 
-#define HIP_TRY(expr)                                                                               \
-    do {                                                                                            \
-        hipError_t e_ = (expr);                                                                     \
-        if (e_ != hipSuccess)                                                                       \
-            return fail(e_ == hipErrorOutOfMemory ? MCQ_ENOMEM : MCQ_EDEVICE, #expr, hipGetErrorString(e_)); \
-    } while (0)
-
-/* No C++ exception may cross the C ABI (std::bad_alloc from the staging vectors, std::system_error from thread
- * creation): every entry point body runs inside this guard. */
-#define ABI_GUARD_BEGIN try {
-#define ABI_GUARD_END(who)                                                     \
-    }                                                                          \
-    catch (const std::bad_alloc &) { return fail(MCQ_ENOMEM, who, "out of host memory"); } \
-    catch (const std::exception &ex) { return fail(MCQ_EDEVICE, who, ex.what()); }          \
-    catch (...) { return fail(MCQ_EDEVICE, who, "unexpected exception"); }
-
-struct DevBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-    hipError_t reserve(size_t bytes) {
-        if (bytes <= cap) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        size_t want = bytes + bytes / 4 + 256;
-        hipError_t e = hipMalloc(&p, want);
-        if (e == hipSuccess) cap = want;
-        return e;
-    }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-};
-
-struct PinBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-    hipError_t reserve(size_t bytes) {
-        if (bytes <= cap) return hipSuccess;
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        cap = 0;
-        size_t want = bytes + bytes / 4 + 256;
-        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
-        if (e == hipSuccess) cap = want;
-        return e;
-    }
-    void release() {
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-};
-
-constexpr size_t kReplayChunkBytes = 256u << 20; /* draw bytes staged per launch in parity mode */
-constexpr uint32_t kBlock = 1024;                /* threads per block of the evaluation kernels */
-
-}  // namespace
-
-struct mcq_ctx {
-    int device = 0;
-    int n_cu = 0;
-    int occ[3] = {1, 1, 1}; /* resident kBlock-thread blocks per CU of the eval kernels (by internal mode) */
-    int law = MCQ_LAW_REFERENCE;
-    uint32_t split_max = 4; /* finest cut of a task for small batches: 16 >> split_max iterations per lane */
-    hipStream_t stream = nullptr;
-    static constexpr int kRing = 64; /* event pairs around the most recent evaluation-kernel launches */
-    hipEvent_t ev0[kRing] = {}, ev1[kRing] = {};
-    uint64_t n_timed = 0;
-    float last_ms = 0.f;
-    McqTables *d_luts = nullptr;
-    DevBuf d_q, d_res, d_prefix, d_draws, d_off, d_hands, d_win, d_wt, d_keys, d_ext;
-    PinBuf h_q, h_res, h_draws, h_off, h_misc;
-};
-
 namespace {
-
-uint32_t tasks_of(const mcq_query &q) { return q.runs / MCQ_TASK_ITERS + (q.runs % MCQ_TASK_ITERS != 0u ? 1u : 0u); }
 
 /* grid/block for a launch whose total task count is known (host entry) or unknown (0) */
 void pick_geometry(const mcq_ctx *c, int mode, uint64_t total_tasks, uint32_t *grid, uint32_t *block,
@@ -136,12 +63,71 @@ void pick_geometry(const mcq_ctx *c, int mode, uint64_t total_tasks, uint32_t *g
     *grid = (uint32_t)(blocks < (uint64_t)c->n_cu ? blocks : (wpb == kBlock / 64 ? full : (uint64_t)c->n_cu));
 }
 
-int run_slice(mcq_ctx *c, int mode, const mcq_query *d_q, uint32_t n, mcq_result *d_res, uint64_t seed,
-              uint64_t first_qid, uint64_t total_tasks, const uint8_t *d_draws, const uint64_t *d_off, hipStream_t s,
-              bool timed, uint64_t max_tasks = 0, uint32_t part = 0, uint32_t n_parts = 1) {
+/* is stream s being captured into a graph? (a failing query counts as "no") */
+bool stream_capturing(hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return st != hipStreamCaptureStatusNone;
+}
+
+/* The scheduling scratch of stream s, at least `bytes` large.  A new stream takes a free slot, else the least
+ * recently used one (after making s wait for that slot's last reader).  Growing is not possible while s is being
+ * captured (hipMalloc / hipFree inside a capture would break it): the call fails cleanly instead. */
+int scratch_for(mcq_ctx *c, hipStream_t s, size_t bytes, bool capturing, mcq_ctx::Scratch **out) {
+    mcq_ctx::Scratch *slot = nullptr;
+    for (auto &sc : c->scratch)
+        if (sc.used && sc.stream == s) { slot = &sc; break; }
+    if (!slot) {
+        for (int i = 1; i < mcq_ctx::kScratch && !slot; i++)
+            if (!c->scratch[i].used) slot = &c->scratch[i];
+        if (!slot) {
+            for (int i = 1; i < mcq_ctx::kScratch; i++) {
+                mcq_ctx::Scratch &sc = c->scratch[i];
+                if (sc.pinned) continue;
+                if (!slot || sc.last_use < slot->last_use) slot = &sc;
+            }
+            if (!slot) return mcq_fail(MCQ_EINVAL, "mcq: every scheduling scratch slot is pinned by a captured graph");
+            if (capturing) {
+                if (hipEventQuery(slot->done) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return mcq_fail(MCQ_EINVAL, "mcq: no free scheduling scratch for a stream that is being captured");
+                }
+            } else {
+                HIP_TRY(hipStreamWaitEvent(s, slot->done, 0));
+            }
+        }
+        slot->stream = s;
+        slot->used = true;
+    }
+    if (bytes > slot->prefix.cap) {
+        if (capturing)
+            return mcq_fail(MCQ_EINVAL, "mcq_eval_batch_device: the context's scratch would have to grow inside a stream "
+                                        "capture; issue one call of at least this size on this stream before capturing");
+        if (slot->done_recorded) HIP_TRY(hipEventSynchronize(slot->done)); /* its last reader may still be running */
+        HIP_TRY(slot->prefix.reserve(bytes));
+    }
+    slot->last_use = ++c->scratch_clock;
+    if (capturing) slot->pinned = true; /* the graph keeps reading this buffer whenever it is replayed */
+    *out = slot;
+    return MCQ_OK;
+}
+
+}  // namespace
+
+int mcq_run_slice(mcq_ctx *c, int mode, const mcq_query *d_q, uint32_t n, mcq_result *d_res, uint64_t seed,
+                  uint64_t first_qid, uint64_t total_tasks, const uint8_t *d_draws, const uint64_t *d_off, hipStream_t s,
+                  bool timed, uint64_t max_tasks, uint32_t part, uint32_t n_parts) {
     if (mode == MCQ_MODE_PHILOX && c->law == MCQ_LAW_UNIFORM) mode = MCQ_INTERNAL_MODE_UNIFORM;
-    HIP_TRY(c->d_prefix.reserve(((size_t)n + 2) * sizeof(uint64_t)));
-    HIP_TRY(mcq_launch_prep(d_q, n, d_res, (uint64_t *)c->d_prefix.p, part, n_parts, (uint32_t)c->n_cu, c->split_max, s));
+    const bool capturing = stream_capturing(s);
+    if (capturing) timed = false; /* events recorded inside a capture cannot be read back */
+    mcq_ctx::Scratch *sc = nullptr;
+    int rc = scratch_for(c, s, ((size_t)n + 2) * sizeof(uint64_t), capturing, &sc);
+    if (rc) return rc;
+    uint64_t *d_prefix = (uint64_t *)sc->prefix.p;
+    HIP_TRY(mcq_launch_prep(d_q, n, d_res, d_prefix, part, n_parts, (uint32_t)c->n_cu, c->split_max, s));
     uint32_t grid, block, split;
     pick_geometry(c, mode, total_tasks, &grid, &block, &split, max_tasks);
     /* queries in HBM (the host has not seen them): up to 1024 of them may be a small batch -- the prep kernel
@@ -149,26 +135,36 @@ int run_slice(mcq_ctx *c, int mode, const mcq_query *d_q, uint32_t n, mcq_result
     if (total_tasks == 0 && n <= 1024u) split = MCQ_SPLIT_FROM_PREP;
     const int slot = (int)(c->n_timed % mcq_ctx::kRing);
     if (timed) HIP_TRY(hipEventRecord(c->ev0[slot], s));
-    HIP_TRY(mcq_launch_eval(mode, d_q, n, (const uint64_t *)c->d_prefix.p, d_res, seed, first_qid, c->d_luts, d_draws,
-                            d_off, grid, block, split, part, n_parts, s));
+    HIP_TRY(mcq_launch_eval(mode, d_q, n, d_prefix, d_res, seed, first_qid, c->d_luts, d_draws, d_off, grid, block, split,
+                            part, n_parts, s));
     if (timed) {
         HIP_TRY(hipEventRecord(c->ev1[slot], s));
         c->n_timed++;
     }
+    if (!capturing) {
+        HIP_TRY(hipEventRecord(sc->done, s));
+        sc->done_recorded = true;
+    }
     return MCQ_OK;
 }
 
-int validate(const mcq_query *q, size_t n) {
+uint32_t mcq_tasks_of(const mcq_query &q) { return q.runs / MCQ_TASK_ITERS + (q.runs % MCQ_TASK_ITERS != 0u ? 1u : 0u); }
+
+int mcq_validate_queries(const mcq_query *q, size_t n) {
     for (size_t i = 0; i < n; i++)
         if (!mcq_query_valid(mcq_query_words(q[i]))) {
             char buf[160];
             snprintf(buf, sizeof buf,
                      "query %zu invalid (cards must be distinct ids < 52, n_board <= 5, 1 <= n_players <= 10)", i);
-            return fail(MCQ_EINVAL, buf);
+            return mcq_fail(MCQ_EINVAL, buf);
         }
     return MCQ_OK;
 }
 
+namespace {
+
+inline uint32_t tasks_of(const mcq_query &q) { return mcq_tasks_of(q); }
+inline int validate(const mcq_query *q, size_t n) { return mcq_validate_queries(q, n); }
 }  // namespace
 
 extern "C" int mcq_kernel_times(mcq_ctx *c, float *ms, int max_n);
@@ -229,7 +225,7 @@ int replay_batch(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed, uint64
         }
         HIP_TRY(hipMemcpyAsync(c->d_draws.p, hd, bytes, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(c->d_off.p, off, m * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-        int rc = run_slice(c, MCQ_MODE_REPLAY_MT19937, (const mcq_query *)c->d_q.p + a, (uint32_t)m,
+        int rc = mcq_run_slice(c, MCQ_MODE_REPLAY_MT19937, (const mcq_query *)c->d_q.p + a, (uint32_t)m,
                            (mcq_result *)c->d_res.p + a, seed, first_query_id + a, tasks, (const uint8_t *)c->d_draws.p,
                            (const uint64_t *)c->d_off.p, c->stream, true, max_tasks);
         if (rc) return rc;
@@ -246,17 +242,16 @@ int replay_batch(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed, uint64
     return MCQ_OK;
 }
 
-/* validation + query upload shared by the host entry points */
+/* validation + query upload shared by the host entry points (the caller has selected the context's device) */
 int stage_queries(mcq_ctx *c, const mcq_query *q, size_t n, mcq_result *out, const char *who) {
-    if (!c) return fail(MCQ_EINVAL, who, "null context");
-    if (!q || !out) return fail(MCQ_EINVAL, who, "null buffer");
-    if (n > 0x7fffffffu) return fail(MCQ_EINVAL, who, "n too large");
+    if (!c) return mcq_fail(MCQ_EINVAL, who, "null context");
+    if (!q || !out) return mcq_fail(MCQ_EINVAL, who, "null buffer");
+    if (n > 0x7fffffffu) return mcq_fail(MCQ_EINVAL, who, "n too large");
     int rc = validate(q, n);
     if (rc) return rc;
     uint64_t total_tasks = 0;
     for (size_t i = 0; i < n; i++) total_tasks += tasks_of(q[i]);
-    if (total_tasks > 0xfffffff0ull) return fail(MCQ_EINVAL, who, "too many iterations in one call");
-    HIP_TRY(hipSetDevice(c->device));
+    if (total_tasks > 0xfffffff0ull) return mcq_fail(MCQ_EINVAL, who, "too many iterations in one call");
     HIP_TRY(c->h_q.reserve(n * sizeof(mcq_query)));
     HIP_TRY(c->h_res.reserve(n * sizeof(mcq_result)));
     HIP_TRY(c->d_q.reserve(n * sizeof(mcq_query)));
@@ -273,7 +268,7 @@ extern "C" {
 
 const char *mcq_last_error(void) { return g_err.c_str(); }
 
-int mcq_tables_set_error(const char *msg) { return fail(MCQ_EINVAL, msg); } /* for mcq_tables.cpp; not exported */
+int mcq_tables_set_error(const char *msg) { return mcq_fail(MCQ_EINVAL, msg); } /* for mcq_tables.cpp; not exported */
 
 /* a second context like c (same device, dealing law and tuning) with its own stream and buffers; not exported */
 mcq_ctx *mcq_ctx_clone(const mcq_ctx *c) {
@@ -294,16 +289,20 @@ void mcq_version(int *major, int *minor, int *patch) {
 int mcq_device_count(void) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess) return fail(MCQ_EDEVICE, "hipGetDeviceCount", hipGetErrorString(e));
+    if (e != hipSuccess) return mcq_fail(MCQ_EDEVICE, "hipGetDeviceCount", hipGetErrorString(e));
     return n;
 }
 
 void mcq_destroy(mcq_ctx *c) {
     if (!c) return;
-    (void)hipSetDevice(c->device);
+    McqDeviceScope dev_(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf *db[] = {&c->d_q, &c->d_res, &c->d_prefix, &c->d_draws, &c->d_off, &c->d_hands, &c->d_win, &c->d_wt,
-                    &c->d_keys, &c->d_ext};
+    DevBuf *db[] = {&c->d_q, &c->d_res, &c->d_draws, &c->d_off, &c->d_hands, &c->d_win, &c->d_wt, &c->d_keys, &c->d_ext,
+                    &c->d_mt};
+    for (auto &sc : c->scratch) {
+        sc.prefix.release();
+        if (sc.done) (void)hipEventDestroy(sc.done);
+    }
     for (DevBuf *b : db) b->release();
     PinBuf *pb[] = {&c->h_q, &c->h_res, &c->h_draws, &c->h_off, &c->h_misc};
     for (PinBuf *b : pb) b->release();
@@ -317,32 +316,35 @@ void mcq_destroy(mcq_ctx *c) {
 }
 
 mcq_ctx *mcq_create(int device, int flags) {
-    if (flags != 0) { fail(MCQ_EINVAL, "mcq_create: flags must be 0"); return nullptr; }
+    if (flags != 0) { mcq_fail(MCQ_EINVAL, "mcq_create: flags must be 0"); return nullptr; }
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {
-        fail(MCQ_EDEVICE, "mcq_create: no HIP device available (this library has no CPU path)",
+        mcq_fail(MCQ_EDEVICE, "mcq_create: no HIP device available (this library has no CPU path)",
              e != hipSuccess ? hipGetErrorString(e) : nullptr);
         return nullptr;
     }
-    if (device < 0 || device >= n) { fail(MCQ_EINVAL, "mcq_create: device ordinal out of range"); return nullptr; }
+    if (device < 0 || device >= n) { mcq_fail(MCQ_EINVAL, "mcq_create: device ordinal out of range"); return nullptr; }
     mcq_ctx *c = new (std::nothrow) mcq_ctx();
-    if (!c) { fail(MCQ_ENOMEM, "mcq_create: out of host memory"); return nullptr; }
+    if (!c) { mcq_fail(MCQ_ENOMEM, "mcq_create: out of host memory"); return nullptr; }
     c->device = device;
     hipDeviceProp_t prop;
     McqTables *tabs = new (std::nothrow) McqTables();
-    if (!tabs) { fail(MCQ_ENOMEM, "mcq_create: out of host memory"); delete c; return nullptr; }
+    if (!tabs) { mcq_fail(MCQ_ENOMEM, "mcq_create: out of host memory"); delete c; return nullptr; }
     mcq_fill_tables(tabs);
 #define CREATE_TRY(expr)                                                      \
     do {                                                                      \
         hipError_t e2_ = (expr);                                              \
         if (e2_ != hipSuccess) {                                              \
-            fail(MCQ_EDEVICE, #expr, hipGetErrorString(e2_));                 \
+            mcq_fail(MCQ_EDEVICE, #expr, hipGetErrorString(e2_));                 \
             mcq_destroy(c);                                                   \
             delete tabs;                                                      \
+            if (prev_dev >= 0) (void)hipSetDevice(prev_dev);                  \
             return nullptr;                                                   \
         }                                                                     \
     } while (0)
+    int prev_dev = -1; /* the caller's current device is left as it was */
+    if (hipGetDevice(&prev_dev) != hipSuccess) prev_dev = -1;
     CREATE_TRY(hipSetDevice(device));
     CREATE_TRY(hipGetDeviceProperties(&prop, device));
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -351,6 +353,9 @@ mcq_ctx *mcq_create(int device, int flags) {
         c->split_max = (uint32_t)(v < 0 ? 0 : (v > 4 ? 4 : v));
     }
     CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (auto &sc : c->scratch) CREATE_TRY(hipEventCreateWithFlags(&sc.done, hipEventDisableTiming));
+    c->scratch[0].stream = c->stream; /* slot 0: the context's own stream (host entries) */
+    c->scratch[0].used = true;
     for (int i = 0; i < mcq_ctx::kRing; i++) {
         CREATE_TRY(hipEventCreate(&c->ev0[i]));
         CREATE_TRY(hipEventCreate(&c->ev1[i]));
@@ -364,14 +369,16 @@ mcq_ctx *mcq_create(int device, int flags) {
     }
 #undef CREATE_TRY
     delete tabs;
+    if (prev_dev >= 0 && prev_dev != device) (void)hipSetDevice(prev_dev);
     return c;
 }
 
 int mcq_kernel_times(mcq_ctx *c, float *ms, int max_n) {
-    if (!c || !ms || max_n < 0) return fail(MCQ_EINVAL, "mcq_kernel_times: bad argument");
+    if (!c || !ms || max_n < 0) return mcq_fail(MCQ_EINVAL, "mcq_kernel_times: bad argument");
     uint64_t have = c->n_timed < (uint64_t)mcq_ctx::kRing ? c->n_timed : (uint64_t)mcq_ctx::kRing;
     int n = (int)(have < (uint64_t)max_n ? have : (uint64_t)max_n);
-    HIP_TRY(hipSetDevice(c->device));
+    McqDeviceScope dev_(c->device);
+    HIP_TRY(dev_.err);
     for (int i = 0; i < n; i++) {
         int slot = (int)((c->n_timed - (uint64_t)n + (uint64_t)i) % mcq_ctx::kRing);
         HIP_TRY(hipEventElapsedTime(&ms[i], c->ev0[slot], c->ev1[slot]));
@@ -380,7 +387,7 @@ int mcq_kernel_times(mcq_ctx *c, float *ms, int max_n) {
 }
 
 int mcq_set_dealing_law(mcq_ctx *c, int law) {
-    if (!c || (law != MCQ_LAW_REFERENCE && law != MCQ_LAW_UNIFORM)) return fail(MCQ_EINVAL, "mcq_set_dealing_law: bad argument");
+    if (!c || (law != MCQ_LAW_REFERENCE && law != MCQ_LAW_UNIFORM)) return mcq_fail(MCQ_EINVAL, "mcq_set_dealing_law: bad argument");
     c->law = law;
     return MCQ_OK;
 }
@@ -395,26 +402,30 @@ float mcq_last_kernel_ms(mcq_ctx *c) {
 int mcq_eval_batch_device(mcq_ctx *c, const void *d_queries, size_t n, uint64_t seed, uint64_t first_query_id,
                           void *d_results, void *hip_stream) {
     ABI_GUARD_BEGIN
-    if (!c) return fail(MCQ_EINVAL, "mcq_eval_batch_device: null context");
+    if (!c) return mcq_fail(MCQ_EINVAL, "mcq_eval_batch_device: null context");
     if (n == 0) return MCQ_OK;
-    if (!d_queries || !d_results) return fail(MCQ_EINVAL, "mcq_eval_batch_device: null buffer");
-    if (n > 0x7fffffffu) return fail(MCQ_EINVAL, "mcq_eval_batch_device: n too large");
-    HIP_TRY(hipSetDevice(c->device));
+    if (!d_queries || !d_results) return mcq_fail(MCQ_EINVAL, "mcq_eval_batch_device: null buffer");
+    if (n > 0x7fffffffu) return mcq_fail(MCQ_EINVAL, "mcq_eval_batch_device: n too large");
+    McqDeviceScope dev_(c->device);
+    HIP_TRY(dev_.err);
     hipStream_t s = (hipStream_t)hip_stream; /* NULL = the HIP null stream */
     /* the prefix buffer must already be large enough when the call is being captured into a graph */
     c->last_ms = 0.f;
-    return run_slice(c, MCQ_MODE_PHILOX, (const mcq_query *)d_queries, (uint32_t)n, (mcq_result *)d_results, seed,
+    return mcq_run_slice(c, MCQ_MODE_PHILOX, (const mcq_query *)d_queries, (uint32_t)n, (mcq_result *)d_results, seed,
                      first_query_id, 0, nullptr, nullptr, s, true);
     ABI_GUARD_END("mcq_eval_batch_device")
 }
 
 static int eval_batch_impl(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed, uint64_t first_query_id, int mode,
                            uint32_t part, uint32_t n_parts, mcq_result *out, const char *who) {
-    if (mode != MCQ_MODE_PHILOX && mode != MCQ_MODE_REPLAY_MT19937) return fail(MCQ_EINVAL, who, "bad mode");
-    if (n_parts == 0 || part >= n_parts) return fail(MCQ_EINVAL, who, "part must be < n_parts");
+    if (mode != MCQ_MODE_PHILOX && mode != MCQ_MODE_REPLAY_MT19937) return mcq_fail(MCQ_EINVAL, who, "bad mode");
+    if (n_parts == 0 || part >= n_parts) return mcq_fail(MCQ_EINVAL, who, "part must be < n_parts");
     if (n_parts > 1 && mode != MCQ_MODE_PHILOX)
-        return fail(MCQ_EINVAL, who, "only MCQ_MODE_PHILOX can split the iterations of a query");
+        return mcq_fail(MCQ_EINVAL, who, "only MCQ_MODE_PHILOX can split the iterations of a query");
     if (n == 0) return MCQ_OK;
+    if (!c) return mcq_fail(MCQ_EINVAL, who, "null context");
+    McqDeviceScope dev_(c->device);
+    HIP_TRY(dev_.err);
     int rc = stage_queries(c, q, n, out, who);
     if (rc) return rc;
     uint64_t total_tasks = 0, max_tasks = 0;
@@ -427,7 +438,7 @@ static int eval_batch_impl(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t se
 
     if (mode == MCQ_MODE_PHILOX) {
         if (total_tasks == 0) total_tasks = 1; /* 0 means "unknown" to pick_geometry */
-        rc = run_slice(c, mode, (const mcq_query *)c->d_q.p, (uint32_t)n, (mcq_result *)c->d_res.p, seed,
+        rc = mcq_run_slice(c, mode, (const mcq_query *)c->d_q.p, (uint32_t)n, (mcq_result *)c->d_res.p, seed,
                        first_query_id, total_tasks, nullptr, nullptr, c->stream, true, max_tasks, part, n_parts);
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(c->h_res.p, c->d_res.p, n * sizeof(mcq_result), hipMemcpyDeviceToHost, c->stream));
@@ -461,11 +472,11 @@ int mcq_eval_one(mcq_ctx *c, const mcq_query *q, uint64_t seed, int mode, mcq_re
 int mcq_eval_batch_ext(mcq_ctx *c, const mcq_query *q, const mcq_query_ext *ext, size_t n, uint64_t seed,
                        uint64_t first_query_id, int mode, mcq_result *out) {
     ABI_GUARD_BEGIN
-    if (mode != MCQ_MODE_PHILOX && mode != MCQ_MODE_REPLAY_MT19937) return fail(MCQ_EINVAL, "mcq_eval_batch_ext: bad mode");
+    if (mode != MCQ_MODE_PHILOX && mode != MCQ_MODE_REPLAY_MT19937) return mcq_fail(MCQ_EINVAL, "mcq_eval_batch_ext: bad mode");
     if (n == 0) return MCQ_OK;
-    if (!c) return fail(MCQ_EINVAL, "mcq_eval_batch_ext: null context");
-    if (!q || !ext || !out) return fail(MCQ_EINVAL, "mcq_eval_batch_ext: null buffer");
-    if (n > 0x7fffffffu) return fail(MCQ_EINVAL, "mcq_eval_batch_ext: n too large");
+    if (!c) return mcq_fail(MCQ_EINVAL, "mcq_eval_batch_ext: null context");
+    if (!q || !ext || !out) return mcq_fail(MCQ_EINVAL, "mcq_eval_batch_ext: null buffer");
+    if (n > 0x7fffffffu) return mcq_fail(MCQ_EINVAL, "mcq_eval_batch_ext: n too large");
     uint64_t total_tasks = 0;
     for (size_t i = 0; i < n; i++) {
         McqExtWords ew;
@@ -474,18 +485,19 @@ int mcq_eval_batch_ext(mcq_ctx *c, const mcq_query *q, const mcq_query_ext *ext,
             char buf[200];
             snprintf(buf, sizeof buf, "extended query %zu invalid (distinct card ids < 52 among hole/table/ghost/known2, "
                      "n_players >= known hands, used ranges not empty)", i);
-            return fail(MCQ_EINVAL, buf);
+            return mcq_fail(MCQ_EINVAL, buf);
         }
         total_tasks += tasks_of(q[i]);
     }
-    if (total_tasks > 0xfffffff0ull) return fail(MCQ_EINVAL, "mcq_eval_batch_ext: too many iterations in one call");
-    HIP_TRY(hipSetDevice(c->device));
+    if (total_tasks > 0xfffffff0ull) return mcq_fail(MCQ_EINVAL, "mcq_eval_batch_ext: too many iterations in one call");
+    McqDeviceScope dev_(c->device);
+    HIP_TRY(dev_.err);
     HIP_TRY(c->h_q.reserve(n * (sizeof(mcq_query) + sizeof(mcq_query_ext))));
     HIP_TRY(c->h_res.reserve(n * sizeof(mcq_result)));
     HIP_TRY(c->d_q.reserve(n * sizeof(mcq_query)));
     HIP_TRY(c->d_ext.reserve(n * sizeof(mcq_query_ext)));
     HIP_TRY(c->d_res.reserve(n * sizeof(mcq_result)));
-    HIP_TRY(c->d_prefix.reserve((n + 1) * sizeof(uint64_t)));
+    HIP_TRY(c->scratch[0].prefix.reserve((n + 2) * sizeof(uint64_t)));
     uint8_t *hq = (uint8_t *)c->h_q.p;
     memcpy(hq, q, n * sizeof(mcq_query));
     memcpy(hq + n * sizeof(mcq_query), ext, n * sizeof(mcq_query_ext));
@@ -504,7 +516,7 @@ int mcq_eval_batch_ext(mcq_ctx *c, const mcq_query *q, const mcq_query_ext *ext,
             off[i] = bytes;
             bytes += (((uint64_t)q[i].runs + 63u) & ~63ull) * mcq_ext_draws_per_iteration(q[i], ext[i]);
         }
-        if (bytes > (1ull << 31)) return fail(MCQ_EINVAL, "mcq_eval_batch_ext: replay batch too large (split it)");
+        if (bytes > (1ull << 31)) return mcq_fail(MCQ_EINVAL, "mcq_eval_batch_ext: replay batch too large (split it)");
         HIP_TRY(c->h_draws.reserve(bytes + 64));
         HIP_TRY(c->d_draws.reserve(bytes + 64));
         HIP_TRY(c->d_off.reserve(n * sizeof(uint64_t)));
@@ -530,21 +542,21 @@ int mcq_eval_batch_ext(mcq_ctx *c, const mcq_query *q, const mcq_query_ext *ext,
         for (size_t t = 1; t < nt; t++) th.emplace_back(work);
         work();
         for (auto &t : th) t.join();
-        if (bad.load()) return fail(MCQ_EINVAL, "mcq_eval_batch_ext: a range cannot be dealt from the remaining cards");
+        if (bad.load()) return mcq_fail(MCQ_EINVAL, "mcq_eval_batch_ext: a range cannot be dealt from the remaining cards");
         HIP_TRY(hipMemcpyAsync(c->d_draws.p, hd, bytes, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(c->d_off.p, c->h_off.p, n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     }
     HIP_TRY(mcq_launch_prep_ext((const mcq_query *)c->d_q.p, (const mcq_query_ext *)c->d_ext.p, (uint32_t)n,
-                                (mcq_result *)c->d_res.p, (uint64_t *)c->d_prefix.p, c->stream));
+                                (mcq_result *)c->d_res.p, (uint64_t *)c->scratch[0].prefix.p, c->stream));
     HIP_TRY(mcq_launch_eval_ext(mode, (const mcq_query *)c->d_q.p, (const mcq_query_ext *)c->d_ext.p, (uint32_t)n,
-                                (const uint64_t *)c->d_prefix.p, (mcq_result *)c->d_res.p, seed, first_query_id, c->d_luts,
+                                (const uint64_t *)c->scratch[0].prefix.p, (mcq_result *)c->d_res.p, seed, first_query_id, c->d_luts,
                                 (const uint8_t *)c->d_draws.p, (const uint64_t *)c->d_off.p, grid, block, c->stream));
     HIP_TRY(hipMemcpyAsync(c->h_res.p, c->d_res.p, n * sizeof(mcq_result), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     const mcq_result *hr = (const mcq_result *)c->h_res.p;
     for (size_t i = 0; i < n; i++)
         if (hr[i].runs != q[i].runs)
-            return fail(MCQ_EINVAL, "mcq_eval_batch_ext: a range cannot be dealt from the remaining cards");
+            return mcq_fail(MCQ_EINVAL, "mcq_eval_batch_ext: a range cannot be dealt from the remaining cards");
     memcpy(out, hr, n * sizeof(mcq_result));
     if (mode == MCQ_MODE_REPLAY_MT19937)
         for (size_t i = 0; i < n; i++) out[i].passes = passes[i];
@@ -556,7 +568,10 @@ int mcq_eval_batch_numpy_stream(mcq_ctx *c, const mcq_query *q, size_t n, uint32
                                 mcq_result *out) {
     ABI_GUARD_BEGIN
     if (n == 0) return MCQ_OK;
-    if (!mt_key || !mt_pos || *mt_pos > 624) return fail(MCQ_EINVAL, "mcq_eval_batch_numpy_stream: bad MT19937 state");
+    if (!mt_key || !mt_pos || *mt_pos > 624) return mcq_fail(MCQ_EINVAL, "mcq_eval_batch_numpy_stream: bad MT19937 state");
+    if (!c) return mcq_fail(MCQ_EINVAL, "mcq_eval_batch_numpy_stream: null context");
+    McqDeviceScope dev_(c->device);
+    HIP_TRY(dev_.err);
     int rc = stage_queries(c, q, n, out, "mcq_eval_batch_numpy_stream");
     if (rc) return rc;
     McqMt19937 g;
@@ -573,22 +588,23 @@ int mcq_eval_batch_numpy_stream(mcq_ctx *c, const mcq_query *q, size_t n, uint32
 int mcq_showdown(mcq_ctx *c, const uint8_t *hands, size_t n_tables, int n_players, uint8_t *winner,
                  uint8_t *winner_type, uint32_t *keys) {
     ABI_GUARD_BEGIN
-    if (!c) return fail(MCQ_EINVAL, "mcq_showdown: null context");
+    if (!c) return mcq_fail(MCQ_EINVAL, "mcq_showdown: null context");
     if (n_tables == 0) return MCQ_OK;
-    if (!hands || !winner || !winner_type) return fail(MCQ_EINVAL, "mcq_showdown: null buffer");
-    if (n_players < 1 || n_players > 10) return fail(MCQ_EINVAL, "mcq_showdown: n_players must be in [1,10]");
-    if (n_tables > 0x7fffffffu / 70u) return fail(MCQ_EINVAL, "mcq_showdown: n_tables too large");
+    if (!hands || !winner || !winner_type) return mcq_fail(MCQ_EINVAL, "mcq_showdown: null buffer");
+    if (n_players < 1 || n_players > 10) return mcq_fail(MCQ_EINVAL, "mcq_showdown: n_players must be in [1,10]");
+    if (n_tables > 0x7fffffffu / 70u) return mcq_fail(MCQ_EINVAL, "mcq_showdown: n_tables too large");
     const size_t nh = n_tables * (size_t)n_players;
     for (size_t h = 0; h < nh; h++) {
         uint64_t seen = 0;
         for (int k = 0; k < 7; k++) {
             uint8_t cd = hands[h * 7 + k];
             if (cd >= 52 || (seen >> cd) & 1)
-                return fail(MCQ_EINVAL, "mcq_showdown: a hand needs 7 distinct card ids < 52");
+                return mcq_fail(MCQ_EINVAL, "mcq_showdown: a hand needs 7 distinct card ids < 52");
             seen |= 1ull << cd;
         }
     }
-    HIP_TRY(hipSetDevice(c->device));
+    McqDeviceScope dev_(c->device);
+    HIP_TRY(dev_.err);
     HIP_TRY(c->d_hands.reserve(nh * 7));
     HIP_TRY(c->d_win.reserve(n_tables));
     HIP_TRY(c->d_wt.reserve(n_tables));
@@ -612,17 +628,18 @@ int mcq_showdown(mcq_ctx *c, const uint8_t *hands, size_t n_tables, int n_player
 
 int mcq_exact_batch(mcq_ctx *c, const mcq_query *q, size_t n, int law, mcq_result *out) {
     ABI_GUARD_BEGIN
-    if (!c) return fail(MCQ_EINVAL, "mcq_exact_batch: null context");
+    if (!c) return mcq_fail(MCQ_EINVAL, "mcq_exact_batch: null context");
     if (n == 0) return MCQ_OK;
-    if (!q || !out) return fail(MCQ_EINVAL, "mcq_exact_batch: null buffer");
-    if (law != MCQ_LAW_REFERENCE && law != MCQ_LAW_UNIFORM) return fail(MCQ_EINVAL, "mcq_exact_batch: bad law");
-    if (n > 0x7fffffffu) return fail(MCQ_EINVAL, "mcq_exact_batch: n too large");
+    if (!q || !out) return mcq_fail(MCQ_EINVAL, "mcq_exact_batch: null buffer");
+    if (law != MCQ_LAW_REFERENCE && law != MCQ_LAW_UNIFORM) return mcq_fail(MCQ_EINVAL, "mcq_exact_batch: bad law");
+    if (n > 0x7fffffffu) return mcq_fail(MCQ_EINVAL, "mcq_exact_batch: n too large");
     int rc = validate(q, n);
     if (rc) return rc;
     for (size_t i = 0; i < n; i++)
         if (q[i].n_players > 3)
-            return fail(MCQ_EINVAL, "mcq_exact_batch: exact enumeration covers 1 to 3 players");
-    HIP_TRY(hipSetDevice(c->device));
+            return mcq_fail(MCQ_EINVAL, "mcq_exact_batch: exact enumeration covers 1 to 3 players");
+    McqDeviceScope dev_(c->device);
+    HIP_TRY(dev_.err);
     HIP_TRY(c->d_res.reserve(n * sizeof(mcq_result)));
     HIP_TRY(c->h_res.reserve(n * sizeof(mcq_result)));
     HIP_TRY(hipMemsetAsync(c->d_res.p, 0, n * sizeof(mcq_result), c->stream));

@@ -26,3 +26,5 @@ hipError_t mcq_launch_eval_ext(int mode, const mcq_query *d_q, const mcq_query_e
                                const uint64_t *d_prefix, mcq_result *d_res, uint64_t seed, uint64_t first_qid,
                                const McqTables *d_luts, const uint8_t *d_draws, const uint64_t *d_draw_off, uint32_t grid,
                                uint32_t block, hipStream_t s);
+/* dst[i] += src[i], i < n (tally matrices of two shards on one device, both 16-byte aligned) */
+hipError_t mcq_launch_add_u64(uint64_t *d_dst, const uint64_t *d_src, uint64_t n, hipStream_t s);

@@ -123,6 +123,25 @@ __global__ __launch_bounds__(1024) void mcq_prep_kernel(const mcq_query *__restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------- multi-GPU helper
+// dst[i] += src[i]: adds the tally matrix of a second shard on the same device (mcq_multi.cpp) -- HBM-bound
+// streaming, two 16-byte loads and one store per lane.
+__global__ __launch_bounds__(256) void mcq_add_u64_kernel(uint64_t *__restrict__ dst, const uint64_t *__restrict__ src,
+                                                          uint64_t n) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t n2 = n >> 1;
+    ulonglong2 *d2 = reinterpret_cast<ulonglong2 *>(dst);
+    const ulonglong2 *s2 = reinterpret_cast<const ulonglong2 *>(src);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+        ulonglong2 a = d2[i];
+        const ulonglong2 b = s2[i];
+        a.x += b.x;
+        a.y += b.y;
+        d2[i] = a;
+    }
+    if ((n & 1ull) && blockIdx.x == 0 && threadIdx.x == 0) dst[n - 1] += src[n - 1];
+}
+
 // ---------------------------------------------------------------------------------------------- eval
 struct WaveTally { /* per-lane running sums of the current (wave, query) pair */
     uint32_t code[MCQ_N_CODES], tie, passes;
@@ -546,6 +565,15 @@ hipError_t mcq_launch_eval(int mode, const mcq_query *d_q, uint32_t n, const uin
     else if (mode == MCQ_INTERNAL_MODE_UNIFORM) MCQ_LAUNCH_EVAL(MCQ_INTERNAL_MODE_UNIFORM);
     else MCQ_LAUNCH_EVAL(MCQ_MODE_REPLAY_MT19937);
 #undef MCQ_LAUNCH_EVAL
+    return hipGetLastError();
+}
+
+hipError_t mcq_launch_add_u64(uint64_t *d_dst, const uint64_t *d_src, uint64_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = (n / 2 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(mcq_add_u64_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, d_dst, d_src, n);
     return hipGetLastError();
 }
 

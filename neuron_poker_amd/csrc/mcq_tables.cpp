@@ -467,6 +467,7 @@ struct mcq_tables {
     std::vector<mcq_result> r;
     std::vector<double> eq;
     uint64_t calls;
+    bool failed = false; /* a lock-step died half way: the tables are out of step with the query ids, nothing more may run */
     Pool *pool = nullptr;
     Pool *pool2 = nullptr; /* the helper thread's pool in the two-stream schedule */
     mcq_ctx *ctx2 = nullptr; /* second stream + buffers: the upper half of the tables is stepped by a helper thread
@@ -575,28 +576,65 @@ mcq_tables *mcq_tables_create(mcq_ctx *ctx, const mcq_tables_config *cfg) {
 
 void mcq_tables_destroy(mcq_tables *t) { delete t; }
 
+/* No C++ exception may cross the C ABI (std::system_error from thread creation, std::bad_alloc from std::function or
+ * the pools): the bodies below run inside try blocks, as the entries of mcq_host.cpp do. */
 size_t mcq_tables_begin(mcq_tables *t, mcq_query *q) {
     if (!t || !q) return 0;
-    const uint32_t runs = t->cfg.runs;
-    t->for_tables([&](size_t a, size_t b) {
-        for (size_t i = a; i < b; i++) t->tables[i].observe(q[i], runs);
-    });
+    if (t->failed) { mcq_tables_set_error("mcq_tables_begin: the driver failed in an earlier call; create a new one"); return 0; }
+    try {
+        const uint32_t runs = t->cfg.runs;
+        t->for_tables([&](size_t a, size_t b) {
+            for (size_t i = a; i < b; i++) t->tables[i].observe(q[i], runs);
+        });
+    } catch (const std::exception &ex) {
+        t->failed = true;
+        mcq_tables_set_error((std::string("mcq_tables_begin: ") + ex.what()).c_str());
+        return 0;
+    } catch (...) {
+        t->failed = true;
+        mcq_tables_set_error("mcq_tables_begin: unexpected exception");
+        return 0;
+    }
     return t->tables.size();
 }
 
 int mcq_tables_resume(mcq_tables *t, const double *equity) {
     if (!t || !equity) return mcq_tables_set_error("mcq_tables_resume: null argument");
-    t->for_tables([&](size_t a, size_t b) {
-        for (size_t i = a; i < b; i++) t->tables[i].resume(equity[i]);
-    });
+    if (t->failed) return mcq_tables_set_error("mcq_tables_resume: the driver failed in an earlier call; create a new one");
+    try {
+        t->for_tables([&](size_t a, size_t b) {
+            for (size_t i = a; i < b; i++) t->tables[i].resume(equity[i]);
+        });
+    } catch (const std::exception &ex) {
+        t->failed = true;
+        return mcq_tables_set_error((std::string("mcq_tables_resume: ") + ex.what()).c_str());
+    } catch (...) {
+        t->failed = true;
+        return mcq_tables_set_error("mcq_tables_resume: unexpected exception");
+    }
     return MCQ_OK;
 }
 
+static int tables_run_impl(mcq_tables *t, uint32_t lock_steps, uint64_t *stats);
+
 int mcq_tables_run(mcq_tables *t, uint32_t lock_steps, uint64_t *stats) {
     if (!t || !t->ctx) return mcq_tables_set_error("mcq_tables_run: needs a context");
+    if (t->failed) return mcq_tables_set_error("mcq_tables_run: the driver failed in an earlier call; create a new one");
+    try {
+        return tables_run_impl(t, lock_steps, stats);
+    } catch (const std::exception &ex) {
+        t->failed = true;
+        return mcq_tables_set_error((std::string("mcq_tables_run: ") + ex.what()).c_str());
+    } catch (...) {
+        t->failed = true;
+        return mcq_tables_set_error("mcq_tables_run: unexpected exception");
+    }
+}
+
+static int tables_run_impl(mcq_tables *t, uint32_t lock_steps, uint64_t *stats) {
     const size_t n = t->tables.size();
     const uint32_t runs = t->cfg.runs;
-    if (lock_steps) mcq_tables_begin(t, t->q.data());
+    if (lock_steps && mcq_tables_begin(t, t->q.data()) == 0) return MCQ_EINVAL;
     /* Two halves on two streams.  While one half's batch is on the GPU the other half's tables are stepped on the
      * host (by its own thread pool when the table count is large); per-query ids, hence all results, are as in
      * one batch per step. */
@@ -606,10 +644,29 @@ int mcq_tables_run(mcq_tables *t, uint32_t lock_steps, uint64_t *stats) {
         if (t->ctx2 && (!t->pool || t->pool2)) {
             std::string err2;
             int rc2 = MCQ_OK;
-            std::thread helper([&] { rc2 = run_range(t, t->ctx2, t->pool2, n / 2, n, lock_steps, &err2); });
-            int rc1 = run_range(t, t->ctx, t->pool, 0, n / 2, lock_steps, nullptr);
+            std::thread helper([&] {
+                try {
+                    rc2 = run_range(t, t->ctx2, t->pool2, n / 2, n, lock_steps, &err2);
+                } catch (const std::exception &ex) {
+                    rc2 = MCQ_EDEVICE;
+                    err2 = std::string("mcq_tables_run (helper thread): ") + ex.what();
+                } catch (...) {
+                    rc2 = MCQ_EDEVICE;
+                    err2 = "mcq_tables_run (helper thread): unexpected exception";
+                }
+            });
+            int rc1;
+            try {
+                rc1 = run_range(t, t->ctx, t->pool, 0, n / 2, lock_steps, nullptr);
+            } catch (...) {
+                helper.join(); /* never leave the helper running (or joinable: std::terminate) behind an exception */
+                throw;
+            }
             helper.join();
-            if (rc1) return rc1; /* a failed half leaves its tables at the step it reached; the driver is not resumable then */
+            /* a failed half leaves its tables at the step it reached while the other half went on: the halves are out
+             * of step with each other and with the query ids -- the driver is marked failed and refuses further calls */
+            if (rc1 || rc2) t->failed = true;
+            if (rc1) return rc1;
             if (rc2) { mcq_tables_set_error(err2.c_str()); return rc2; }
             t->calls += (uint64_t)lock_steps * n;
             if (stats) mcq_tables_stats(t, stats);
@@ -618,7 +675,7 @@ int mcq_tables_run(mcq_tables *t, uint32_t lock_steps, uint64_t *stats) {
     }
     for (uint32_t s = 0; s < lock_steps; s++) {
         int rc = mcq_eval_batch(t->ctx, t->q.data(), n, t->cfg.seed, t->calls, MCQ_MODE_PHILOX, t->r.data());
-        if (rc) return rc; /* the queries stay pending: the tables were not advanced */
+        if (rc) return rc; /* the queries stay pending: the tables were not advanced, the call may be repeated */
         t->calls += n;
         const bool more = s + 1 < lock_steps;
         t->for_tables([&](size_t a, size_t b) { /* answer, act, and issue the next query in one pass */

@@ -12,13 +12,20 @@ h = open(R + "/include/mcq.h").read()
 decls = re.findall(r"MCQ_API\s+([\w\s\*]+?)\b(mcq_\w+)\s*\(([^;]*?)\)\s*;", h, re.S)
 own = {"mcq_tables_create", "mcq_tables_destroy", "mcq_tables_begin", "mcq_tables_resume", "mcq_tables_run",
        "mcq_tables_stats", "mcq_tables_state", "mcq_last_error", "mcq_eval_batch", "mcq_destroy"}
-out = ['#include "mcq.h"', '#include <string>', 'static thread_local std::string g_err;', 'extern "C" {',
+out = ['#include "mcq.h"', '#include <string>', '#include <atomic>', '#include <stdlib.h>',
+       'static thread_local std::string g_err;', 'static std::atomic<long> g_calls(-1);', 'extern "C" {',
        'const char *mcq_last_error(void) { return g_err.c_str(); }',
        'int mcq_tables_set_error(const char *m) { g_err = m; return MCQ_EINVAL; }',
        'mcq_ctx *mcq_ctx_clone(const mcq_ctx *c) { return (mcq_ctx *)c; }', 'void mcq_destroy(mcq_ctx *) {}',
        # a stand-in equity so that mcq_tables_run (helper thread, thread pool) can run without a GPU: the same
        # function of the query as _fake_equity in tests/test_table_driver.py
+       # MCQ_STUB_FAIL_AFTER=k: the k-th call after the variable appeared fails like a device error (a lock-step dying
+       # half way); unsetting it disarms the countdown
        'int mcq_eval_batch(mcq_ctx *, const mcq_query *q, size_t n, uint64_t, uint64_t, int, mcq_result *out) {',
+       '    const char *fa = getenv("MCQ_STUB_FAIL_AFTER");',
+       '    if (!fa) g_calls = -1;',
+       '    else { long e = -1; g_calls.compare_exchange_strong(e, atol(fa));',
+       '           if (g_calls.fetch_sub(1) == 1) { g_err = "stand-in device failure"; return MCQ_EDEVICE; } }',
        '    for (size_t i = 0; i < n; i++) { unsigned x = q[i].hole[0] * 131u + q[i].hole[1] * 31u + q[i].n_players * 13u + q[i].n_board * 3u;',
        '        for (unsigned k = 0; k < q[i].n_board; k++) x += q[i].board[k] * 7u;',
        '        mcq_result r = {}; r.runs = 100; r.win = x % 101u; out[i] = r; }',
@@ -44,4 +51,4 @@ python3 -m pytest tests/test_oracle_golden.py tests/test_lane_arithmetic_host.py
 g++ -O1 -g -fsanitize=thread -fno-omit-frame-pointer -shared -fPIC -std=c++17 -Wno-unknown-pragmas -I$R/include \
     -o $T/libmcq_tsan.so $T/stub.cpp $R/neuron_poker_amd/csrc/mcq_tables.cpp -lpthread
 LD_PRELOAD="$(gcc -print-file-name=libtsan.so)" TSAN_OPTIONS="report_signal_unsafe=0 exitcode=66" \
-MCQ_LIBRARY=$T/libmcq_tsan.so MCQ_SAN_STUB=1 python3 -m pytest tests/test_table_driver.py -x -q -k "stand_in or thread_count" -p no:cacheprovider
+MCQ_LIBRARY=$T/libmcq_tsan.so MCQ_SAN_STUB=1 python3 -m pytest tests/test_table_driver.py -x -q -k "stand_in or thread_count or half_way" -p no:cacheprovider

@@ -404,6 +404,16 @@ def test_config4_full_size_sharded_like_8_gpus(eng):
         part[lo:hi] = u64(eng.eval_batch(q[lo:hi], seed=4, first_query_id=lo))
         total += part  # the all-reduce(SUM)
     assert np.array_equal(total, whole)
+    # the same 8-way partition through the C ABI's multi-GPU entry: 8 shards (here all on this device), their tally
+    # matrices joined by the entry's ONE ncclAllReduce on a communicator from ncclCommInitAll
+    me = npa.MultiEngine([0] * 8)
+    try:
+        got = u64(me.eval_batch(q, seed=4, first_query_id=0))
+        info = me.info
+    finally:
+        me.close()
+    assert info["shards"] == 8 and info["devices"] == 1 and info["last_partition"] == "queries" and info["rccl_version"] > 0
+    assert np.array_equal(got, whole)
     assert (whole[:, 0] == 20000).all() and (whole[:, 1] == 5 * 20000).all()
     assert np.array_equal(whole[:, 2] + whole[:, 3], whole[:, 4:].sum(1))
     idx = np.arange(17, B, 4099)  # a few rows bit for bit against the oracle
@@ -645,16 +655,141 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
-                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--states", "256", "--iters", "3000",
-                          "--backend", "gloo", "--single-device"], capture_output=True, text=True, timeout=300, cwd=root)
+    small = ["--steps", "2", "--warmup", "1", "--states", "256", "--iters", "3000", "--no-extras", "--no-cpu-baseline"]
+    # (a) exactly as the scaling driver may invoke it: no launcher prefix; bench.py starts its own ranks
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                          "--single-device"] + small, capture_output=True, text=True, timeout=300, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [x for x in out.stdout.splitlines() if x.startswith("{")]
     assert len(line) == 1, out.stdout
     d = _json.loads(line[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["hand_evals_per_step"] == 2 * 256 * 3000 * 6
+    # (b) under the launcher, as the contract's N > 1 command line
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--backend", "gloo", "--single-device"] + small,
+                         capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert len([x for x in out.stdout.splitlines() if x.startswith("{")]) == 1, out.stdout
+
+
+def test_bench_rccl_branch_runs_on_this_gpu():
+    """The RCCL code path of bench.py (process group "nccl" = RCCL, all-reduce of the tally matrix on the device,
+    barrier, max-over-ranks timing) executed for real: one rank under the launcher -- all a one-GPU box can hold,
+    RCCL refuses two ranks on one device -- makes exactly the calls an N-GPU job makes."""
+    import json as _json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                          "--gpus", "1", "--steps", "2", "--warmup", "1", "--states", "256", "--iters", "3000",
+                          "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [x for x in out.stdout.splitlines() if x.startswith("{")]
+    assert len(line) == 1, out.stdout
+    d = _json.loads(line[0])
+    assert d["n_gpus"] == 1 and "RCCL all-reduce" in d["config"]["workload"] and d["value"] > 0
+
+
+def test_multi_gpu_entry_partitions_equal_single_context(eng):
+    """mcq_multi_eval_batch (include/mcq.h): shards + one ncclAllReduce.  Whatever the partition -- blocks of
+    queries, shares of every query's iterations, more shards than queries, one shard -- the tallies are those of
+    mcq_eval_batch on one context, and of the oracle."""
+    g = np.random.default_rng(2026)
+    B = 41
+    hole, board, npl = [], [], []
+    for i in range(B):
+        nb = [0, 3, 4, 5][i % 4]
+        c = g.permutation(52)[:2 + nb]
+        hole.append(c[:2])
+        board.append(list(c[2:]) + [255] * (5 - nb))
+        npl.append(1 + i % 10)
+    runs = g.choice([1, 700, 1024, 3073, 20000], B)
+    q = npa.pack_queries(hole, board, npl, runs)
+    want = u64(eng.eval_batch(q, seed=11, first_query_id=500))
+    assert np.array_equal(want, O.run_batch(O.MODE_CTR, q.view(np.uint8).reshape(-1, 16), 11, first_qid=500, threads=8))
+    for shards in (1, 2, 3, 8):
+        me = npa.MultiEngine([0] * shards)
+        try:
+            for part in ("queries", "iterations", "auto"):
+                got = u64(me.eval_batch(q, seed=11, first_query_id=500, partition=part))
+                assert np.array_equal(got, want), (shards, part)
+            assert me.info["last_partition"] == "iterations"      # 41 < 256 * shards
+            assert np.array_equal(u64(me.eval_batch(q[:2], seed=11, first_query_id=500, partition="queries")), want[:2])
+            bad = q.copy()
+            bad["hole"][7] = (3, 3)
+            with pytest.raises(ValueError):
+                me.eval_batch(bad, seed=1)
+            assert len(me.eval_batch(q[:0], seed=1)) == 0
+            t = me.last_times_ms
+            assert t["call"] > 0 and t["all_reduce"] >= 0
+            me.set_dealing_law("uniform")
+            eng.set_dealing_law("uniform")
+            try:
+                assert np.array_equal(u64(me.eval_batch(q, seed=3)), u64(eng.eval_batch(q, seed=3)))
+            finally:
+                eng.set_dealing_law("reference")
+        finally:
+            me.close()
+
+
+def test_device_entry_on_two_streams_at_once(eng):
+    """Two asynchronous device-entry calls in flight on different streams of one context: each stream has its own
+    scheduling scratch, so neither disturbs the other (and a host-entry call in between uses the context's own)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    g = np.random.default_rng(5)
+    qa = npa.pack_queries([g.permutation(52)[:2] for _ in range(900)], np.full((900, 5), 255, np.uint8), 6, 40000)
+    qb = npa.pack_queries([g.permutation(52)[:2] for _ in range(300)], np.full((300, 5), 255, np.uint8), 3, 2000)
+    want_a, want_b = u64(eng.eval_batch(qa, 7, first_query_id=1)), u64(eng.eval_batch(qb, 8, first_query_id=2))
+    d_a = torch.from_numpy(qa.view(np.uint8).reshape(-1, 16).copy()).to(dev)
+    d_b = torch.from_numpy(qb.view(np.uint8).reshape(-1, 16).copy()).to(dev)
+    o_a = torch.zeros((900, 13), dtype=torch.int64, device=dev)
+    o_b = torch.zeros((300, 13), dtype=torch.int64, device=dev)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        o_a.zero_(); o_b.zero_()
+        torch.cuda.synchronize()
+        eng.eval_batch_device(d_a.data_ptr(), 900, 7, o_a.data_ptr(), first_query_id=1, stream=s1.cuda_stream)   # long
+        eng.eval_batch_device(d_b.data_ptr(), 300, 8, o_b.data_ptr(), first_query_id=2, stream=s2.cuda_stream)   # short
+        mid = u64(eng.eval_batch(qb, 8, first_query_id=2))                                                        # host entry
+        torch.cuda.synchronize()
+        assert np.array_equal(o_a.cpu().numpy().view(np.uint64), want_a)
+        assert np.array_equal(o_b.cpu().numpy().view(np.uint64), want_b) and np.array_equal(mid, want_b)
+
+
+def test_device_entry_refuses_to_grow_its_scratch_inside_a_capture(eng):
+    """A first call on a stream that is being captured would have to allocate: it fails cleanly with ValueError
+    (MCQ_EINVAL) instead of breaking the capture half way; after one call outside the capture it works."""
+    import torch
+    dev = torch.device("cuda", 0)
+    e2 = npa.Engine(0)
+    try:
+        q = npa.pack_queries([[1, 2]] * 64, np.full((64, 5), 255, np.uint8), 2, 1000)
+        d_q = torch.from_numpy(q.view(np.uint8).reshape(-1, 16).copy()).to(dev)
+        out = torch.zeros((64, 13), dtype=torch.int64, device=dev)
+        s = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with pytest.raises(ValueError):
+            with torch.cuda.graph(graph, stream=s):
+                e2.eval_batch_device(d_q.data_ptr(), 64, 1, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        prev = torch.cuda.current_device()
+        e2.eval_batch_device(d_q.data_ptr(), 64, 1, out.data_ptr(), stream=s.cuda_stream)
+        assert torch.cuda.current_device() == prev
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), u64(e2.eval_batch(q, 1)))
+    finally:
+        e2.close()
 
 
 def test_device_entry_inside_a_hip_graph(eng):

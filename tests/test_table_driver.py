@@ -244,3 +244,31 @@ def test_native_run_loop_with_stand_in_equity(T, threads, overlap):
         sa, sb = a.state(t), b.state(t)
         assert np.array_equal(sa.pop("stacks"), sb.pop("stacks")) and sa == sb
     assert np.array_equal(a.begin(), b.begin())
+
+
+@pytest.mark.skipif(os.environ.get("MCQ_SAN_STUB") != "1", reason="needs the stand-in equity of tests/sanitize_cpu.sh")
+@pytest.mark.parametrize("overlap", [True, False])
+def test_native_run_loop_failing_half_way_marks_the_driver_failed(overlap, monkeypatch):
+    """A device error in the middle of mcq_tables_run (the stand-in's 5th batch) comes back as an error code -- no
+    exception crosses the C ABI, the helper thread is joined -- and when the two halves of the tables are out of step
+    afterwards the driver refuses every later call instead of reusing query ids on desynchronised tables."""
+    from neuron_poker_amd import _lib
+
+    class FakeEngine:
+        _ctx = 1
+
+    seats = [("equity", .3, .5), ("random",), ("equity", .2, .75)]
+    t = _lib.Tables(FakeEngine(), 200, seats, seed=3, threads=1, overlap=overlap)
+    t.run(3)
+    monkeypatch.setenv("MCQ_STUB_FAIL_AFTER", "5")
+    with pytest.raises(_lib.McqError, match="stand-in device failure"):
+        t.run(8)
+    monkeypatch.delenv("MCQ_STUB_FAIL_AFTER")
+    if overlap:   # the halves are out of step: refused for good
+        with pytest.raises(ValueError, match="failed in an earlier call"):
+            t.run(1)
+        with pytest.raises(ValueError, match="failed in an earlier call"):
+            t.resume(np.zeros(200))
+    else:         # one batch per step: the failed step's queries are still pending, the call can be repeated
+        t.run(1)
+    t.close()
