@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+JSON_OUT = sys.stdout  # where the ONE JSON line goes (see main)
 PEAK_VALU_TOPS = 256 * 4 * 2.4e9 * 32 / 1e12  # 256 CU x 4 SIMD-32 x 2.4 GHz full-rate int32 lane-ops
 HBM_PEAK_GBPS = 8000.0
 
@@ -148,7 +149,7 @@ def native_multi(args):
                                                                     info["last_partition"], info["devices"]),
                    "states_per_gpu": args.states, "n_players": N, "iterations": runs, "hand_evals_per_step": evals},
         "native_multi": {"kernel_max_ms": float(np.mean(kmax)), "all_reduce_ms": float(np.mean(ar)),
-                         "rccl_version": info["rccl_version"]}}), flush=True)
+                         "rccl_version": info["rccl_version"]}}), file=JSON_OUT, flush=True)
     me.close()
 
 
@@ -170,9 +171,17 @@ def main():
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
 
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.native_multi or under_launcher or args.gpus == 1:
+        # RCCL prints a version banner on STDOUT when a communicator is created; this process's stdout carries the
+        # JSON line and nothing else, so everything else written to fd 1 from here on goes to stderr
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
+        global JSON_OUT
+        JSON_OUT = os.fdopen(json_fd, "w")
     if args.native_multi:
         return native_multi(args)
-    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if args.gpus > 1 and not under_launcher:
         # `python bench.py --gpus N` as such: start the one-process-per-GPU job as a CHILD (torch.distributed.run ->
         # N ranks) before this process has touched the GPU or imported torch, and hand its output and exit code on.
@@ -310,6 +319,16 @@ def main():
             dt = (time.perf_counter() - t1) / 5
             extras["configs[2]_4096x3x50k"] = {"call_ms_host_buffers": 1e3 * dt, "kernel_ms": eng.last_kernel_ms,
                                                "hand_evals_per_s": 4096 * 3 * 50000 / dt}
+            # the same batch in the PARITY mode (bit-exact replay of np.random.seed(s) per query): MT19937 walked on
+            # the device, one wave per query, then the evaluation kernel on the draws it left in HBM
+            eng.eval_batch(q3, seed=1, mode=npa.MODE_REPLAY_MT19937)
+            t1 = time.perf_counter()
+            for i in range(3):
+                eng.eval_batch(q3, seed=i, mode=npa.MODE_REPLAY_MT19937)
+            dt = (time.perf_counter() - t1) / 3
+            extras["configs[2]_replay"] = {"call_ms_host_buffers": 1e3 * dt, "kernel_ms_parse_plus_eval": eng.last_kernel_ms,
+                                           "hand_evals_per_s": 4096 * 3 * 50000 / dt,
+                                           "mt19937_words_per_s": 4096 * 50000 * 12.8 / dt}
         # BASELINE configs[3] (the 8-GPU config) on this one GPU: 65 536 states, flop / turn tables alternating, 6 players,
         # 20k iterations, host buffers; one rank of 8 would take an eighth of the queries
         g3 = np.random.default_rng(65536)
@@ -382,7 +401,7 @@ def main():
         ref = cpu_reference_cpp(N)
         if ref:
             out["cpu_baseline_reference_cpp"] = ref
-    print(json.dumps(out), flush=True)
+    print(json.dumps(out), file=JSON_OUT, flush=True)
     if grouped:
         dist.destroy_process_group()
 

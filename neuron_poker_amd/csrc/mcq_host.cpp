@@ -26,7 +26,7 @@ namespace {
 
 thread_local std::string g_err;
 
-constexpr size_t kReplayChunkBytes = 256u << 20; /* draw bytes staged per launch in parity mode */
+constexpr size_t kReplayChunkBytes = 256u << 20;  /* draw bytes staged per launch by the host walk (numpy-stream entry) */
 constexpr uint32_t kBlock = 1024;                /* threads per block of the evaluation kernels */
 
 }  // namespace
@@ -119,12 +119,12 @@ int scratch_for(mcq_ctx *c, hipStream_t s, size_t bytes, bool capturing, mcq_ctx
 
 int mcq_run_slice(mcq_ctx *c, int mode, const mcq_query *d_q, uint32_t n, mcq_result *d_res, uint64_t seed,
                   uint64_t first_qid, uint64_t total_tasks, const uint8_t *d_draws, const uint64_t *d_off, hipStream_t s,
-                  bool timed, uint64_t max_tasks, uint32_t part, uint32_t n_parts) {
+                  bool timed, uint64_t max_tasks, uint32_t part, uint32_t n_parts, const uint32_t *mt_seed32) {
     if (mode == MCQ_MODE_PHILOX && c->law == MCQ_LAW_UNIFORM) mode = MCQ_INTERNAL_MODE_UNIFORM;
     const bool capturing = stream_capturing(s);
     if (capturing) timed = false; /* events recorded inside a capture cannot be read back */
     mcq_ctx::Scratch *sc = nullptr;
-    int rc = scratch_for(c, s, ((size_t)n + 2) * sizeof(uint64_t), capturing, &sc);
+    int rc = scratch_for(c, s, ((size_t)n + 3) * sizeof(uint64_t), capturing, &sc);
     if (rc) return rc;
     uint64_t *d_prefix = (uint64_t *)sc->prefix.p;
     HIP_TRY(mcq_launch_prep(d_q, n, d_res, d_prefix, part, n_parts, (uint32_t)c->n_cu, c->split_max, s));
@@ -135,6 +135,9 @@ int mcq_run_slice(mcq_ctx *c, int mode, const mcq_query *d_q, uint32_t n, mcq_re
     if (total_tasks == 0 && n <= 1024u) split = MCQ_SPLIT_FROM_PREP;
     const int slot = (int)(c->n_timed % mcq_ctx::kRing);
     if (timed) HIP_TRY(hipEventRecord(c->ev0[slot], s));
+    if (mt_seed32) /* parity mode: the stream walk belongs to the timed region */
+        HIP_TRY(mcq_launch_mt_parse(d_q, n, *mt_seed32, const_cast<uint8_t *>(d_draws), d_off, d_res,
+                                    reinterpret_cast<uint32_t *>(d_prefix + n + 2), (uint32_t)c->n_cu, s));
     HIP_TRY(mcq_launch_eval(mode, d_q, n, d_prefix, d_res, seed, first_qid, c->d_luts, d_draws, d_off, grid, block, split,
                             part, n_parts, s));
     if (timed) {
@@ -171,11 +174,65 @@ extern "C" int mcq_kernel_times(mcq_ctx *c, float *ms, int max_n);
 
 namespace {
 
-/* parity mode: chunks of queries whose draw bytes fit the staging budget.  stream == nullptr: query i replays
- * np.random.seed((seed + first_qid + i) mod 2^32) (parsed in parallel); otherwise all queries continue the
- * one MT19937 stream `stream` in order, as consecutive reference calls share numpy's global state. */
+/* parity mode, independent streams: query i replays np.random.seed((seed + first_qid + i) mod 2^32).  The stream walk
+ * runs on the DEVICE (mcq_mt_parse_kernel, one wave per query) and fills the draw buffer the evaluation kernel
+ * reads; the host only lays the buffer out.  Chunks of queries whose draws fit c->replay_device_bytes. */
+int replay_batch_device(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed, uint64_t first_query_id, mcq_result *out) {
+    HIP_TRY(c->h_off.reserve(n * sizeof(uint64_t)));
+    HIP_TRY(c->d_off.reserve(n * sizeof(uint64_t)));
+    uint64_t *off = (uint64_t *)c->h_off.p;
+    struct Chunk { size_t a, b; uint64_t bytes, tasks, max_tasks; };
+    std::vector<Chunk> chunks;
+    size_t a = 0;
+    uint64_t largest = 0;
+    while (a < n) {
+        Chunk ch = {a, a, 0, 0, 0};
+        while (ch.b < n && ch.b - ch.a < 0x7fffffffu) {
+            const uint64_t stride = ((uint64_t)q[ch.b].runs + 63u) & ~63ull;
+            const uint64_t need = stride * mcq_draws_per_iteration(q[ch.b]);
+            if (ch.b > ch.a && ch.bytes + need > c->replay_device_bytes) break;
+            off[ch.b] = ch.bytes;
+            ch.bytes += need;
+            const uint64_t t = tasks_of(q[ch.b]);
+            ch.tasks += t;
+            if (t > ch.max_tasks) ch.max_tasks = t;
+            ch.b++;
+        }
+        if (ch.bytes > largest) largest = ch.bytes;
+        chunks.push_back(ch);
+        a = ch.b;
+    }
+    HIP_TRY(c->d_draws.reserve(largest + 64));
+    HIP_TRY(hipMemcpyAsync(c->d_off.p, off, n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    const uint64_t timed0 = c->n_timed;
+    for (const Chunk &ch : chunks) { /* stream order keeps a chunk's parse behind the previous chunk's evaluation */
+        const uint32_t seed32 = (uint32_t)(seed + first_query_id + ch.a);
+        int rc = mcq_run_slice(c, MCQ_MODE_REPLAY_MT19937, (const mcq_query *)c->d_q.p + ch.a, (uint32_t)(ch.b - ch.a),
+                               (mcq_result *)c->d_res.p + ch.a, seed, first_query_id + ch.a, ch.tasks ? ch.tasks : 1,
+                               (const uint8_t *)c->d_draws.p, (const uint64_t *)c->d_off.p + ch.a, c->stream, true,
+                               ch.max_tasks, 0, 1, &seed32);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(c->h_res.p, c->d_res.p, n * sizeof(mcq_result), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(out, c->h_res.p, n * sizeof(mcq_result));
+    float total = 0.f;
+    const int launched = (int)(c->n_timed - timed0);
+    if (launched > 0 && launched <= mcq_ctx::kRing) {
+        float ms[mcq_ctx::kRing];
+        if (mcq_kernel_times(c, ms, launched) == launched)
+            for (int i = 0; i < launched; i++) total += ms[i];
+    }
+    c->last_ms = total;
+    return MCQ_OK;
+}
+
+/* parity mode coupled to ONE MT19937 stream that all queries continue in order, as consecutive reference calls
+ * share numpy's global state (mcq_eval_batch_numpy_stream): a serial walk by construction, done on the host
+ * (mcq_replay.hpp); chunks of queries whose draw bytes fit the staging budget. */
 int replay_batch(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed, uint64_t first_query_id, McqMt19937 *stream,
                  mcq_result *out) {
+    if (!stream) return replay_batch_device(c, q, n, seed, first_query_id, out);
     std::vector<uint64_t> passes(n, 0);
     float replay_ms = 0.f;
     size_t a = 0;
@@ -199,35 +256,16 @@ int replay_batch(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed, uint64
         HIP_TRY(c->d_draws.reserve(bytes + 64));
         HIP_TRY(c->d_off.reserve(m * sizeof(uint64_t)));
         uint8_t *hd = (uint8_t *)c->h_draws.p;
-        if (stream) {
-            for (size_t i = 0; i < m; i++) {
-                const mcq_query &qq = q[a + i];
-                uint64_t stride = ((uint64_t)qq.runs + 63u) & ~63ull;
-                passes[a + i] = mcq_replay_parse_stream(qq, *stream, hd + off[i], stride);
-            }
-        } else {
-            std::atomic<size_t> next(0);
-            unsigned hw = std::thread::hardware_concurrency();
-            size_t nt = hw ? hw : 4;
-            if (nt > 32) nt = 32;
-            if (nt > m) nt = m;
-            auto work = [&]() {
-                for (size_t i = next.fetch_add(1); i < m; i = next.fetch_add(1)) {
-                    const mcq_query &qq = q[a + i];
-                    uint64_t stride = ((uint64_t)qq.runs + 63u) & ~63ull;
-                    passes[a + i] = mcq_replay_parse(qq, (uint32_t)(seed + first_query_id + a + i), hd + off[i], stride);
-                }
-            };
-            std::vector<std::thread> th;
-            for (size_t t = 1; t < nt; t++) th.emplace_back(work);
-            work();
-            for (auto &t : th) t.join();
+        for (size_t i = 0; i < m; i++) {
+            const mcq_query &qq = q[a + i];
+            uint64_t stride = ((uint64_t)qq.runs + 63u) & ~63ull;
+            passes[a + i] = mcq_replay_parse_stream(qq, *stream, hd + off[i], stride);
         }
         HIP_TRY(hipMemcpyAsync(c->d_draws.p, hd, bytes, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(c->d_off.p, off, m * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
         int rc = mcq_run_slice(c, MCQ_MODE_REPLAY_MT19937, (const mcq_query *)c->d_q.p + a, (uint32_t)m,
-                           (mcq_result *)c->d_res.p + a, seed, first_query_id + a, tasks, (const uint8_t *)c->d_draws.p,
-                           (const uint64_t *)c->d_off.p, c->stream, true, max_tasks);
+                               (mcq_result *)c->d_res.p + a, seed, first_query_id + a, tasks, (const uint8_t *)c->d_draws.p,
+                               (const uint64_t *)c->d_off.p, c->stream, true, max_tasks);
         if (rc) return rc;
         HIP_TRY(hipStreamSynchronize(c->stream)); /* staging buffers are reused by the next chunk */
         float ms = 0.f;
@@ -276,6 +314,7 @@ mcq_ctx *mcq_ctx_clone(const mcq_ctx *c) {
     if (d) {
         d->law = c->law;
         d->split_max = c->split_max;
+        d->replay_device_bytes = c->replay_device_bytes;
     }
     return d;
 }
@@ -351,6 +390,10 @@ mcq_ctx *mcq_create(int device, int flags) {
     if (const char *e = getenv("MCQ_SPLIT_MAX")) { /* tuning knob, see pick_geometry */
         int v = atoi(e);
         c->split_max = (uint32_t)(v < 0 ? 0 : (v > 4 ? 4 : v));
+    }
+    if (const char *e = getenv("MCQ_REPLAY_DEVICE_BYTES")) { /* chunking of the parity mode's draw buffer (tests) */
+        const long long v = atoll(e);
+        if (v > 0) c->replay_device_bytes = (uint64_t)v;
     }
     CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto &sc : c->scratch) CREATE_TRY(hipEventCreateWithFlags(&sc.done, hipEventDisableTiming));
@@ -497,7 +540,7 @@ int mcq_eval_batch_ext(mcq_ctx *c, const mcq_query *q, const mcq_query_ext *ext,
     HIP_TRY(c->d_q.reserve(n * sizeof(mcq_query)));
     HIP_TRY(c->d_ext.reserve(n * sizeof(mcq_query_ext)));
     HIP_TRY(c->d_res.reserve(n * sizeof(mcq_result)));
-    HIP_TRY(c->scratch[0].prefix.reserve((n + 2) * sizeof(uint64_t)));
+    HIP_TRY(c->scratch[0].prefix.reserve((n + 3) * sizeof(uint64_t)));
     uint8_t *hq = (uint8_t *)c->h_q.p;
     memcpy(hq, q, n * sizeof(mcq_query));
     memcpy(hq + n * sizeof(mcq_query), ext, n * sizeof(mcq_query_ext));

@@ -28,3 +28,7 @@ hipError_t mcq_launch_eval_ext(int mode, const mcq_query *d_q, const mcq_query_e
                                uint32_t block, hipStream_t s);
 /* dst[i] += src[i], i < n (tally matrices of two shards on one device, both 16-byte aligned) */
 hipError_t mcq_launch_add_u64(uint64_t *d_dst, const uint64_t *d_src, uint64_t n, hipStream_t s);
+/* parity mode: one wave per query parses np.random.seed(seed32 + i)'s MT19937 stream into d_draws (+ passes into the
+ * result rows); d_counter must be zero (the prep kernel leaves one behind the cost prefix) */
+hipError_t mcq_launch_mt_parse(const mcq_query *d_q, uint32_t n, uint32_t seed32, uint8_t *d_draws, const uint64_t *d_draw_off,
+                               mcq_result *d_res, uint32_t *d_counter, uint32_t n_cu, hipStream_t s);

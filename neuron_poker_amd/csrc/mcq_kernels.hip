@@ -16,6 +16,7 @@
 #include "mcq_device.hpp"
 #include "mcq_exact.hpp"
 #include "mcq_internal.hpp"
+#include "mcq_mt.hpp"
 
 namespace {
 
@@ -120,6 +121,41 @@ __global__ __launch_bounds__(1024) void mcq_prep_kernel(const mcq_query *__restr
         prefix[n] = carry;
         /* the cut for MCQ_SPLIT_FROM_PREP launches (queries resident in HBM, at most 1024 of them) */
         prefix[n + 1] = n <= 1024u && sum_tasks ? mcq_pick_split(sum_tasks, max_tasks, n_cu, split_max) : 0u;
+        prefix[n + 2] = 0; /* work counter of mcq_mt_parse_kernel */
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- parity mode: MT19937
+// One wave per query walks np.random.seed(seed32 + query index)'s stream (mcq_mt.hpp) and leaves the accepted draws
+// in the draw-major global buffer the evaluation kernel reads, `passes` in the query's result row.  Queries are
+// handed out through an atomic counter (their lengths differ); every wave leaves when the counter passes n.
+// 5.5 KB of LDS per wave (MT state, draw table, ring), no lookup tables: several blocks per CU.
+constexpr int kMtBlock = 256;
+__global__ __launch_bounds__(kMtBlock) void mcq_mt_parse_kernel(const mcq_query *__restrict__ queries, uint32_t n,
+                                                                uint32_t seed32, uint8_t *__restrict__ draws,
+                                                                const uint64_t *__restrict__ draw_off,
+                                                                mcq_result *__restrict__ res, uint32_t *__restrict__ counter) {
+    __shared__ __attribute__((aligned(16))) McqMtWave ws[kMtBlock / 64];
+    McqMtWave &w = ws[threadIdx.x >> 6];
+    const uint32_t lane = threadIdx.x & 63u;
+    for (;;) {
+        uint32_t qi = 0;
+        if (lane == 0) qi = atomicAdd(counter, 1u);
+        qi = __builtin_amdgcn_readfirstlane(qi);
+        if (qi >= n) break;
+        const uint4 raw = reinterpret_cast<const uint4 *>(queries)[qi];
+        const McqQueryWords q = {(uint32_t)__builtin_amdgcn_readfirstlane(raw.x), (uint32_t)__builtin_amdgcn_readfirstlane(raw.y),
+                                 (uint32_t)__builtin_amdgcn_readfirstlane(raw.z), (uint32_t)__builtin_amdgcn_readfirstlane(raw.w)};
+        if (!mcq_query_valid(q)) continue;
+        const uint32_t n_opp = q.n_players() - 1u, n_deal = 5u - q.n_board(), runs = q.runs();
+        if (2u * n_opp + n_deal == 0u || runs == 0u) continue; /* nothing is drawn: passes stays 0 */
+        MCQ_WAVE_SYNC(); /* the previous query's reads of this wave's LDS are done */
+        mcq_mt_seed(w, seed32 + qi);
+        MCQ_WAVE_SYNC();
+        McqMtState st = {MCQ_MT_N, 0u, 0u, 0u, 0u, 0ull};
+        mcq_mt_parse_query(w, st, 50u - q.n_board(), n_opp, n_deal, runs, draws + draw_off[qi],
+                           ((uint64_t)runs + 63u) & ~63ull);
+        if (lane == 0) reinterpret_cast<unsigned long long *>(res + qi)[1] = st.passes;
     }
 }
 
@@ -565,6 +601,16 @@ hipError_t mcq_launch_eval(int mode, const mcq_query *d_q, uint32_t n, const uin
     else if (mode == MCQ_INTERNAL_MODE_UNIFORM) MCQ_LAUNCH_EVAL(MCQ_INTERNAL_MODE_UNIFORM);
     else MCQ_LAUNCH_EVAL(MCQ_MODE_REPLAY_MT19937);
 #undef MCQ_LAUNCH_EVAL
+    return hipGetLastError();
+}
+
+hipError_t mcq_launch_mt_parse(const mcq_query *d_q, uint32_t n, uint32_t seed32, uint8_t *d_draws, const uint64_t *d_draw_off,
+                               mcq_result *d_res, uint32_t *d_counter, uint32_t n_cu, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    uint32_t blocks = (n + kMtBlock / 64 - 1) / (kMtBlock / 64);
+    if (blocks > 8u * n_cu) blocks = 8u * n_cu; /* what fits a CU at once: 8 blocks x 4 waves */
+    hipLaunchKernelGGL(mcq_mt_parse_kernel, dim3(blocks), dim3(kMtBlock), 0, s, d_q, n, seed32, d_draws, d_draw_off, d_res,
+                       d_counter);
     return hipGetLastError();
 }
 

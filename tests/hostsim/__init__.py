@@ -11,6 +11,7 @@ _SRCS = [os.path.join(_HERE, "hostsim.cpp"),
          os.path.join(_HERE, "..", "..", "neuron_poker_amd", "csrc", "mcq_device.hpp"),
          os.path.join(_HERE, "..", "..", "neuron_poker_amd", "csrc", "mcq_replay.hpp"),
          os.path.join(_HERE, "..", "..", "neuron_poker_amd", "csrc", "mcq_exact.hpp"),
+         os.path.join(_HERE, "..", "..", "neuron_poker_amd", "csrc", "mcq_mt.hpp"),
          os.path.join(_HERE, "..", "..", "include", "mcq.h")]
 _lib = None
 
@@ -114,3 +115,28 @@ def exact(query16, uniform=False):
     if rc:
         raise ValueError(rc)
     return out
+
+
+def mt_parse(query16, seed32, reference=False):
+    """Accepted draws [D, stride] (r | 0x80 bytes) and passes of one query's MT19937 stream: the device's
+    wave-cooperative parse (mcq_mt.hpp, lanes as arrays) or, reference=True, the sequential host walk."""
+    q = np.ascontiguousarray(query16, np.uint8)
+    runs = int(q[12:16].view(np.uint32)[0])
+    D = 2 * (int(q[8]) - 1) + 5 - int(q[7])
+    stride = (runs + 63) & ~63
+    draws = np.zeros((max(D, 1), max(stride, 64)), np.uint8)
+    f = lib().hs_mt_parse_reference if reference else lib().hs_mt_parse
+    f.restype = C.c_uint64
+    passes = f(_p(q, C.c_uint8), C.c_uint32(seed32), _p(draws, C.c_uint8), C.c_uint64(max(stride, 64)))
+    return draws[:D, :runs], int(passes)
+
+
+def mt_wave_words(seed32, n):
+    out = np.zeros(n, np.uint32)
+    lib().hs_mt_regenerate_words(C.c_uint32(seed32), C.c_uint32(n), _p(out, C.c_uint32))
+    return out
+
+
+def mt_magic_ok():
+    lib().hs_mt_magic_ok.restype = C.c_uint32
+    return bool(lib().hs_mt_magic_ok())

@@ -11,6 +11,7 @@
 
 #include "../../neuron_poker_amd/csrc/mcq_device.hpp"
 #include "../../neuron_poker_amd/csrc/mcq_exact.hpp"
+#include "../../neuron_poker_amd/csrc/mcq_mt.hpp"
 #include "../../neuron_poker_amd/csrc/mcq_replay.hpp"
 
 namespace {
@@ -255,4 +256,34 @@ extern "C" int hs_exact(const mcq_query *q, int law, uint64_t *out13) {
         out13[4 + mcq_key_type(bd.hero_key)] += win + tie;
     }
     return 0;
+}
+
+// ---- the wave-cooperative MT19937 parse of the device (mcq_mt.hpp), compiled with every per-lane variable as a
+// 64-entry array: draws / passes must equal the sequential host walk (mcq_replay_parse) byte for byte
+extern "C" uint64_t hs_mt_parse(const mcq_query *q, uint32_t seed32, uint8_t *draws, uint64_t stride) {
+    static thread_local McqMtWave w;
+    const uint32_t n_opp = q->n_players - 1u, n_deal = 5u - q->n_board;
+    if (2u * n_opp + n_deal == 0u || q->runs == 0u) return 0;
+    mcq_mt_seed(w, seed32);
+    McqMtState st = {MCQ_MT_N, 0, 0, 0, 0, 0};
+    mcq_mt_parse_query(w, st, 50u - q->n_board, n_opp, n_deal, q->runs, draws, stride);
+    return st.passes;
+}
+extern "C" uint64_t hs_mt_parse_reference(const mcq_query *q, uint32_t seed32, uint8_t *draws, uint64_t stride) {
+    return mcq_replay_parse(*q, seed32, draws, stride);
+}
+extern "C" void hs_mt_regenerate_words(uint32_t seed32, uint32_t n, uint32_t *out) { /* tempered words via the wave code */
+    static thread_local McqMtWave w;
+    mcq_mt_seed(w, seed32);
+    uint32_t pos = MCQ_MT_N;
+    for (uint32_t i = 0; i < n; i++) {
+        if (pos >= MCQ_MT_N) { mcq_mt_regenerate(w); pos = 0; }
+        out[i] = mcq_mt_temper(w.mt[pos++]);
+    }
+}
+extern "C" uint32_t hs_mt_magic_ok(void) { /* (p * magic) >> 16 == p / D for every p the parse can form */
+    for (uint32_t D = 1; D <= MCQ_MT_MAX_DRAWS; D++)
+        for (uint32_t p = 0; p < 128u; p++)
+            if (((p * mcq_mt_magic(D)) >> 16) != p / D) return 0;
+    return 1;
 }

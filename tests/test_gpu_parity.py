@@ -106,6 +106,38 @@ def test_replay_batch_equals_oracle_mt_per_query(eng):
     assert np.array_equal(got, exp)
 
 
+def test_replay_stream_walk_runs_on_the_device(eng, monkeypatch):
+    """The parity mode's MT19937 walk is a HIP kernel (mcq_mt_parse_kernel: one wave per query, mcq_mt.hpp): more
+    queries than resident waves, ragged run counts around the 64-iteration flushes and the 624-word regenerations,
+    queries that draw nothing (one player, five table cards), seeds wrapping 2^32, and the draw buffer cut into
+    several launches -- all equal to the oracle's literal walk (MT19937 + numpy randint + the reference's loops)."""
+    g = np.random.default_rng(77)
+    B = 9000
+    hole = np.zeros((B, 2), np.uint8)
+    board = np.full((B, 5), 255, np.uint8)
+    npl = np.zeros(B, np.uint8)
+    for i in range(B):
+        nb = [0, 3, 4, 5][i % 4]
+        c = g.permutation(52)[:2 + nb]
+        hole[i] = c[:2]
+        board[i, :nb] = c[2:]
+        npl[i] = 1 + i % 10
+    runs = g.choice([1, 2, 31, 63, 64, 65, 127, 128, 129, 200, 777], B)
+    runs[::1000] = 30000
+    q = npa.pack_queries(hole, board, npl, runs)
+    first = 2 ** 32 - 4000          # (seed + query id) wraps around 2^32 inside the batch
+    exp = O.run_batch(O.MODE_MT, q.view(np.uint8).reshape(-1, 16), 99, first, threads=8)
+    got = u64(eng.eval_batch(q, seed=99, first_query_id=first, mode=npa.MODE_REPLAY_MT19937))
+    assert np.array_equal(got, exp)
+    assert eng.last_kernel_ms > 0
+    monkeypatch.setenv("MCQ_REPLAY_DEVICE_BYTES", str(1 << 20))   # many launches: 1 MB of draws each
+    e2 = npa.Engine(0)
+    try:
+        assert np.array_equal(u64(e2.eval_batch(q, seed=99, first_query_id=first, mode=npa.MODE_REPLAY_MT19937)), exp)
+    finally:
+        e2.close()
+
+
 # ------------------------------------------------------------------------------------------ production mode
 def test_philox_equals_oracle_ctr_bit_exact(eng):
     g = np.random.default_rng(5)

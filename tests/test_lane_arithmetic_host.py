@@ -214,3 +214,27 @@ def test_exact_enumeration_three_players_on_the_turn():
         g = H.exact(_xq(hero, board, 3), uniform)
         win, tie, _ = O.exact(hero, board, 3, uniform)
         assert abs(int(g[2]) / int(g[0]) - win) < 1e-9 and abs(int(g[3]) / int(g[0]) - tie) < 1e-9
+
+
+def test_wave_cooperative_mt19937_parse_equals_the_sequential_walk():
+    """mcq_mt.hpp -- the device's parse of numpy's stream (64 words at a time, fixed-point iteration over the lanes'
+    positions, re-drawn pairs rewound, 64-iteration flushes) compiled with the lanes as arrays: accepted draws and
+    `passes` must equal the sequential walk of mcq_replay.hpp (itself pinned to the reference's deal traces) byte for
+    byte; the state words must be numpy's."""
+    assert H.mt_magic_ok()
+    for s in (0, 1, 5489, 12345, 2 ** 32 - 1):
+        w = H.mt_wave_words(s, 2600)                      # four regenerations
+        assert np.array_equal(w, H.mt_words(s, 2600))
+        rs = np.random.RandomState(s)
+        assert np.array_equal(w[:50], rs.randint(0, 2 ** 32, 50, dtype=np.uint64).astype(np.uint32))
+    g = np.random.default_rng(20261004)
+    for t in range(400):
+        nb = int(g.choice([0, 3, 4, 5]))
+        npl = int(g.integers(1, 11))
+        runs = int(g.choice([1, 2, 63, 64, 65, 127, 128, 129, 1000, 4097]))
+        c = g.permutation(52)[:2 + nb]
+        q = O.pack_queries([c[:2]], [list(c[2:]) + [255] * (5 - nb)], npl, runs)[0]
+        seed = int(g.integers(0, 2 ** 32))
+        d1, p1 = H.mt_parse(q, seed)
+        d2, p2 = H.mt_parse(q, seed, reference=True)
+        assert p1 == p2 and np.array_equal(d1, d2), (nb, npl, runs, seed)

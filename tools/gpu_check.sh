@@ -11,7 +11,7 @@ echo "bench rc=$?"
 python - <<PY
 import json
 try:
-    d = json.load(open("gpurun_out/bench_$TAG.json"))
+    d = [json.loads(l) for l in open("gpurun_out/bench_$TAG.json") if l.startswith("{")][-1]
     print("value %.4g evals/s  ms/step %.3f  kernel_ms %.3f  frac %.3f" % (d["value"], d["ms_per_step"], d["roofline"]["kernel_ms"], d["roofline"]["frac"]))
     for k, v in d.get("other_configs", {}).items():
         print(k, {a: round(b, 4) for a, b in v.items()})
