@@ -139,23 +139,26 @@ __global__ __launch_bounds__(kMtBlock) void mcq_mt_parse_kernel(const mcq_query 
     McqMtWave &w = ws[threadIdx.x >> 6];
     const uint32_t lane = threadIdx.x & 63u;
     for (;;) {
-        uint32_t qi = 0;
-        if (lane == 0) qi = atomicAdd(counter, 1u);
-        qi = __builtin_amdgcn_readfirstlane(qi);
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(counter, 1u);
+        const uint32_t qi = __builtin_amdgcn_readfirstlane(t);
         if (qi >= n) break;
         const uint4 raw = reinterpret_cast<const uint4 *>(queries)[qi];
         const McqQueryWords q = {(uint32_t)__builtin_amdgcn_readfirstlane(raw.x), (uint32_t)__builtin_amdgcn_readfirstlane(raw.y),
                                  (uint32_t)__builtin_amdgcn_readfirstlane(raw.z), (uint32_t)__builtin_amdgcn_readfirstlane(raw.w)};
-        if (!mcq_query_valid(q)) continue;
         const uint32_t n_opp = q.n_players() - 1u, n_deal = 5u - q.n_board(), runs = q.runs();
-        if (2u * n_opp + n_deal == 0u || runs == 0u) continue; /* nothing is drawn: passes stays 0 */
-        MCQ_WAVE_SYNC(); /* the previous query's reads of this wave's LDS are done */
-        mcq_mt_seed(w, seed32 + qi);
-        MCQ_WAVE_SYNC();
-        McqMtState st = {MCQ_MT_N, 0u, 0u, 0u, 0u, 0ull};
-        mcq_mt_parse_query(w, st, 50u - q.n_board(), n_opp, n_deal, runs, draws + draw_off[qi],
-                           ((uint64_t)runs + 63u) & ~63ull);
-        if (lane == 0) reinterpret_cast<unsigned long long *>(res + qi)[1] = st.passes;
+        /* wave-uniform: invalid queries and queries that draw nothing keep passes = 0 */
+        if (mcq_query_valid(q) && 2u * n_opp + n_deal != 0u && runs != 0u) {
+            MCQ_WAVE_SYNC(); /* the previous query's reads of this wave's LDS are done */
+            mcq_mt_seed(w, seed32 + qi);
+            MCQ_WAVE_SYNC();
+            McqMtState st = {MCQ_MT_N, 0u, 0u, 0u, 0u, 0ull};
+            mcq_mt_parse_query(w, st, 50u - q.n_board(), n_opp, n_deal, runs, draws + draw_off[qi],
+                               ((uint64_t)runs + 63u) & ~63ull);
+            /* every lane stores the same word: a store under `lane == 0` here would be a divergent branch in front of
+             * the loop's back edge, and the wave must be whole when it fetches the next query */
+            reinterpret_cast<unsigned long long *>(res + qi)[1] = st.passes;
+        }
     }
 }
 

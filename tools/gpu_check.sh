@@ -3,7 +3,7 @@
 set -o pipefail
 TAG=${1:-x}
 mkdir -p gpurun_out
-timeout -k 10 600 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests_$TAG.log 2>&1
+timeout -k 10 ${GPU_TEST_TIMEOUT:-600} python -m pytest tests -m gpu -x -v --timeout 240 > gpurun_out/gpu_tests_$TAG.log 2>&1
 echo "pytest rc=$?" >> gpurun_out/gpu_tests_$TAG.log
 tail -3 gpurun_out/gpu_tests_$TAG.log
 timeout -k 10 300 python bench.py --no-cpu-baseline > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
