@@ -94,6 +94,7 @@ struct mcq_ctx {
     int occ[3] = {1, 1, 1}; /* resident kBlock-thread blocks per CU of the eval kernels (by internal mode) */
     int law = MCQ_LAW_REFERENCE;
     uint64_t replay_device_bytes = 4ull << 30; /* parity mode: draw bytes per launch (MCQ_REPLAY_DEVICE_BYTES) */
+    uint32_t load_waves = 16; /* waves per block that load the table image when fewer take work (MCQ_LOAD_WAVES) */
     uint32_t split_max = 4; /* finest cut of a task for small batches: 16 >> split_max iterations per lane */
     hipStream_t stream = nullptr;
     static constexpr int kRing = 64; /* event pairs around the most recent evaluation-kernel launches */
@@ -114,6 +115,7 @@ struct mcq_ctx {
         DevBuf prefix;
     } scratch[kScratch];
     uint64_t scratch_clock = 0;
+    size_t res_clean = 0; /* leading bytes of d_res known to be zero (host entries leave their rows zeroed again) */
     DevBuf d_q, d_res, d_draws, d_off, d_hands, d_win, d_wt, d_keys, d_ext, d_mt;
     PinBuf h_q, h_res, h_draws, h_off, h_misc;
 };
@@ -123,8 +125,9 @@ uint32_t mcq_tasks_of(const mcq_query &q);
 int mcq_validate_queries(const mcq_query *q, size_t n);
 /* prep + evaluation launch of n device-resident queries on stream s (asynchronous).  total_tasks = 0: unknown
  * (queries never seen by the host).  mt_seed32 (parity mode): the draws are not in d_draws yet -- the device parses
- * np.random.seed(*mt_seed32 + i)'s stream of query i into it first (mcq_mt.hpp). */
+ * np.random.seed(*mt_seed32 + i)'s stream of query i into it first (mcq_mt.hpp).  d_prefix_ready: the cost prefix
+ * has been computed by the host and the result rows are zero already -- no prep kernel (host entries). */
 int mcq_run_slice(mcq_ctx *c, int mode, const mcq_query *d_q, uint32_t n, mcq_result *d_res, uint64_t seed,
                   uint64_t first_qid, uint64_t total_tasks, const uint8_t *d_draws, const uint64_t *d_off, hipStream_t s,
                   bool timed, uint64_t max_tasks = 0, uint32_t part = 0, uint32_t n_parts = 1,
-                  const uint32_t *mt_seed32 = nullptr);
+                  const uint32_t *mt_seed32 = nullptr, const uint64_t *d_prefix_ready = nullptr);

@@ -44,9 +44,10 @@ namespace {
 
 /* grid/block for a launch whose total task count is known (host entry) or unknown (0) */
 void pick_geometry(const mcq_ctx *c, int mode, uint64_t total_tasks, uint32_t *grid, uint32_t *block,
-                   uint32_t *split = nullptr, uint64_t max_tasks = 0) {
+                   uint32_t *split = nullptr, uint64_t max_tasks = 0, uint32_t *work_wpb = nullptr) {
     const uint32_t full = (uint32_t)c->n_cu * (uint32_t)c->occ[mode];
     if (split) *split = 0;
+    if (work_wpb) *work_wpb = 0;
     if (total_tasks == 0) { *block = kBlock; *grid = full; return; }
     if (split) { /* small batches are cut finer, see mcq_pick_split */
         *split = mcq_pick_split(total_tasks, max_tasks ? max_tasks : total_tasks, (uint32_t)c->n_cu, c->split_max);
@@ -58,9 +59,13 @@ void pick_geometry(const mcq_ctx *c, int mode, uint64_t total_tasks, uint32_t *g
     if (wpb < 1) wpb = 1;
     if (wpb > kBlock / 64) wpb = kBlock / 64;
     const uint64_t blocks = (total_tasks + wpb - 1) / wpb;
-    if (wpb < 4) wpb = 4; /* at least 256 threads per block: idle waves only help to load the 97 KB table image */
-    *block = (uint32_t)(64 * wpb);
     *grid = (uint32_t)(blocks < (uint64_t)c->n_cu ? blocks : (wpb == kBlock / 64 ? full : (uint64_t)c->n_cu));
+    /* the block brings 97 KB of tables into LDS before anything else happens: more waves than take work shorten
+     * that (six 16-byte loads per lane with 16 waves, one round trip, instead of 24 with four) */
+    uint64_t launch = wpb < c->load_waves ? c->load_waves : wpb;
+    if (work_wpb && launch != wpb) *work_wpb = (uint32_t)wpb;
+    else launch = wpb < 4 ? 4 : wpb, wpb = launch;
+    *block = (uint32_t)(64 * launch);
 }
 
 /* is stream s being captured into a graph? (a failing query counts as "no") */
@@ -119,32 +124,41 @@ int scratch_for(mcq_ctx *c, hipStream_t s, size_t bytes, bool capturing, mcq_ctx
 
 int mcq_run_slice(mcq_ctx *c, int mode, const mcq_query *d_q, uint32_t n, mcq_result *d_res, uint64_t seed,
                   uint64_t first_qid, uint64_t total_tasks, const uint8_t *d_draws, const uint64_t *d_off, hipStream_t s,
-                  bool timed, uint64_t max_tasks, uint32_t part, uint32_t n_parts, const uint32_t *mt_seed32) {
+                  bool timed, uint64_t max_tasks, uint32_t part, uint32_t n_parts, const uint32_t *mt_seed32,
+                  const uint64_t *d_prefix_ready) {
     if (mode == MCQ_MODE_PHILOX && c->law == MCQ_LAW_UNIFORM) mode = MCQ_INTERNAL_MODE_UNIFORM;
     const bool capturing = stream_capturing(s);
     if (capturing) timed = false; /* events recorded inside a capture cannot be read back */
     mcq_ctx::Scratch *sc = nullptr;
-    int rc = scratch_for(c, s, ((size_t)n + 3) * sizeof(uint64_t), capturing, &sc);
-    if (rc) return rc;
-    uint64_t *d_prefix = (uint64_t *)sc->prefix.p;
-    HIP_TRY(mcq_launch_prep(d_q, n, d_res, d_prefix, part, n_parts, (uint32_t)c->n_cu, c->split_max, s));
-    uint32_t grid, block, split;
-    pick_geometry(c, mode, total_tasks, &grid, &block, &split, max_tasks);
+    const uint64_t *d_prefix = d_prefix_ready;
+    if (!d_prefix) {
+        int rc = scratch_for(c, s, ((size_t)n + 3) * sizeof(uint64_t), capturing, &sc);
+        if (rc) return rc;
+        d_prefix = (const uint64_t *)sc->prefix.p;
+        HIP_TRY(mcq_launch_prep(d_q, n, d_res, (uint64_t *)sc->prefix.p, part, n_parts, (uint32_t)c->n_cu, c->split_max, s));
+    }
+    uint32_t grid, block, split, work_wpb;
+    pick_geometry(c, mode, total_tasks, &grid, &block, &split, max_tasks, &work_wpb);
     /* queries in HBM (the host has not seen them): up to 1024 of them may be a small batch -- the prep kernel
      * decides the cut and the evaluation kernel reads it; more queries are at least as many tasks: never cut */
     if (total_tasks == 0 && n <= 1024u) split = MCQ_SPLIT_FROM_PREP;
+    /* timing: the events take the evaluation kernel's own begin / end timestamps (no marker packets around a short
+     * kernel); in parity mode the timed region starts in front of the stream walk */
     const int slot = (int)(c->n_timed % mcq_ctx::kRing);
-    if (timed) HIP_TRY(hipEventRecord(c->ev0[slot], s));
-    if (mt_seed32) /* parity mode: the stream walk belongs to the timed region */
+    hipEvent_t t0 = timed ? c->ev0[slot] : nullptr, t1 = timed ? c->ev1[slot] : nullptr;
+    if (mt_seed32) {
+        if (timed) HIP_TRY(hipEventRecord(t0, s));
+        t0 = nullptr;
         HIP_TRY(mcq_launch_mt_parse(d_q, n, *mt_seed32, const_cast<uint8_t *>(d_draws), d_off, d_res,
-                                    reinterpret_cast<uint32_t *>(d_prefix + n + 2), (uint32_t)c->n_cu, s));
-    HIP_TRY(mcq_launch_eval(mode, d_q, n, d_prefix, d_res, seed, first_qid, c->d_luts, d_draws, d_off, grid, block, split,
-                            part, n_parts, s));
-    if (timed) {
-        HIP_TRY(hipEventRecord(c->ev1[slot], s));
-        c->n_timed++;
+                                    const_cast<uint32_t *>(reinterpret_cast<const uint32_t *>(d_prefix + n + 2)),
+                                    (uint32_t)c->n_cu, s));
     }
-    if (!capturing) {
+    HIP_TRY(mcq_launch_eval(mode, d_q, n, d_prefix, d_res, seed, first_qid, c->d_luts, d_draws, d_off, grid, block, split,
+                            part, n_parts, s, t0, t1, work_wpb));
+    if (timed) c->n_timed++;
+    /* a caller's stream may run on while another stream's call takes over the scratch: mark its last reader.  The
+     * context's own stream (slot 0) is synchronised by every host entry before it returns. */
+    if (sc && !capturing && sc != &c->scratch[0]) {
         HIP_TRY(hipEventRecord(sc->done, s));
         sc->done_recorded = true;
     }
@@ -294,6 +308,7 @@ int stage_queries(mcq_ctx *c, const mcq_query *q, size_t n, mcq_result *out, con
     HIP_TRY(c->h_res.reserve(n * sizeof(mcq_result)));
     HIP_TRY(c->d_q.reserve(n * sizeof(mcq_query)));
     HIP_TRY(c->d_res.reserve(n * sizeof(mcq_result)));
+    c->res_clean = 0; /* these entries zero their rows in the prep kernel and leave them filled */
     memcpy(c->h_q.p, q, n * sizeof(mcq_query));
     HIP_TRY(hipMemcpyAsync(c->d_q.p, c->h_q.p, n * sizeof(mcq_query), hipMemcpyHostToDevice, c->stream));
     c->last_ms = 0.f;
@@ -314,6 +329,7 @@ mcq_ctx *mcq_ctx_clone(const mcq_ctx *c) {
     if (d) {
         d->law = c->law;
         d->split_max = c->split_max;
+        d->load_waves = c->load_waves;
         d->replay_device_bytes = c->replay_device_bytes;
     }
     return d;
@@ -391,6 +407,10 @@ mcq_ctx *mcq_create(int device, int flags) {
         int v = atoi(e);
         c->split_max = (uint32_t)(v < 0 ? 0 : (v > 4 ? 4 : v));
     }
+    if (const char *e = getenv("MCQ_LOAD_WAVES")) { /* tuning knob, see pick_geometry */
+        const int v = atoi(e);
+        c->load_waves = (uint32_t)(v < 1 ? 1 : (v > 16 ? 16 : v));
+    }
     if (const char *e = getenv("MCQ_REPLAY_DEVICE_BYTES")) { /* chunking of the parity mode's draw buffer (tests) */
         const long long v = atoll(e);
         if (v > 0) c->replay_device_bytes = (uint64_t)v;
@@ -459,6 +479,60 @@ int mcq_eval_batch_device(mcq_ctx *c, const void *d_queries, size_t n, uint64_t 
     ABI_GUARD_END("mcq_eval_batch_device")
 }
 
+/* Production mode from host buffers.  The host has the queries in its hands, so it prices them itself: the cost
+ * prefix travels with the queries in ONE copy, the result rows are zero already (every call leaves them so), and
+ * the only kernel of the call is the evaluation kernel -- no prep launch on the path of the reference's own call
+ * pattern, thousands of 1000-run queries (gym_env/env.py:22,261-262).  `runs` (and nothing else) of a row is the
+ * host's to fill in. */
+static int eval_host_philox(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed, uint64_t first_query_id, uint32_t part,
+                            uint32_t n_parts, mcq_result *out, const char *who) {
+    if (!q || !out) return mcq_fail(MCQ_EINVAL, who, "null buffer");
+    if (n > 0x7fffffffu) return mcq_fail(MCQ_EINVAL, who, "n too large");
+    int rc = validate(q, n);
+    if (rc) return rc;
+    const size_t q_bytes = n * sizeof(mcq_query), p_bytes = (n + 3) * sizeof(uint64_t), r_bytes = n * sizeof(mcq_result);
+    HIP_TRY(c->h_q.reserve(q_bytes + p_bytes));
+    HIP_TRY(c->d_q.reserve(q_bytes + p_bytes));
+    HIP_TRY(c->h_res.reserve(r_bytes));
+    if (r_bytes > c->d_res.cap) c->res_clean = 0;
+    HIP_TRY(c->d_res.reserve(r_bytes));
+    memcpy(c->h_q.p, q, q_bytes);
+    uint64_t *prefix = reinterpret_cast<uint64_t *>(static_cast<char *>(c->h_q.p) + q_bytes);
+    uint64_t total_tasks = 0, max_tasks = 0, cost = 0, unsplit = 0;
+    for (size_t i = 0; i < n; i++) {
+        const McqQueryWords w = mcq_query_words(q[i]);
+        const McqPart pt = mcq_part(mcq_task_count(w), w.runs(), part, n_parts);
+        const uint64_t t = pt.t_hi - pt.t_lo;
+        prefix[i] = cost;
+        cost += t * mcq_task_weight(w);
+        total_tasks += t;
+        unsplit += tasks_of(q[i]);
+        if (t > max_tasks) max_tasks = t;
+    }
+    if (unsplit > 0xfffffff0ull) return mcq_fail(MCQ_EINVAL, who, "too many iterations in one call");
+    prefix[n] = cost;
+    prefix[n + 1] = 0;
+    prefix[n + 2] = 0;
+    HIP_TRY(hipMemcpyAsync(c->d_q.p, c->h_q.p, q_bytes + p_bytes, hipMemcpyHostToDevice, c->stream));
+    if (c->res_clean < r_bytes) HIP_TRY(hipMemsetAsync(c->d_res.p, 0, r_bytes, c->stream));
+    c->res_clean = 0; /* dirty until this call has put its rows back to zero */
+    c->last_ms = 0.f;
+    if (total_tasks) {
+        rc = mcq_run_slice(c, MCQ_MODE_PHILOX, (const mcq_query *)c->d_q.p, (uint32_t)n, (mcq_result *)c->d_res.p, seed,
+                           first_query_id, total_tasks, nullptr, nullptr, c->stream, true, max_tasks, part, n_parts, nullptr,
+                           reinterpret_cast<const uint64_t *>(static_cast<const char *>(c->d_q.p) + q_bytes));
+        if (rc) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(c->h_res.p, c->d_res.p, r_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_res.p, 0, r_bytes, c->stream)); /* not waited for: the next call finds its rows zero */
+    c->res_clean = r_bytes;
+    if (!total_tasks || mcq_kernel_times(c, &c->last_ms, 1) != 1) c->last_ms = 0.f;
+    memcpy(out, c->h_res.p, r_bytes);
+    for (size_t i = 0; i < n; i++) out[i].runs = mcq_part(tasks_of(q[i]), q[i].runs, part, n_parts).runs;
+    return MCQ_OK;
+}
+
 static int eval_batch_impl(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed, uint64_t first_query_id, int mode,
                            uint32_t part, uint32_t n_parts, mcq_result *out, const char *who) {
     if (mode != MCQ_MODE_PHILOX && mode != MCQ_MODE_REPLAY_MT19937) return mcq_fail(MCQ_EINVAL, who, "bad mode");
@@ -469,28 +543,9 @@ static int eval_batch_impl(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t se
     if (!c) return mcq_fail(MCQ_EINVAL, who, "null context");
     McqDeviceScope dev_(c->device);
     HIP_TRY(dev_.err);
+    if (mode == MCQ_MODE_PHILOX) return eval_host_philox(c, q, n, seed, first_query_id, part, n_parts, out, who);
     int rc = stage_queries(c, q, n, out, who);
     if (rc) return rc;
-    uint64_t total_tasks = 0, max_tasks = 0;
-    for (size_t i = 0; i < n; i++) {
-        const McqPart pt = mcq_part(tasks_of(q[i]), q[i].runs, part, n_parts);
-        const uint64_t t = pt.t_hi - pt.t_lo;
-        total_tasks += t;
-        if (t > max_tasks) max_tasks = t;
-    }
-
-    if (mode == MCQ_MODE_PHILOX) {
-        if (total_tasks == 0) total_tasks = 1; /* 0 means "unknown" to pick_geometry */
-        rc = mcq_run_slice(c, mode, (const mcq_query *)c->d_q.p, (uint32_t)n, (mcq_result *)c->d_res.p, seed,
-                       first_query_id, total_tasks, nullptr, nullptr, c->stream, true, max_tasks, part, n_parts);
-        if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(c->h_res.p, c->d_res.p, n * sizeof(mcq_result), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        if (mcq_kernel_times(c, &c->last_ms, 1) != 1) c->last_ms = 0.f;
-        memcpy(out, c->h_res.p, n * sizeof(mcq_result));
-        return MCQ_OK;
-    }
-
     return replay_batch(c, q, n, seed, first_query_id, nullptr, out);
 }
 
@@ -540,6 +595,7 @@ int mcq_eval_batch_ext(mcq_ctx *c, const mcq_query *q, const mcq_query_ext *ext,
     HIP_TRY(c->d_q.reserve(n * sizeof(mcq_query)));
     HIP_TRY(c->d_ext.reserve(n * sizeof(mcq_query_ext)));
     HIP_TRY(c->d_res.reserve(n * sizeof(mcq_result)));
+    c->res_clean = 0;
     HIP_TRY(c->scratch[0].prefix.reserve((n + 3) * sizeof(uint64_t)));
     uint8_t *hq = (uint8_t *)c->h_q.p;
     memcpy(hq, q, n * sizeof(mcq_query));
@@ -684,6 +740,7 @@ int mcq_exact_batch(mcq_ctx *c, const mcq_query *q, size_t n, int law, mcq_resul
     McqDeviceScope dev_(c->device);
     HIP_TRY(dev_.err);
     HIP_TRY(c->d_res.reserve(n * sizeof(mcq_result)));
+    c->res_clean = 0;
     HIP_TRY(c->h_res.reserve(n * sizeof(mcq_result)));
     HIP_TRY(hipMemsetAsync(c->d_res.p, 0, n * sizeof(mcq_result), c->stream));
     for (size_t i = 0; i < n; i++)

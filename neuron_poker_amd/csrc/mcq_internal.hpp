@@ -14,7 +14,7 @@ hipError_t mcq_launch_prep(const mcq_query *d_q, uint32_t n, mcq_result *d_res, 
 hipError_t mcq_launch_eval(int mode, const mcq_query *d_q, uint32_t n, const uint64_t *d_prefix, mcq_result *d_res,
                            uint64_t seed, uint64_t first_qid, const McqTables *d_luts, const uint8_t *d_draws,
                            const uint64_t *d_draw_off, uint32_t grid, uint32_t block, uint32_t split, uint32_t part,
-                           uint32_t n_parts, hipStream_t s);
+                           uint32_t n_parts, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr, uint32_t work_wpb = 0);
 /* exact enumeration of ONE query (host pointer q; n_players <= 3): adds into the zeroed row d_row */
 hipError_t mcq_launch_exact(const mcq_query *q, int law, mcq_result *d_row, const McqTables *d_luts, uint32_t n_cu,
                             hipStream_t s);

@@ -12,6 +12,7 @@
 // Memory: 16 B in / 104 B out per QUERY; per iteration nothing touches HBM in production mode (parity mode
 // reads <= 23 draw bytes).  LDS holds the lookup tables (97 KB per block; the flush table is read from global memory) and one 64-entry base deck per wave.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include "mcq_device.hpp"
 #include "mcq_exact.hpp"
@@ -53,6 +54,31 @@ __device__ __forceinline__ void load_tables(LdsTablesEval &dst, const McqTables 
     __syncthreads();
 }
 
+// Exclusive prefix sum of one 64-bit value per thread over a 1024-thread block (two barriers): wave-level scan by
+// shuffles, the 16 wave totals through LDS.  Returns the sum of the values of all lower threads; *total = block sum.
+__device__ __forceinline__ uint64_t block_exclusive_scan_1024(uint64_t v, uint64_t *wave_tot /* LDS, 16 entries */,
+                                                               uint64_t *total) {
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    uint64_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint64_t o = __shfl_up((unsigned long long)inc, off, 64);
+        if (lane >= (uint32_t)off) inc += o;
+    }
+    __syncthreads(); /* wave_tot may still be read from the previous call */
+    if (lane == 63u) wave_tot[wv] = inc;
+    __syncthreads();
+    uint64_t before = 0, all = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) {
+        const uint64_t t = wave_tot[k];
+        before += k < wv ? t : 0ull;
+        all += t;
+    }
+    *total = all;
+    return before + inc - v;
+}
+
 // ---------------------------------------------------------------------------------------------- prep
 // One block.  Validates every query, zeroes its result row and builds the exclusive prefix of the queries'
 // scheduling cost (tasks x weight; prefix[n] = total).  Invalid queries cost nothing and get runs = 0,
@@ -61,13 +87,12 @@ __global__ __launch_bounds__(1024) void mcq_prep_kernel(const mcq_query *__restr
                                                         mcq_result *__restrict__ res, uint64_t *__restrict__ prefix,
                                                         uint32_t part_idx, uint32_t n_parts, uint32_t n_cu,
                                                         uint32_t split_max) {
-    __shared__ uint64_t part[1024];
-    __shared__ uint64_t carry;
+    __shared__ uint64_t wave_tot[16];
+    uint64_t carry = 0; /* every thread keeps the running total */
     __shared__ unsigned long long sum_tasks;
     __shared__ uint32_t max_tasks;
     const uint32_t tid = threadIdx.x;
     if (tid == 0) {
-        carry = 0;
         sum_tasks = 0;
         max_tasks = 0;
     }
@@ -104,19 +129,12 @@ __global__ __launch_bounds__(1024) void mcq_prep_kernel(const mcq_query *__restr
                 atomicMax(&max_tasks, wm);
             }
         }
-        part[tid] = cost;
-        __syncthreads();
-        for (uint32_t off = 1; off < 1024; off <<= 1) { /* Hillis-Steele inclusive scan */
-            uint64_t v = tid >= off ? part[tid - off] : 0ull;
-            __syncthreads();
-            part[tid] += v;
-            __syncthreads();
-        }
-        if (i < n) prefix[i] = carry + part[tid] - cost;
-        __syncthreads();
-        if (tid == 1023) carry += part[1023];
-        __syncthreads();
+        uint64_t chunk_total;
+        const uint64_t before = block_exclusive_scan_1024(cost, wave_tot, &chunk_total);
+        if (i < n) prefix[i] = carry + before;
+        carry += chunk_total;
     }
+    __syncthreads(); /* sum_tasks / max_tasks are complete */
     if (tid == 0) {
         prefix[n] = carry;
         /* the cut for MCQ_SPLIT_FROM_PREP launches (queries resident in HBM, at most 1024 of them) */
@@ -229,7 +247,7 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
                                                              uint64_t first_qid, const McqTables *__restrict__ g_tab,
                                                              const uint8_t *__restrict__ draws,
                                                              const uint64_t *__restrict__ draw_off, uint32_t split_arg,
-                                                             uint32_t part, uint32_t n_parts) {
+                                                             uint32_t part, uint32_t n_parts, uint32_t work_wpb) {
     /* SPLIT = false: the bulk path, compiled without the cut */
     const uint32_t split = !SPLIT ? 0u
                            : split_arg == MCQ_SPLIT_FROM_PREP ? (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)prefix[n + 1])
@@ -242,7 +260,9 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
     load_tables(tab, g_tab);
 
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t waves_per_block = blockDim.x >> 6;
+    /* small batches launch more waves than take work: the extra ones only help to bring the 97 KB table image in */
+    const uint32_t waves_per_block = work_wpb ? work_wpb : blockDim.x >> 6;
+    if ((threadIdx.x >> 6) >= waves_per_block) return;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * waves_per_block + (threadIdx.x >> 6));
     const uint64_t n_waves = (uint64_t)gridDim.x * waves_per_block;
     const uint32_t chunk = MCQ_STREAM_ITERS >> split, sub_mask = (1u << split) - 1u;
@@ -333,11 +353,9 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
 __global__ __launch_bounds__(1024) void mcq_prep_ext_kernel(const mcq_query *__restrict__ q,
                                                             const mcq_query_ext *__restrict__ ext, uint32_t n,
                                                             mcq_result *__restrict__ res, uint64_t *__restrict__ prefix) {
-    __shared__ uint64_t part[1024];
-    __shared__ uint64_t carry;
+    __shared__ uint64_t wave_tot[16];
+    uint64_t carry = 0;
     const uint32_t tid = threadIdx.x;
-    if (tid == 0) carry = 0;
-    __syncthreads();
     for (uint32_t base = 0; base < n; base += 1024) {
         uint32_t i = base + tid;
         uint64_t cost = 0;
@@ -355,18 +373,10 @@ __global__ __launch_bounds__(1024) void mcq_prep_ext_kernel(const mcq_query *__r
 #pragma unroll
             for (int k = 2; k < 13; k++) r[k] = 0;
         }
-        part[tid] = cost;
-        __syncthreads();
-        for (uint32_t off = 1; off < 1024; off <<= 1) {
-            uint64_t v = tid >= off ? part[tid - off] : 0ull;
-            __syncthreads();
-            part[tid] += v;
-            __syncthreads();
-        }
-        if (i < n) prefix[i] = carry + part[tid] - cost;
-        __syncthreads();
-        if (tid == 1023) carry += part[1023];
-        __syncthreads();
+        uint64_t chunk_total;
+        const uint64_t before = block_exclusive_scan_1024(cost, wave_tot, &chunk_total);
+        if (i < n) prefix[i] = carry + before;
+        carry += chunk_total;
     }
     if (tid == 0) prefix[n] = carry;
 }
@@ -586,19 +596,21 @@ hipError_t mcq_launch_prep(const mcq_query *d_q, uint32_t n, mcq_result *d_res, 
     return hipGetLastError();
 }
 
+/* t0 / t1 (either may be null): events that take the kernel's own begin / end timestamps (hipExtLaunchKernel: read
+ * from the dispatch packet's completion signal -- no marker packets in the queue around a short kernel) */
 hipError_t mcq_launch_eval(int mode, const mcq_query *d_q, uint32_t n, const uint64_t *d_prefix, mcq_result *d_res,
                            uint64_t seed, uint64_t first_qid, const McqTables *d_luts, const uint8_t *d_draws,
                            const uint64_t *d_draw_off, uint32_t grid, uint32_t block, uint32_t split, uint32_t part,
-                           uint32_t n_parts, hipStream_t s) {
+                           uint32_t n_parts, hipStream_t s, hipEvent_t t0, hipEvent_t t1, uint32_t work_wpb) {
     if ((split > 4 && split != MCQ_SPLIT_FROM_PREP) || n_parts == 0 || part >= n_parts) return hipErrorInvalidValue;
-#define MCQ_LAUNCH_EVAL(M)                                                                                        \
-    do {                                                                                                          \
-        if (split)                                                                                                \
-            hipLaunchKernelGGL((mcq_eval_kernel<M, true>), dim3(grid), dim3(block), 0, s, d_q, n, d_prefix, d_res, \
-                               seed, first_qid, d_luts, d_draws, d_draw_off, split, part, n_parts);               \
-        else                                                                                                      \
-            hipLaunchKernelGGL((mcq_eval_kernel<M, false>), dim3(grid), dim3(block), 0, s, d_q, n, d_prefix, d_res, \
-                               seed, first_qid, d_luts, d_draws, d_draw_off, 0u, part, n_parts);                  \
+#define MCQ_LAUNCH_EVAL(M)                                                                                          \
+    do {                                                                                                            \
+        if (split)                                                                                                  \
+            hipExtLaunchKernelGGL((mcq_eval_kernel<M, true>), dim3(grid), dim3(block), 0, s, t0, t1, 0, d_q, n,     \
+                                  d_prefix, d_res, seed, first_qid, d_luts, d_draws, d_draw_off, split, part, n_parts, work_wpb); \
+        else                                                                                                        \
+            hipExtLaunchKernelGGL((mcq_eval_kernel<M, false>), dim3(grid), dim3(block), 0, s, t0, t1, 0, d_q, n,    \
+                                  d_prefix, d_res, seed, first_qid, d_luts, d_draws, d_draw_off, 0u, part, n_parts, work_wpb); \
     } while (0)
     if (mode == MCQ_MODE_PHILOX) MCQ_LAUNCH_EVAL(MCQ_MODE_PHILOX);
     else if (mode == MCQ_INTERNAL_MODE_UNIFORM) MCQ_LAUNCH_EVAL(MCQ_INTERNAL_MODE_UNIFORM);
