@@ -70,15 +70,24 @@ struct DevBuf {
 
 struct PinBuf {
     void *p = nullptr;
+    void *dev = nullptr; /* the same memory as the device sees it (pinned host memory is device-visible) */
     size_t cap = 0;
     hipError_t reserve(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
         if (p) (void)hipHostFree(p);
         p = nullptr;
+        dev = nullptr;
         cap = 0;
         size_t want = bytes + bytes / 4 + 256;
         hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
-        if (e == hipSuccess) cap = want;
+        if (e != hipSuccess) return e;
+        e = hipHostGetDevicePointer(&dev, p, 0);
+        if (e != hipSuccess) {
+            (void)hipHostFree(p);
+            p = nullptr;
+            return e;
+        }
+        cap = want;
         return e;
     }
     void release() {
@@ -94,6 +103,7 @@ struct mcq_ctx {
     int occ[3] = {1, 1, 1}; /* resident kBlock-thread blocks per CU of the eval kernels (by internal mode) */
     int law = MCQ_LAW_REFERENCE;
     uint64_t replay_device_bytes = 4ull << 30; /* parity mode: draw bytes per launch (MCQ_REPLAY_DEVICE_BYTES) */
+    uint32_t direct_max_tasks = 8; /* queries of at most this many 1024-iteration tasks take the one-launch path (MCQ_DIRECT_MAX_TASKS, 0 = never) */
     uint32_t load_waves = 16; /* waves per block that load the table image when fewer take work (MCQ_LOAD_WAVES) */
     uint32_t split_max = 4; /* finest cut of a task for small batches: 16 >> split_max iterations per lane */
     hipStream_t stream = nullptr;

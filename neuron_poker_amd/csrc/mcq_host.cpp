@@ -330,6 +330,7 @@ mcq_ctx *mcq_ctx_clone(const mcq_ctx *c) {
         d->law = c->law;
         d->split_max = c->split_max;
         d->load_waves = c->load_waves;
+        d->direct_max_tasks = c->direct_max_tasks;
         d->replay_device_bytes = c->replay_device_bytes;
     }
     return d;
@@ -406,6 +407,10 @@ mcq_ctx *mcq_create(int device, int flags) {
     if (const char *e = getenv("MCQ_SPLIT_MAX")) { /* tuning knob, see pick_geometry */
         int v = atoi(e);
         c->split_max = (uint32_t)(v < 0 ? 0 : (v > 4 ? 4 : v));
+    }
+    if (const char *e = getenv("MCQ_DIRECT_MAX_TASKS")) { /* tuning knob, see eval_host_philox */
+        const int v = atoi(e);
+        c->direct_max_tasks = (uint32_t)(v < 0 ? 0 : v);
     }
     if (const char *e = getenv("MCQ_LOAD_WAVES")) { /* tuning knob, see pick_geometry */
         const int v = atoi(e);
@@ -510,6 +515,26 @@ static int eval_host_philox(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t s
         if (t > max_tasks) max_tasks = t;
     }
     if (unsplit > 0xfffffff0ull) return mcq_fail(MCQ_EINVAL, who, "too many iterations in one call");
+    if (n_parts == 1 && max_tasks <= c->direct_max_tasks && total_tasks > 0) {
+        /* Small queries -- the reference's call pattern: ONE launch.  The kernel reads the records from this pinned
+         * buffer and stores finished rows into the pinned result buffer (mcq_eval_direct_kernel); about 4 waves per
+         * SIMD by giving every query 2^split waves of a block. */
+        const uint32_t mode = c->law == MCQ_LAW_UNIFORM ? MCQ_INTERNAL_MODE_UNIFORM : MCQ_MODE_PHILOX;
+        const uint64_t want_waves = 16ull * (uint64_t)c->n_cu;
+        uint32_t split = 0;
+        while (split < c->split_max && ((uint64_t)n << (split + 1u)) <= want_waves) split++;
+        const uint64_t slots = 16u >> split, blocks = (n + slots - 1) / slots;
+        const uint32_t grid = (uint32_t)(blocks < (uint64_t)c->n_cu ? blocks : (uint64_t)c->n_cu);
+        const int slot = (int)(c->n_timed % mcq_ctx::kRing);
+        c->last_ms = 0.f;
+        HIP_TRY(mcq_launch_eval_direct((int)mode, (const mcq_query *)c->h_q.dev, (uint32_t)n, (mcq_result *)c->h_res.dev, seed,
+                                       first_query_id, c->d_luts, grid, split, c->stream, c->ev0[slot], c->ev1[slot]));
+        c->n_timed++;
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (mcq_kernel_times(c, &c->last_ms, 1) != 1) c->last_ms = 0.f;
+        memcpy(out, c->h_res.p, r_bytes);
+        return MCQ_OK;
+    }
     prefix[n] = cost;
     prefix[n + 1] = 0;
     prefix[n + 2] = 0;

@@ -217,6 +217,24 @@ struct WaveTally { /* per-lane running sums of the current (wave, query) pair */
         passes += a.passes;
         dirty = true;
     }
+    /* lanes -> wave: lane k < 12 returns word k + 1 of the result row (passes, win, tie, by_type[9]) */
+    __device__ __forceinline__ unsigned long long row_words(uint32_t lane) {
+        uint32_t wins = 0;
+        unsigned long long mine = 0;
+#pragma unroll
+        for (uint32_t c = 0; c < MCQ_N_CODES; c++) {
+            if (c == 5) continue;
+            const uint32_t v = wave_sum(code[c]);
+            wins += v;
+            if (lane == 3u + mcq_code_to_type(c)) mine = v;
+        }
+        const uint32_t ties = wave_sum(tie);
+        const uint32_t pass = wave_sum(passes);
+        if (lane == 0) mine = pass;
+        if (lane == 1) mine = wins - ties;
+        if (lane == 2) mine = ties;
+        return mine;
+    }
     /* lanes -> wave (shuffles) -> one 64-bit atomic per counter */
     __device__ __forceinline__ void flush(mcq_result *row, uint32_t lane) {
         if (!dirty) return;
@@ -345,6 +363,88 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
         task++;
     }
     if (qi < n) tally.flush(res + qi, lane);
+}
+
+// ---------------------------------------------------------------------------------------------- eval, small queries
+// The reference's own call pattern is thousands of SMALL queries (1000 runs each, gym_env/env.py:22,261-262).  For
+// those the cost of a call is not the arithmetic but the launches and copies around it, so this kernel needs
+// nothing else: it reads the query records straight from the caller's (pinned, device-visible) memory, every query
+// is owned by ONE block -- 2^split waves take the 2^split cuts of each of its 1024-iteration tasks -- the waves'
+// sums meet in LDS and one wave stores the finished 104-byte row straight into the caller's memory.  No prep
+// kernel, no atomics in HBM, no zeroing, no copy kernels.  Iterations, random numbers and hence tallies are those
+// of mcq_eval_kernel (same streams, same cut arithmetic).
+template <int MODE>
+__global__ __launch_bounds__(kMaxBlock) void mcq_eval_direct_kernel(const mcq_query *__restrict__ queries, uint32_t n,
+                                                                    mcq_result *__restrict__ res, uint64_t seed,
+                                                                    uint64_t first_qid, const McqTables *__restrict__ g_tab,
+                                                                    uint32_t split) {
+    __shared__ __attribute__((aligned(16))) LdsTablesEval tab;
+    __shared__ McqCard base_tab[kMaxBlock];
+    __shared__ unsigned long long partial[2][kMaxBlock / 64][12]; /* [round parity][wave][passes, win, tie, by_type[9]] */
+    load_tables(tab, g_tab);
+
+    const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
+    const uint32_t wpq = 1u << split, slots = (kMaxBlock / 64u) >> split; /* waves per query, queries per block and round */
+    const uint32_t slot = wib >> split, sub = wib & (wpq - 1u);
+    const uint32_t chunk = MCQ_STREAM_ITERS >> split;
+    const uint32_t per_round = gridDim.x * slots;
+    const uint32_t rounds = (n + per_round - 1u) / per_round; /* the same for every wave: the block meets once per round */
+    McqCard *base = base_tab + (threadIdx.x & ~63u);
+    for (uint32_t round = 0; round < rounds; round++) {
+        const uint32_t qi = __builtin_amdgcn_readfirstlane(round * per_round + blockIdx.x * slots + slot);
+        unsigned long long mine = 0; /* lane k < 12: word k + 1 of the row */
+        uint32_t runs = 0;
+        if (qi < n) {
+            const uint4 raw = reinterpret_cast<const uint4 *>(queries)[qi];
+            const McqQueryWords q = {(uint32_t)__builtin_amdgcn_readfirstlane(raw.x), (uint32_t)__builtin_amdgcn_readfirstlane(raw.y),
+                                     (uint32_t)__builtin_amdgcn_readfirstlane(raw.z), (uint32_t)__builtin_amdgcn_readfirstlane(raw.w)};
+            McqQueryCtx qc;
+            mcq_query_ctx(q, qc);
+            runs = qc.runs;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); /* the previous query's lookups are done */
+            base[lane] = mcq_base_entry(qc, lane, tab.sel8);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            WaveTally tally;
+            tally.clear();
+            const uint32_t tasks = mcq_task_count(q);
+            for (uint32_t task = 0; task < tasks; task++) {
+                McqLaneAcc acc = {0, 0, 0};
+                const uint32_t stream = task * MCQ_WAVE + lane;
+                const uint64_t it0 = (uint64_t)stream * MCQ_STREAM_ITERS + sub * chunk;
+                if (it0 < qc.runs) {
+                    McqCtrDrawsT<MODE == MCQ_INTERNAL_MODE_UNIFORM> dr;
+                    dr.w = 0;
+                    dr.rng.seed(seed, first_qid + qi, stream);
+                    for (uint32_t k = sub * chunk * (qc.n_opp + ((qc.n_deal + 1u) >> 1)); k != 0; k--) dr.rng.next();
+                    const uint32_t cnt = (uint32_t)min((uint64_t)chunk, (uint64_t)qc.runs - it0);
+                    for (uint32_t j = 0; j < cnt; j++) mcq_iteration(qc, dr, base - 128, g_tab->tf, tab.tops, tab.sd, acc);
+                    acc.passes = cnt * qc.n_opp;
+                }
+                tally.add(acc);
+            }
+            mine = tally.row_words(lane);
+        }
+        /* Row word w = min(lane, 12): lanes 13..63 repeat lane 12's store (same address, same value) so that no
+         * branch on the lane number stands in front of the loop's back edge -- the wave stays whole for the
+         * cross-lane steps of the next round. */
+        const uint32_t w = lane < 12u ? lane : 12u;
+        if (wpq == 1u) { /* the wave owns the query: its sums are the row */
+            const unsigned long long word = w == 0u ? (unsigned long long)runs : __shfl(mine, (int)w - 1, 64);
+            if (qi < n) reinterpret_cast<unsigned long long *>(res + qi)[w] = word;
+            continue;
+        }
+        if (lane < 12u) partial[round & 1u][wib][lane] = mine;
+        __syncthreads(); /* every wave of the block, every round; two buffers: a wave may run one round ahead */
+        if (sub == 0u && qi < n) {
+            unsigned long long v = runs;
+            if (w > 0u) {
+                v = 0;
+                for (uint32_t k = 0; k < wpq; k++) v += partial[round & 1u][wib + k][w - 1u];
+            }
+            reinterpret_cast<unsigned long long *>(res + qi)[w] = v;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- extended queries
@@ -616,6 +716,19 @@ hipError_t mcq_launch_eval(int mode, const mcq_query *d_q, uint32_t n, const uin
     else if (mode == MCQ_INTERNAL_MODE_UNIFORM) MCQ_LAUNCH_EVAL(MCQ_INTERNAL_MODE_UNIFORM);
     else MCQ_LAUNCH_EVAL(MCQ_MODE_REPLAY_MT19937);
 #undef MCQ_LAUNCH_EVAL
+    return hipGetLastError();
+}
+
+hipError_t mcq_launch_eval_direct(int mode, const mcq_query *q, uint32_t n, mcq_result *res, uint64_t seed, uint64_t first_qid,
+                                  const McqTables *d_luts, uint32_t grid, uint32_t split, hipStream_t s, hipEvent_t t0,
+                                  hipEvent_t t1) {
+    if (split > 4 || grid == 0) return hipErrorInvalidValue;
+    if (mode == MCQ_INTERNAL_MODE_UNIFORM)
+        hipExtLaunchKernelGGL((mcq_eval_direct_kernel<MCQ_INTERNAL_MODE_UNIFORM>), dim3(grid), dim3(kMaxBlock), 0, s, t0, t1, 0, q,
+                              n, res, seed, first_qid, d_luts, split);
+    else
+        hipExtLaunchKernelGGL((mcq_eval_direct_kernel<MCQ_MODE_PHILOX>), dim3(grid), dim3(kMaxBlock), 0, s, t0, t1, 0, q, n, res,
+                              seed, first_qid, d_luts, split);
     return hipGetLastError();
 }
 

@@ -549,6 +549,50 @@ def test_small_batch_task_split_does_not_change_tallies():
             os.environ["MCQ_SPLIT_MAX"] = old
 
 
+def test_one_launch_path_for_small_queries_equals_the_general_path(monkeypatch):
+    """Host entries send batches of small queries (the reference's pattern: 1000 runs each) through ONE launch
+    (mcq_eval_direct_kernel: records read from and rows stored to pinned host memory, a query per block slot, no
+    atomics).  Whatever the number of waves per query -- it follows the batch size -- the tallies are those of the
+    general path (prep + sliced kernel + atomics) and of the oracle; both dealing laws; ragged runs and players."""
+    g = np.random.default_rng(4242)
+
+    def batch(n):
+        hole, board, npl = [], [], []
+        for i in range(n):
+            nb = [0, 3, 4, 5][i % 4]
+            c = g.permutation(52)[:2 + nb]
+            hole.append(c[:2])
+            board.append(list(c[2:]) + [255] * (5 - nb))
+            npl.append(1 + (i * 7) % 10)
+        runs = g.choice([1, 15, 16, 17, 64, 999, 1000, 1024, 1025, 3000, 8192], n)
+        return npa.pack_queries(hole, board, npl, runs)
+
+    monkeypatch.setenv("MCQ_DIRECT_MAX_TASKS", "0")
+    general = npa.Engine(0)
+    monkeypatch.setenv("MCQ_DIRECT_MAX_TASKS", "8")
+    direct = npa.Engine(0)
+    try:
+        for n in (1, 2, 3, 100, 257, 1000, 5000):      # 16, 16, 16, 16, 8, 4, 1 waves per query
+            q = batch(n)
+            want = u64(general.eval_batch(q, seed=77, first_query_id=9))
+            got = u64(direct.eval_batch(q, seed=77, first_query_id=9))
+            assert np.array_equal(got, want), n
+            if n <= 257:
+                assert np.array_equal(want, O.run_batch(O.MODE_CTR, q.view(np.uint8).reshape(-1, 16), 77, first_qid=9, threads=8))
+            assert direct.last_kernel_ms > 0
+        q = batch(300)
+        for e in (general, direct):
+            e.set_dealing_law("uniform")
+        assert np.array_equal(u64(direct.eval_batch(q, seed=5)), u64(general.eval_batch(q, seed=5)))
+        for e in (general, direct):
+            e.set_dealing_law("reference")
+        q["runs"][7] = 9000     # nine tasks: the whole batch takes the general path again
+        assert np.array_equal(u64(direct.eval_batch(q, seed=5)), u64(general.eval_batch(q, seed=5)))
+    finally:
+        general.close()
+        direct.close()
+
+
 # ---- exact enumeration on the GPU (mcq_exact_batch, SURVEY 8f-3)
 def _xq(hero, board, n):
     b = [O.card_id(c) for c in board]
