@@ -430,8 +430,8 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_direct_kernel(const mcq_qu
          * cross-lane steps of the next round. */
         const uint32_t w = lane < 12u ? lane : 12u;
         if (wpq == 1u) { /* the wave owns the query: its sums are the row */
-            const unsigned long long word = w == 0u ? (unsigned long long)runs : __shfl(mine, (int)w - 1, 64);
-            if (qi < n) reinterpret_cast<unsigned long long *>(res + qi)[w] = word;
+            const unsigned long long up = __shfl(mine, (int)((w + 63u) & 63u), 64); /* every lane takes part in the exchange */
+            if (qi < n) reinterpret_cast<unsigned long long *>(res + qi)[w] = w == 0u ? (unsigned long long)runs : up;
             continue;
         }
         if (lane < 12u) partial[round & 1u][wib][lane] = mine;
