@@ -7,6 +7,7 @@
 #include <exception>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "../../include/mcq.h"
 
@@ -127,7 +128,11 @@ struct mcq_ctx {
     uint64_t scratch_clock = 0;
     size_t res_clean = 0; /* leading bytes of d_res known to be zero (host entries leave their rows zeroed again) */
     DevBuf d_q, d_res, d_draws, d_off, d_hands, d_win, d_wt, d_keys, d_ext, d_mt;
-    PinBuf h_q, h_res, h_draws, h_off, h_misc;
+    PinBuf h_q, h_res, h_draws, h_off, h_misc, h_flag;
+    DevBuf d_done;                /* block counter of the one-launch path */
+    uint32_t direct_ticket = 0;   /* value the kernel raises the flag in h_flag to */
+    bool direct_poll = true;      /* pick the rows up at the flag instead of synchronising the stream (MCQ_DIRECT_POLL) */
+    std::vector<uint8_t> direct_lg; /* scratch of the one-launch path's layout */
 };
 
 /* shared between the translation units (defined in mcq_host.cpp) */

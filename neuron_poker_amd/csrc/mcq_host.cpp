@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <chrono>
 #include <exception>
 #include <new>
 #include <string>
@@ -331,6 +332,7 @@ mcq_ctx *mcq_ctx_clone(const mcq_ctx *c) {
         d->split_max = c->split_max;
         d->load_waves = c->load_waves;
         d->direct_max_tasks = c->direct_max_tasks;
+        d->direct_poll = c->direct_poll;
         d->replay_device_bytes = c->replay_device_bytes;
     }
     return d;
@@ -360,7 +362,8 @@ void mcq_destroy(mcq_ctx *c) {
         if (sc.done) (void)hipEventDestroy(sc.done);
     }
     for (DevBuf *b : db) b->release();
-    PinBuf *pb[] = {&c->h_q, &c->h_res, &c->h_draws, &c->h_off, &c->h_misc};
+    PinBuf *pb[] = {&c->h_q, &c->h_res, &c->h_draws, &c->h_off, &c->h_misc, &c->h_flag};
+    c->d_done.release();
     for (PinBuf *b : pb) b->release();
     if (c->d_luts) (void)hipFree(c->d_luts);
     for (int i = 0; i < mcq_ctx::kRing; i++) {
@@ -412,6 +415,7 @@ mcq_ctx *mcq_create(int device, int flags) {
         const int v = atoi(e);
         c->direct_max_tasks = (uint32_t)(v < 0 ? 0 : v);
     }
+    if (const char *e = getenv("MCQ_DIRECT_POLL")) c->direct_poll = atoi(e) != 0;
     if (const char *e = getenv("MCQ_LOAD_WAVES")) { /* tuning knob, see pick_geometry */
         const int v = atoi(e);
         c->load_waves = (uint32_t)(v < 1 ? 1 : (v > 16 ? 16 : v));
@@ -447,6 +451,8 @@ int mcq_kernel_times(mcq_ctx *c, float *ms, int max_n) {
     int n = (int)(have < (uint64_t)max_n ? have : (uint64_t)max_n);
     McqDeviceScope dev_(c->device);
     HIP_TRY(dev_.err);
+    if (n > 0) /* the one-launch path returns when the rows are out, a moment before the kernel has retired */
+        HIP_TRY(hipEventSynchronize(c->ev1[(int)((c->n_timed - 1u) % mcq_ctx::kRing)]));
     for (int i = 0; i < n; i++) {
         int slot = (int)((c->n_timed - (uint64_t)n + (uint64_t)i) % mcq_ctx::kRing);
         HIP_TRY(hipEventElapsedTime(&ms[i], c->ev0[slot], c->ev1[slot]));
@@ -496,7 +502,10 @@ static int eval_host_philox(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t s
     int rc = validate(q, n);
     if (rc) return rc;
     const size_t q_bytes = n * sizeof(mcq_query), p_bytes = (n + 3) * sizeof(uint64_t), r_bytes = n * sizeof(mcq_result);
-    HIP_TRY(c->h_q.reserve(q_bytes + p_bytes));
+    /* behind the records: the cost prefix, then (one-launch path) the wave layout: at most n + 2 * 16 * n_cu waves,
+     * rounded up to whole rounds */
+    const size_t a_off = q_bytes + p_bytes, a_cap = (n + 48u * (size_t)c->n_cu + 64u) * sizeof(uint32_t);
+    HIP_TRY(c->h_q.reserve(a_off + a_cap));
     HIP_TRY(c->d_q.reserve(q_bytes + p_bytes));
     HIP_TRY(c->h_res.reserve(r_bytes));
     if (r_bytes > c->d_res.cap) c->res_clean = 0;
@@ -515,24 +524,83 @@ static int eval_host_philox(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t s
         if (t > max_tasks) max_tasks = t;
     }
     if (unsplit > 0xfffffff0ull) return mcq_fail(MCQ_EINVAL, who, "too many iterations in one call");
-    if (n_parts == 1 && max_tasks <= c->direct_max_tasks && total_tasks > 0) {
-        /* Small queries -- the reference's call pattern: ONE launch.  The kernel reads the records from this pinned
-         * buffer and stores finished rows into the pinned result buffer (mcq_eval_direct_kernel); about 4 waves per
-         * SIMD by giving every query 2^split waves of a block. */
+    if (n_parts == 1 && max_tasks <= c->direct_max_tasks && total_tasks > 0 && n < (1u << 24)) {
+        /* Small queries -- the reference's call pattern: ONE launch (mcq_eval_direct_kernel).  The kernel reads the
+         * records from this pinned buffer and stores finished rows into the pinned result buffer.  Layout of the work:
+         * about 16 waves per CU in all, every query a power-of-two number of them in proportion to its cost (so all
+         * waves carry about the same work), the waves of a query side by side in one block. */
         const uint32_t mode = c->law == MCQ_LAW_UNIFORM ? MCQ_INTERNAL_MODE_UNIFORM : MCQ_MODE_PHILOX;
         const uint64_t want_waves = 16ull * (uint64_t)c->n_cu;
-        uint32_t split = 0;
-        while (split < c->split_max && ((uint64_t)n << (split + 1u)) <= want_waves) split++;
-        const uint64_t slots = 16u >> split, blocks = (n + slots - 1) / slots;
+        std::vector<uint8_t> &lg = c->direct_lg;
+        lg.resize(n);
+        uint64_t waves = 0;
+        size_t count[5] = {0, 0, 0, 0, 0};
+        for (size_t i = 0; i < n; i++) {
+            const uint64_t ci = (i + 1 < n ? prefix[i + 1] : cost) - prefix[i];
+            uint32_t l = 0;
+            while (l < c->split_max && (2ull << l) * cost <= ci * want_waves) l++; /* 2^l <= share of the waves */
+            if (ci == 0) l = 0;
+            lg[i] = (uint8_t)l;
+            count[l]++;
+            waves += 1ull << l;
+        }
+        const uint64_t blocks = (waves + 15u) / 16u;
         const uint32_t grid = (uint32_t)(blocks < (uint64_t)c->n_cu ? blocks : (uint64_t)c->n_cu);
+        const uint32_t rounds = (uint32_t)((blocks + grid - 1) / grid);
+        const size_t a_words = (size_t)rounds * grid * 16u;
+        if (a_words * sizeof(uint32_t) > a_cap) return mcq_fail(MCQ_EDEVICE, who, "internal: wave layout larger than its bound");
+        uint32_t *assign = reinterpret_cast<uint32_t *>(static_cast<char *>(c->h_q.p) + a_off);
+        /* queries in descending order of their wave count fill the blocks without gaps (powers of two); block k runs
+         * in round k / grid on block k % grid */
+        size_t start[5], pos = 0;
+        for (int l = 4; l >= 0; l--) { start[l] = pos; pos += count[l] << l; }
+        for (size_t k = pos; k < a_words; k++) assign[k] = MCQ_DIRECT_IDLE;
+        for (size_t i = 0; i < n; i++) {
+            const uint32_t l = lg[i];
+            for (uint32_t sub = 0; sub < (1u << l); sub++) assign[start[l] + sub] = (uint32_t)i | (l << 24) | (sub << 28);
+            start[l] += 1u << l;
+        }
+        if (!c->h_flag.p) {
+            HIP_TRY(c->h_flag.reserve(64));
+            memset(c->h_flag.p, 0, 64);
+            HIP_TRY(c->d_done.reserve(64));
+            HIP_TRY(hipMemsetAsync(c->d_done.p, 0, 64, c->stream));
+        }
+        const uint32_t ticket = ++c->direct_ticket;
         const int slot = (int)(c->n_timed % mcq_ctx::kRing);
         c->last_ms = 0.f;
-        HIP_TRY(mcq_launch_eval_direct((int)mode, (const mcq_query *)c->h_q.dev, (uint32_t)n, (mcq_result *)c->h_res.dev, seed,
-                                       first_query_id, c->d_luts, grid, split, c->stream, c->ev0[slot], c->ev1[slot]));
+        static const bool trace = getenv("MCQ_TRACE") != nullptr; /* phase times of this path on stderr (tuning) */
+        const auto t0 = std::chrono::steady_clock::now();
+        HIP_TRY(mcq_launch_eval_direct((int)mode, (const mcq_query *)c->h_q.dev,
+                                       reinterpret_cast<const uint32_t *>(static_cast<const char *>(c->h_q.dev) + a_off), rounds,
+                                       count[0] != n ? 1u : 0u, (mcq_result *)c->h_res.dev, seed, first_query_id, c->d_luts, grid,
+                                       (uint32_t *)c->d_done.p, (uint32_t *)c->h_flag.dev, ticket, c->stream, c->ev0[slot],
+                                       c->ev1[slot]));
         c->n_timed++;
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        if (mcq_kernel_times(c, &c->last_ms, 1) != 1) c->last_ms = 0.f;
+        const auto t1 = std::chrono::steady_clock::now();
+        /* The last block raises a flag in pinned memory once every row is out: picking the rows up there saves the
+         * end-of-kernel handshake of a stream synchronisation (measured: 14 us of a 40 us call).  A kernel that has
+         * not answered after a few milliseconds is left to hipStreamSynchronize, which reports what went wrong. */
+        const volatile uint32_t *flag = static_cast<const volatile uint32_t *>(c->h_flag.p);
+        bool seen = false;
+        if (c->direct_poll) {
+            for (uint32_t spin = 0;; spin++) {
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == ticket) { seen = true; break; }
+                if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t1 > std::chrono::milliseconds(5)) break;
+                __builtin_ia32_pause();
+            }
+        }
+        if (!seen) HIP_TRY(hipStreamSynchronize(c->stream));
+        const auto t2 = std::chrono::steady_clock::now();
         memcpy(out, c->h_res.p, r_bytes);
+        if (trace) {
+            const auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+                return std::chrono::duration<double, std::micro>(b - a).count();
+            };
+            fprintf(stderr, "mcq direct n=%zu waves=%llu grid=%u rounds=%u: launch %.1f us, wait %.1f us (%s), copy out %.1f us\n", n,
+                    (unsigned long long)waves, grid, rounds, us(t0, t1), us(t1, t2), seen ? "flag" : "stream sync",
+                    us(t2, std::chrono::steady_clock::now()));
+        }
         return MCQ_OK;
     }
     prefix[n] = cost;

@@ -373,28 +373,34 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
 // sums meet in LDS and one wave stores the finished 104-byte row straight into the caller's memory.  No prep
 // kernel, no atomics in HBM, no zeroing, no copy kernels.  Iterations, random numbers and hence tallies are those
 // of mcq_eval_kernel (same streams, same cut arithmetic).
+// The host lays the work out (mcq_host.cpp, pack_direct): every query gets a power-of-two number of waves in
+// proportion to its cost, so that all waves carry about the same work, and the waves of a query sit side by side in
+// one block.  assign[(round * gridDim.x + block) * 16 + wave] = query index | log2(waves of the query) << 24 |
+// this wave's cut << 28, or MCQ_DIRECT_IDLE.  done[0] (device memory, zero before the launch, reset by the last
+// block) counts finished blocks; the last one raises done_flag (pinned host memory) to `ticket` after a system-scope
+// fence, which lets the host pick the rows up without waiting for the kernel's end-of-grid handshake.
 template <int MODE>
-__global__ __launch_bounds__(kMaxBlock) void mcq_eval_direct_kernel(const mcq_query *__restrict__ queries, uint32_t n,
-                                                                    mcq_result *__restrict__ res, uint64_t seed,
+__global__ __launch_bounds__(kMaxBlock) void mcq_eval_direct_kernel(const mcq_query *__restrict__ queries,
+                                                                    const uint32_t *__restrict__ assign, uint32_t rounds,
+                                                                    uint32_t merge, mcq_result *__restrict__ res, uint64_t seed,
                                                                     uint64_t first_qid, const McqTables *__restrict__ g_tab,
-                                                                    uint32_t split) {
+                                                                    uint32_t *__restrict__ done, volatile uint32_t *done_flag,
+                                                                    uint32_t ticket) {
     __shared__ __attribute__((aligned(16))) LdsTablesEval tab;
     __shared__ McqCard base_tab[kMaxBlock];
     __shared__ unsigned long long partial[2][kMaxBlock / 64][12]; /* [round parity][wave][passes, win, tie, by_type[9]] */
     load_tables(tab, g_tab);
 
     const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
-    const uint32_t wpq = 1u << split, slots = (kMaxBlock / 64u) >> split; /* waves per query, queries per block and round */
-    const uint32_t slot = wib >> split, sub = wib & (wpq - 1u);
-    const uint32_t chunk = MCQ_STREAM_ITERS >> split;
-    const uint32_t per_round = gridDim.x * slots;
-    const uint32_t rounds = (n + per_round - 1u) / per_round; /* the same for every wave: the block meets once per round */
     McqCard *base = base_tab + (threadIdx.x & ~63u);
     for (uint32_t round = 0; round < rounds; round++) {
-        const uint32_t qi = __builtin_amdgcn_readfirstlane(round * per_round + blockIdx.x * slots + slot);
+        const uint32_t a = __builtin_amdgcn_readfirstlane(assign[((size_t)round * gridDim.x + blockIdx.x) * (kMaxBlock / 64) + wib]);
+        const bool work = a != MCQ_DIRECT_IDLE;
+        const uint32_t qi = a & 0xFFFFFFu, split = (a >> 24) & 7u, sub = a >> 28, wpq = 1u << split;
+        const uint32_t chunk = MCQ_STREAM_ITERS >> split;
         unsigned long long mine = 0; /* lane k < 12: word k + 1 of the row */
         uint32_t runs = 0;
-        if (qi < n) {
+        if (work) {
             const uint4 raw = reinterpret_cast<const uint4 *>(queries)[qi];
             const McqQueryWords q = {(uint32_t)__builtin_amdgcn_readfirstlane(raw.x), (uint32_t)__builtin_amdgcn_readfirstlane(raw.y),
                                      (uint32_t)__builtin_amdgcn_readfirstlane(raw.z), (uint32_t)__builtin_amdgcn_readfirstlane(raw.w)};
@@ -429,20 +435,31 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_direct_kernel(const mcq_qu
          * branch on the lane number stands in front of the loop's back edge -- the wave stays whole for the
          * cross-lane steps of the next round. */
         const uint32_t w = lane < 12u ? lane : 12u;
-        if (wpq == 1u) { /* the wave owns the query: its sums are the row */
+        if (!merge) { /* no query of this launch has more than one wave: a wave's sums are the row */
             const unsigned long long up = __shfl(mine, (int)((w + 63u) & 63u), 64); /* every lane takes part in the exchange */
-            if (qi < n) reinterpret_cast<unsigned long long *>(res + qi)[w] = w == 0u ? (unsigned long long)runs : up;
+            if (work) reinterpret_cast<unsigned long long *>(res + qi)[w] = w == 0u ? (unsigned long long)runs : up;
             continue;
         }
         if (lane < 12u) partial[round & 1u][wib][lane] = mine;
         __syncthreads(); /* every wave of the block, every round; two buffers: a wave may run one round ahead */
-        if (sub == 0u && qi < n) {
+        if (work && sub == 0u) {
             unsigned long long v = runs;
             if (w > 0u) {
                 v = 0;
                 for (uint32_t k = 0; k < wpq; k++) v += partial[round & 1u][wib + k][w - 1u];
             }
             reinterpret_cast<unsigned long long *>(res + qi)[w] = v;
+        }
+    }
+    /* completion: rows first (system scope), then the count; the block that completes it tells the host */
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t prev = atomicAdd(done, 1u);
+        if (prev + 1u == gridDim.x) {
+            *done = 0; /* ready for the next launch on this stream */
+            __threadfence_system();
+            *done_flag = ticket;
         }
     }
 }
@@ -719,16 +736,17 @@ hipError_t mcq_launch_eval(int mode, const mcq_query *d_q, uint32_t n, const uin
     return hipGetLastError();
 }
 
-hipError_t mcq_launch_eval_direct(int mode, const mcq_query *q, uint32_t n, mcq_result *res, uint64_t seed, uint64_t first_qid,
-                                  const McqTables *d_luts, uint32_t grid, uint32_t split, hipStream_t s, hipEvent_t t0,
+hipError_t mcq_launch_eval_direct(int mode, const mcq_query *q, const uint32_t *assign, uint32_t rounds, uint32_t merge,
+                                  mcq_result *res, uint64_t seed, uint64_t first_qid, const McqTables *d_luts, uint32_t grid,
+                                  uint32_t *d_done, uint32_t *done_flag, uint32_t ticket, hipStream_t s, hipEvent_t t0,
                                   hipEvent_t t1) {
-    if (split > 4 || grid == 0) return hipErrorInvalidValue;
+    if (grid == 0 || rounds == 0) return hipErrorInvalidValue;
     if (mode == MCQ_INTERNAL_MODE_UNIFORM)
         hipExtLaunchKernelGGL((mcq_eval_direct_kernel<MCQ_INTERNAL_MODE_UNIFORM>), dim3(grid), dim3(kMaxBlock), 0, s, t0, t1, 0, q,
-                              n, res, seed, first_qid, d_luts, split);
+                              assign, rounds, merge, res, seed, first_qid, d_luts, d_done, done_flag, ticket);
     else
-        hipExtLaunchKernelGGL((mcq_eval_direct_kernel<MCQ_MODE_PHILOX>), dim3(grid), dim3(kMaxBlock), 0, s, t0, t1, 0, q, n, res,
-                              seed, first_qid, d_luts, split);
+        hipExtLaunchKernelGGL((mcq_eval_direct_kernel<MCQ_MODE_PHILOX>), dim3(grid), dim3(kMaxBlock), 0, s, t0, t1, 0, q, assign,
+                              rounds, merge, res, seed, first_qid, d_luts, d_done, done_flag, ticket);
     return hipGetLastError();
 }
 
