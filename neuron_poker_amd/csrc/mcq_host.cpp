@@ -502,9 +502,9 @@ static int eval_host_philox(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t s
     int rc = validate(q, n);
     if (rc) return rc;
     const size_t q_bytes = n * sizeof(mcq_query), p_bytes = (n + 3) * sizeof(uint64_t), r_bytes = n * sizeof(mcq_result);
-    /* behind the records: the cost prefix, then (one-launch path) the wave layout: at most n + 2 * 16 * n_cu waves,
-     * rounded up to whole rounds */
-    const size_t a_off = q_bytes + p_bytes, a_cap = (n + 48u * (size_t)c->n_cu + 64u) * sizeof(uint32_t);
+    /* behind the records: the cost prefix, then (one-launch path) the wave layout: at most n + 2 * 16 * n_cu waves, dealt
+     * to the blocks in whole rounds */
+    const size_t a_off = q_bytes + p_bytes, a_cap = (n + 96u * (size_t)c->n_cu + 64u) * sizeof(uint32_t);
     HIP_TRY(c->h_q.reserve(a_off + a_cap));
     HIP_TRY(c->d_q.reserve(q_bytes + p_bytes));
     HIP_TRY(c->h_res.reserve(r_bytes));
@@ -544,21 +544,27 @@ static int eval_host_philox(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t s
             count[l]++;
             waves += 1ull << l;
         }
-        const uint64_t blocks = (waves + 15u) / 16u;
-        const uint32_t grid = (uint32_t)(blocks < (uint64_t)c->n_cu ? blocks : (uint64_t)c->n_cu);
-        const uint32_t rounds = (uint32_t)((blocks + grid - 1) / grid);
+        /* Blocks: as many as there are CUs (or queries).  Queries in descending order of their wave count are dealt
+         * to the blocks in turn, so every block carries about the same number of waves; inside a block the groups
+         * stay in descending order, hence aligned to their size and never across a round's 16 waves. */
+        const uint32_t grid = (uint32_t)(n < (size_t)c->n_cu ? n : (size_t)c->n_cu);
+        const uint64_t per_block = (waves + grid - 1) / grid + 32u; /* bound: dealing in turn, one group per class at most */
+        const uint32_t rounds = (uint32_t)((per_block + 15u) / 16u);
         const size_t a_words = (size_t)rounds * grid * 16u;
         if (a_words * sizeof(uint32_t) > a_cap) return mcq_fail(MCQ_EDEVICE, who, "internal: wave layout larger than its bound");
         uint32_t *assign = reinterpret_cast<uint32_t *>(static_cast<char *>(c->h_q.p) + a_off);
-        /* queries in descending order of their wave count fill the blocks without gaps (powers of two); block k runs
-         * in round k / grid on block k % grid */
-        size_t start[5], pos = 0;
-        for (int l = 4; l >= 0; l--) { start[l] = pos; pos += count[l] << l; }
-        for (size_t k = pos; k < a_words; k++) assign[k] = MCQ_DIRECT_IDLE;
+        for (size_t k = 0; k < a_words; k++) assign[k] = MCQ_DIRECT_IDLE;
+        std::vector<uint32_t> &fill = c->direct_fill; /* waves placed in each block so far */
+        fill.assign(grid, 0u);
+        size_t order[5], dealt = 0;
+        for (int l = 4; l >= 0; l--) { order[l] = dealt; dealt += count[l]; } /* rank of a class's first query in the deal */
         for (size_t i = 0; i < n; i++) {
             const uint32_t l = lg[i];
-            for (uint32_t sub = 0; sub < (1u << l); sub++) assign[start[l] + sub] = (uint32_t)i | (l << 24) | (sub << 28);
-            start[l] += 1u << l;
+            const uint32_t b = (uint32_t)(order[l]++ % grid), at = fill[b];
+            fill[b] = at + (1u << l);
+            /* block b, wave `at` (round at / 16, wave at % 16) */
+            uint32_t *dst = assign + ((size_t)(at >> 4) * grid + b) * 16u + (at & 15u);
+            for (uint32_t sub = 0; sub < (1u << l); sub++) dst[sub] = (uint32_t)i | (l << 24) | (sub << 28);
         }
         if (!c->h_flag.p) {
             HIP_TRY(c->h_flag.reserve(64));
@@ -597,9 +603,11 @@ static int eval_host_philox(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t s
             const auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
                 return std::chrono::duration<double, std::micro>(b - a).count();
             };
-            fprintf(stderr, "mcq direct n=%zu waves=%llu grid=%u rounds=%u: launch %.1f us, wait %.1f us (%s), copy out %.1f us\n", n,
-                    (unsigned long long)waves, grid, rounds, us(t0, t1), us(t1, t2), seen ? "flag" : "stream sync",
-                    us(t2, std::chrono::steady_clock::now()));
+            float kms = 0.f;
+            (void)mcq_kernel_times(c, &kms, 1);
+            fprintf(stderr, "mcq direct n=%zu waves=%llu grid=%u rounds=%u: launch %.1f us, wait %.1f us (%s), copy out %.1f us, "
+                    "kernel %.1f us\n", n, (unsigned long long)waves, grid, rounds, us(t0, t1), us(t1, t2),
+                    seen ? "flag" : "stream sync", us(t2, std::chrono::steady_clock::now()), 1e3 * kms);
         }
         return MCQ_OK;
     }
