@@ -133,7 +133,7 @@ struct mcq_ctx {
     uint32_t direct_ticket = 0;   /* value the kernel raises the flag in h_flag to */
     bool direct_poll = true;      /* pick the rows up at the flag instead of synchronising the stream (MCQ_DIRECT_POLL) */
     std::vector<uint8_t> direct_lg; /* scratch of the one-launch path's layout */
-    std::vector<uint32_t> direct_fill;
+    std::vector<uint32_t> direct_fill, direct_sorted;
 };
 
 /* shared between the translation units (defined in mcq_host.cpp) */

@@ -504,8 +504,8 @@ static int eval_host_philox(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t s
     const size_t q_bytes = n * sizeof(mcq_query), p_bytes = (n + 3) * sizeof(uint64_t), r_bytes = n * sizeof(mcq_result);
     /* behind the records: the cost prefix, then (one-launch path) the wave layout: at most n + 2 * 16 * n_cu waves, dealt
      * to the blocks in whole rounds */
-    const size_t a_off = q_bytes + p_bytes, a_cap = (n + 96u * (size_t)c->n_cu + 64u) * sizeof(uint32_t);
-    HIP_TRY(c->h_q.reserve(a_off + a_cap));
+    const size_t a_off = (q_bytes + p_bytes + 15u) & ~(size_t)15u, a_cap = n + 96u * (size_t)c->n_cu + 64u; /* waves */
+    HIP_TRY(c->h_q.reserve(a_off + a_cap * (sizeof(mcq_query) + sizeof(uint32_t))));
     HIP_TRY(c->d_q.reserve(q_bytes + p_bytes));
     HIP_TRY(c->h_res.reserve(r_bytes));
     if (r_bytes > c->d_res.cap) c->res_clean = 0;
@@ -544,27 +544,41 @@ static int eval_host_philox(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t s
             count[l]++;
             waves += 1ull << l;
         }
-        /* Blocks: as many as there are CUs (or queries).  Queries in descending order of their wave count are dealt
-         * to the blocks in turn, so every block carries about the same number of waves; inside a block the groups
-         * stay in descending order, hence aligned to their size and never across a round's 16 waves. */
+        /* Blocks: as many as there are CUs (or queries).  The queries, sorted by descending wave count, are dealt to
+         * the blocks in turn: every block carries about the same number of waves, and inside a block the groups come
+         * in descending order, hence aligned to their size and never across a round's 16 waves. */
         const uint32_t grid = (uint32_t)(n < (size_t)c->n_cu ? n : (size_t)c->n_cu);
-        const uint64_t per_block = (waves + grid - 1) / grid + 32u; /* bound: dealing in turn, one group per class at most */
-        const uint32_t rounds = (uint32_t)((per_block + 15u) / 16u);
+        std::vector<uint32_t> &sorted = c->direct_sorted, &fill = c->direct_fill;
+        sorted.resize(n);
+        {
+            size_t at[5], pos = 0;
+            for (int l = 4; l >= 0; l--) { at[l] = pos; pos += count[l]; }
+            for (size_t i = 0; i < n; i++) sorted[at[lg[i]]++] = (uint32_t)i; /* counting sort, wide queries first */
+        }
+        fill.assign(grid, 0u); /* waves placed in each block */
+        for (size_t k = 0; k < n; k++) fill[k % grid] += 1u << lg[sorted[k]];
+        uint32_t most = 0;
+        for (uint32_t b = 0; b < grid; b++) most = fill[b] > most ? fill[b] : most;
+        const uint32_t rounds = (most + 15u) / 16u;
         const size_t a_words = (size_t)rounds * grid * 16u;
-        if (a_words * sizeof(uint32_t) > a_cap) return mcq_fail(MCQ_EDEVICE, who, "internal: wave layout larger than its bound");
-        uint32_t *assign = reinterpret_cast<uint32_t *>(static_cast<char *>(c->h_q.p) + a_off);
-        for (size_t k = 0; k < a_words; k++) assign[k] = MCQ_DIRECT_IDLE;
-        std::vector<uint32_t> &fill = c->direct_fill; /* waves placed in each block so far */
+        if (a_words > a_cap) return mcq_fail(MCQ_EDEVICE, who, "internal: wave layout larger than its bound");
+        /* behind the caller's records and the prefix: one record copy per wave (its reserved bytes carry log2 of the
+         * query's wave count and the wave's cut number), then one query index per wave */
+        mcq_query *work_rec = reinterpret_cast<mcq_query *>(static_cast<char *>(c->h_q.p) + a_off);
+        uint32_t *work_qi = reinterpret_cast<uint32_t *>(work_rec + a_words);
+        for (size_t k = 0; k < a_words; k++) work_qi[k] = MCQ_DIRECT_IDLE;
         fill.assign(grid, 0u);
-        size_t order[5], dealt = 0;
-        for (int l = 4; l >= 0; l--) { order[l] = dealt; dealt += count[l]; } /* rank of a class's first query in the deal */
-        for (size_t i = 0; i < n; i++) {
-            const uint32_t l = lg[i];
-            const uint32_t b = (uint32_t)(order[l]++ % grid), at = fill[b];
+        for (size_t k = 0; k < n; k++) {
+            const uint32_t i = sorted[k], l = lg[i], b = (uint32_t)(k % grid), at = fill[b];
             fill[b] = at + (1u << l);
-            /* block b, wave `at` (round at / 16, wave at % 16) */
-            uint32_t *dst = assign + ((size_t)(at >> 4) * grid + b) * 16u + (at & 15u);
-            for (uint32_t sub = 0; sub < (1u << l); sub++) dst[sub] = (uint32_t)i | (l << 24) | (sub << 28);
+            const size_t dst = ((size_t)(at >> 4) * grid + b) * 16u + (at & 15u); /* round at / 16, wave at % 16 */
+            for (uint32_t sub = 0; sub < (1u << l); sub++) {
+                mcq_query r = q[i];
+                r.reserved[0] = (uint8_t)l;
+                r.reserved[1] = (uint8_t)sub;
+                work_rec[dst + sub] = r;
+                work_qi[dst + sub] = i;
+            }
         }
         if (!c->h_flag.p) {
             HIP_TRY(c->h_flag.reserve(64));
@@ -577,8 +591,9 @@ static int eval_host_philox(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t s
         c->last_ms = 0.f;
         static const bool trace = getenv("MCQ_TRACE") != nullptr; /* phase times of this path on stderr (tuning) */
         const auto t0 = std::chrono::steady_clock::now();
-        HIP_TRY(mcq_launch_eval_direct((int)mode, (const mcq_query *)c->h_q.dev,
-                                       reinterpret_cast<const uint32_t *>(static_cast<const char *>(c->h_q.dev) + a_off), rounds,
+        const char *dev_rec = static_cast<const char *>(c->h_q.dev) + a_off;
+        HIP_TRY(mcq_launch_eval_direct((int)mode, dev_rec,
+                                       reinterpret_cast<const uint32_t *>(dev_rec + a_words * sizeof(mcq_query)), rounds,
                                        count[0] != n ? 1u : 0u, (mcq_result *)c->h_res.dev, seed, first_query_id, c->d_luts, grid,
                                        (uint32_t *)c->d_done.p, (uint32_t *)c->h_flag.dev, ticket, c->stream, c->ev0[slot],
                                        c->ev1[slot]));

@@ -32,10 +32,10 @@ hipError_t mcq_launch_add_u64(uint64_t *d_dst, const uint64_t *d_src, uint64_t n
  * result rows); d_counter must be zero (the prep kernel leaves one behind the cost prefix) */
 hipError_t mcq_launch_mt_parse(const mcq_query *d_q, uint32_t n, uint32_t seed32, uint8_t *d_draws, const uint64_t *d_draw_off,
                                mcq_result *d_res, uint32_t *d_counter, uint32_t n_cu, hipStream_t s);
-/* small queries, one launch and nothing else: q, assign, res and done_flag may be pinned host memory (device-visible);
- * assign lays the queries out over rounds x grid blocks x 16 waves (see the kernel); d_done: a zeroed device word */
+/* small queries, one launch and nothing else: work_rec / work_qi (the work laid out wave by wave, see the kernel), res
+ * and done_flag may be pinned host memory (device-visible); d_done: a zeroed device word */
 #define MCQ_DIRECT_IDLE 0xFFFFFFFFu
-hipError_t mcq_launch_eval_direct(int mode, const mcq_query *q, const uint32_t *assign, uint32_t rounds, uint32_t merge,
+hipError_t mcq_launch_eval_direct(int mode, const void *work_rec, const uint32_t *work_qi, uint32_t rounds, uint32_t merge,
                                   mcq_result *res, uint64_t seed, uint64_t first_qid, const McqTables *d_luts, uint32_t grid,
                                   uint32_t *d_done, uint32_t *done_flag, uint32_t ticket, hipStream_t s, hipEvent_t t0,
                                   hipEvent_t t1);

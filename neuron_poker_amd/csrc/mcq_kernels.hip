@@ -373,82 +373,118 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
 // sums meet in LDS and one wave stores the finished 104-byte row straight into the caller's memory.  No prep
 // kernel, no atomics in HBM, no zeroing, no copy kernels.  Iterations, random numbers and hence tallies are those
 // of mcq_eval_kernel (same streams, same cut arithmetic).
-// The host lays the work out (mcq_host.cpp, pack_direct): every query gets a power-of-two number of waves in
+// The host lays the work out (eval_host_philox in mcq_host.cpp): every query gets a power-of-two number of waves in
 // proportion to its cost, so that all waves carry about the same work, and the waves of a query sit side by side in
-// one block.  assign[(round * gridDim.x + block) * 16 + wave] = query index | log2(waves of the query) << 24 |
-// this wave's cut << 28, or MCQ_DIRECT_IDLE.  done[0] (device memory, zero before the launch, reset by the last
-// block) counts finished blocks; the last one raises done_flag (pinned host memory) to `ticket` after a system-scope
-// fence, which lets the host pick the rows up without waiting for the kernel's end-of-grid handshake.
+// one block.  Wave `v` of block `b` in round `r` finds its work at index (r * gridDim.x + b) * 16 + v:
+//   work_qi[]   the query's index (its RNG stream key and result row), or MCQ_DIRECT_IDLE
+//   work_rec[]  a copy of the 16-byte query record whose reserved bytes carry log2(waves of the query) and this
+//               wave's cut number
+// -- both read by a few lanes per block, eight rounds at a time, into LDS while the tables come in (every wave
+// fetching its own record over PCIe costs more than the arithmetic).  done[0] (device memory, zero before the launch,
+// reset by the last block) counts finished blocks; the last one raises done_flag (pinned host memory) to `ticket`
+// after a system-scope fence, which lets the host pick the rows up without waiting for the end-of-grid handshake.
+#define MCQ_DIRECT_STAGE_ROUNDS 8u
 template <int MODE>
-__global__ __launch_bounds__(kMaxBlock) void mcq_eval_direct_kernel(const mcq_query *__restrict__ queries,
-                                                                    const uint32_t *__restrict__ assign, uint32_t rounds,
+__global__ __launch_bounds__(kMaxBlock) void mcq_eval_direct_kernel(const uint4 *__restrict__ work_rec,
+                                                                    const uint32_t *__restrict__ work_qi, uint32_t rounds,
                                                                     uint32_t merge, mcq_result *__restrict__ res, uint64_t seed,
                                                                     uint64_t first_qid, const McqTables *__restrict__ g_tab,
                                                                     uint32_t *__restrict__ done, volatile uint32_t *done_flag,
                                                                     uint32_t ticket) {
+    constexpr uint32_t kWaves = kMaxBlock / 64, kStage = MCQ_DIRECT_STAGE_ROUNDS * kWaves;
     __shared__ __attribute__((aligned(16))) LdsTablesEval tab;
     __shared__ McqCard base_tab[kMaxBlock];
-    __shared__ unsigned long long partial[2][kMaxBlock / 64][12]; /* [round parity][wave][passes, win, tie, by_type[9]] */
-    load_tables(tab, g_tab);
+    __shared__ unsigned long long partial[2][kWaves][12]; /* [round parity][wave][passes, win, tie, by_type[9]] */
+    __shared__ uint4 s_rec[kStage];
+    __shared__ uint32_t s_qi[kStage];
 
     const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
     McqCard *base = base_tab + (threadIdx.x & ~63u);
-    for (uint32_t round = 0; round < rounds; round++) {
-        const uint32_t a = __builtin_amdgcn_readfirstlane(assign[((size_t)round * gridDim.x + blockIdx.x) * (kMaxBlock / 64) + wib]);
-        const bool work = a != MCQ_DIRECT_IDLE;
-        const uint32_t qi = a & 0xFFFFFFu, split = (a >> 24) & 7u, sub = a >> 28, wpq = 1u << split;
-        const uint32_t chunk = MCQ_STREAM_ITERS >> split;
-        unsigned long long mine = 0; /* lane k < 12: word k + 1 of the row */
-        uint32_t runs = 0;
-        if (work) {
-            const uint4 raw = reinterpret_cast<const uint4 *>(queries)[qi];
-            const McqQueryWords q = {(uint32_t)__builtin_amdgcn_readfirstlane(raw.x), (uint32_t)__builtin_amdgcn_readfirstlane(raw.y),
-                                     (uint32_t)__builtin_amdgcn_readfirstlane(raw.z), (uint32_t)__builtin_amdgcn_readfirstlane(raw.w)};
-            McqQueryCtx qc;
-            mcq_query_ctx(q, qc);
-            runs = qc.runs;
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); /* the previous query's lookups are done */
-            base[lane] = mcq_base_entry(qc, lane, tab.sel8);
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            WaveTally tally;
-            tally.clear();
-            const uint32_t tasks = mcq_task_count(q);
-            for (uint32_t task = 0; task < tasks; task++) {
-                McqLaneAcc acc = {0, 0, 0};
-                const uint32_t stream = task * MCQ_WAVE + lane;
-                const uint64_t it0 = (uint64_t)stream * MCQ_STREAM_ITERS + sub * chunk;
-                if (it0 < qc.runs) {
-                    McqCtrDrawsT<MODE == MCQ_INTERNAL_MODE_UNIFORM> dr;
-                    dr.w = 0;
-                    dr.rng.seed(seed, first_qid + qi, stream);
-                    for (uint32_t k = sub * chunk * (qc.n_opp + ((qc.n_deal + 1u) >> 1)); k != 0; k--) dr.rng.next();
-                    const uint32_t cnt = (uint32_t)min((uint64_t)chunk, (uint64_t)qc.runs - it0);
-                    for (uint32_t j = 0; j < cnt; j++) mcq_iteration(qc, dr, base - 128, g_tab->tf, tab.tops, tab.sd, acc);
-                    acc.passes = cnt * qc.n_opp;
+    /* the first rounds' work: the loads leave before the table image is fetched, their latency hides behind it */
+    uint4 pre_rec = {0u, 0u, 0u, 0u};
+    uint32_t pre_qi = MCQ_DIRECT_IDLE;
+    if (threadIdx.x < kStage && threadIdx.x / kWaves < rounds) {
+        const size_t at = ((size_t)(threadIdx.x / kWaves) * gridDim.x + blockIdx.x) * kWaves + threadIdx.x % kWaves;
+        pre_qi = work_qi[at];
+        pre_rec = work_rec[at];
+    }
+    load_tables(tab, g_tab);
+    for (uint32_t g0 = 0; g0 < rounds; g0 += MCQ_DIRECT_STAGE_ROUNDS) {
+        if (g0) __syncthreads(); /* the previous rounds' work has been read by every wave */
+        if (threadIdx.x < kStage) {
+            if (g0) {
+                const uint32_t r = g0 + threadIdx.x / kWaves;
+                pre_qi = MCQ_DIRECT_IDLE;
+                if (r < rounds) {
+                    const size_t at = ((size_t)r * gridDim.x + blockIdx.x) * kWaves + threadIdx.x % kWaves;
+                    pre_qi = work_qi[at];
+                    pre_rec = work_rec[at];
                 }
-                tally.add(acc);
             }
-            mine = tally.row_words(lane);
+            s_qi[threadIdx.x] = pre_qi;
+            s_rec[threadIdx.x] = pre_rec;
         }
-        /* Row word w = min(lane, 12): lanes 13..63 repeat lane 12's store (same address, same value) so that no
-         * branch on the lane number stands in front of the loop's back edge -- the wave stays whole for the
-         * cross-lane steps of the next round. */
-        const uint32_t w = lane < 12u ? lane : 12u;
-        if (!merge) { /* no query of this launch has more than one wave: a wave's sums are the row */
-            const unsigned long long up = __shfl(mine, (int)((w + 63u) & 63u), 64); /* every lane takes part in the exchange */
-            if (work) reinterpret_cast<unsigned long long *>(res + qi)[w] = w == 0u ? (unsigned long long)runs : up;
-            continue;
-        }
-        if (lane < 12u) partial[round & 1u][wib][lane] = mine;
-        __syncthreads(); /* every wave of the block, every round; two buffers: a wave may run one round ahead */
-        if (work && sub == 0u) {
-            unsigned long long v = runs;
-            if (w > 0u) {
-                v = 0;
-                for (uint32_t k = 0; k < wpq; k++) v += partial[round & 1u][wib + k][w - 1u];
+        __syncthreads();
+        const uint32_t g1 = g0 + MCQ_DIRECT_STAGE_ROUNDS < rounds ? g0 + MCQ_DIRECT_STAGE_ROUNDS : rounds;
+        for (uint32_t round = g0; round < g1; round++) {
+            const uint32_t at = (round - g0) * kWaves + wib;
+            const uint32_t qi = __builtin_amdgcn_readfirstlane(s_qi[at]);
+            const bool work = qi != MCQ_DIRECT_IDLE;
+            const uint4 raw = s_rec[at];
+            const uint32_t w2 = __builtin_amdgcn_readfirstlane(raw.z);
+            const uint32_t split = (w2 >> 8) & 0xFFu, sub = (w2 >> 16) & 0xFFu, wpq = 1u << split;
+            const uint32_t chunk = MCQ_STREAM_ITERS >> split;
+            unsigned long long mine = 0; /* lane k < 12: word k + 1 of the row */
+            uint32_t runs = 0;
+            if (work) {
+                const McqQueryWords q = {(uint32_t)__builtin_amdgcn_readfirstlane(raw.x), (uint32_t)__builtin_amdgcn_readfirstlane(raw.y),
+                                         w2 & 0xFFu, (uint32_t)__builtin_amdgcn_readfirstlane(raw.w)};
+                McqQueryCtx qc;
+                mcq_query_ctx(q, qc);
+                runs = qc.runs;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); /* the previous query's lookups are done */
+                base[lane] = mcq_base_entry(qc, lane, tab.sel8);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                WaveTally tally;
+                tally.clear();
+                const uint32_t tasks = mcq_task_count(q);
+                for (uint32_t task = 0; task < tasks; task++) {
+                    McqLaneAcc acc = {0, 0, 0};
+                    const uint32_t stream = task * MCQ_WAVE + lane;
+                    const uint64_t it0 = (uint64_t)stream * MCQ_STREAM_ITERS + sub * chunk;
+                    if (it0 < qc.runs) {
+                        McqCtrDrawsT<MODE == MCQ_INTERNAL_MODE_UNIFORM> dr;
+                        dr.w = 0;
+                        dr.rng.seed(seed, first_qid + qi, stream);
+                        for (uint32_t k = sub * chunk * (qc.n_opp + ((qc.n_deal + 1u) >> 1)); k != 0; k--) dr.rng.next();
+                        const uint32_t cnt = (uint32_t)min((uint64_t)chunk, (uint64_t)qc.runs - it0);
+                        for (uint32_t j = 0; j < cnt; j++) mcq_iteration(qc, dr, base - 128, g_tab->tf, tab.tops, tab.sd, acc);
+                        acc.passes = cnt * qc.n_opp;
+                    }
+                    tally.add(acc);
+                }
+                mine = tally.row_words(lane);
             }
-            reinterpret_cast<unsigned long long *>(res + qi)[w] = v;
+            /* Row word w = min(lane, 12): lanes 13..63 repeat lane 12's store (same address, same value) so that no
+             * branch on the lane number stands in front of the loop's back edge -- the wave stays whole for the
+             * cross-lane steps of the next round. */
+            const uint32_t w = lane < 12u ? lane : 12u;
+            if (!merge) { /* no query of this launch has more than one wave: a wave's sums are the row */
+                const unsigned long long up = __shfl(mine, (int)((w + 63u) & 63u), 64); /* every lane takes part */
+                if (work) reinterpret_cast<unsigned long long *>(res + qi)[w] = w == 0u ? (unsigned long long)runs : up;
+                continue;
+            }
+            if (lane < 12u) partial[round & 1u][wib][lane] = mine;
+            __syncthreads(); /* every wave of the block, every round; two buffers: a wave may run one round ahead */
+            if (work && sub == 0u) {
+                unsigned long long v = runs;
+                if (w > 0u) {
+                    v = 0;
+                    for (uint32_t k = 0; k < wpq; k++) v += partial[round & 1u][wib + k][w - 1u];
+                }
+                reinterpret_cast<unsigned long long *>(res + qi)[w] = v;
+            }
         }
     }
     /* completion: rows first (system scope), then the count; the block that completes it tells the host */
@@ -736,16 +772,17 @@ hipError_t mcq_launch_eval(int mode, const mcq_query *d_q, uint32_t n, const uin
     return hipGetLastError();
 }
 
-hipError_t mcq_launch_eval_direct(int mode, const mcq_query *q, const uint32_t *assign, uint32_t rounds, uint32_t merge,
+hipError_t mcq_launch_eval_direct(int mode, const void *work_rec, const uint32_t *work_qi, uint32_t rounds, uint32_t merge,
                                   mcq_result *res, uint64_t seed, uint64_t first_qid, const McqTables *d_luts, uint32_t grid,
                                   uint32_t *d_done, uint32_t *done_flag, uint32_t ticket, hipStream_t s, hipEvent_t t0,
                                   hipEvent_t t1) {
     if (grid == 0 || rounds == 0) return hipErrorInvalidValue;
+    const uint4 *rec = static_cast<const uint4 *>(work_rec);
     if (mode == MCQ_INTERNAL_MODE_UNIFORM)
-        hipExtLaunchKernelGGL((mcq_eval_direct_kernel<MCQ_INTERNAL_MODE_UNIFORM>), dim3(grid), dim3(kMaxBlock), 0, s, t0, t1, 0, q,
-                              assign, rounds, merge, res, seed, first_qid, d_luts, d_done, done_flag, ticket);
+        hipExtLaunchKernelGGL((mcq_eval_direct_kernel<MCQ_INTERNAL_MODE_UNIFORM>), dim3(grid), dim3(kMaxBlock), 0, s, t0, t1, 0, rec,
+                              work_qi, rounds, merge, res, seed, first_qid, d_luts, d_done, done_flag, ticket);
     else
-        hipExtLaunchKernelGGL((mcq_eval_direct_kernel<MCQ_MODE_PHILOX>), dim3(grid), dim3(kMaxBlock), 0, s, t0, t1, 0, q, assign,
+        hipExtLaunchKernelGGL((mcq_eval_direct_kernel<MCQ_MODE_PHILOX>), dim3(grid), dim3(kMaxBlock), 0, s, t0, t1, 0, rec, work_qi,
                               rounds, merge, res, seed, first_qid, d_luts, d_done, done_flag, ticket);
     return hipGetLastError();
 }
