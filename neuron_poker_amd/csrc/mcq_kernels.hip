@@ -487,10 +487,12 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_direct_kernel(const uint4 
             }
         }
     }
-    /* completion: rows first (system scope), then the count; the block that completes it tells the host */
-    __threadfence_system();
+    /* completion: rows first (ONE system-scope release per block, behind the barrier that orders the other waves'
+     * stores before it -- a fence in every wave would write the L2 back 16 times over), then the count; the block
+     * that completes the count tells the host */
     __syncthreads();
     if (threadIdx.x == 0) {
+        __threadfence_system();
         const uint32_t prev = atomicAdd(done, 1u);
         if (prev + 1u == gridDim.x) {
             *done = 0; /* ready for the next launch on this stream */
