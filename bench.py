@@ -36,6 +36,34 @@ PEAK_VALU_TOPS = 256 * 4 * 2.4e9 * 32 / 1e12  # 256 CU x 4 SIMD-32 x 2.4 GHz ful
 HBM_PEAK_GBPS = 8000.0
 
 
+KERNEL_SOURCES = ["neuron_poker_amd/csrc/mcq_device.hpp", "neuron_poker_amd/csrc/mcq_kernels.hip", "neuron_poker_amd/csrc/mcq_mt.hpp",
+                  "neuron_poker_amd/csrc/mcq_exact.hpp"]
+
+
+def kernel_source_hash():
+    """sha256 over the kernel sources: ties a rocprof summary under profiles/ to the code it was measured on (the GPU
+    box has no .git, so a commit id is not available there)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def profile_counters():
+    """Counter-based figures of the evaluation kernel from the committed rocprofv3 PMC passes (profiles/current.json,
+    written by tools/profile.sh) -- only if they were measured on exactly these kernel sources."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "current.json")) as f:
+            s = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if s.get("kernel_sources_sha256") != kernel_source_hash():
+        return None
+    return s
+
+
 def alg_ops_per_iteration(n_players, n_board):
     """SURVEY.md 8(d) canonical cost model: A(N, b) = 48 D + 30 + 82 N int32 lane-ops, D = 2(N-1) + (5-b)."""
     d = 2 * (n_players - 1) + (5 - n_board)
@@ -49,11 +77,11 @@ def make_states(n_states, rank):
     return hole, board
 
 
-def cpu_baseline(n_players, runs, seconds=12.0):
+def cpu_baseline(n_players, runs, seconds=12.0, threads=None):
     """Time the oracle (kind 'port') on this host's cores on a bounded sample of the same workload."""
     from oracle import oracle as O
     cores = max(1, len(os.sched_getaffinity(0)))
-    threads = min(cores, 64)
+    threads = min(cores, 64) if threads is None else threads
     hole, board = make_states(threads, 0)
     probe = O.pack_queries(hole, board, n_players, 20000)
     t0 = time.perf_counter()
@@ -66,7 +94,8 @@ def cpu_baseline(n_players, runs, seconds=12.0):
     t0 = time.perf_counter()
     O.run_batch(O.MODE_MT, q, 1, 0, threads=threads)
     dt = time.perf_counter() - t0
-    return {"value": len(hole) * iters * n_players / dt, "unit": "hand-evals/s", "cores": threads, "kind": "port",
+    return {"value": len(hole) * iters * n_players / dt, "unit": "hand-evals/s", "cores": threads,
+            "host_cores_available": cores, "host_cores_total": os.cpu_count(), "kind": "port",
             "sample": "%d of the workload's preflop states x %d iterations x %d players, oracle MT19937 mode "
                       "(bit-exact to tools/montecarlo_python.py), %d threads, %.1f s" %
                       (len(hole), iters, n_players, threads, dt)}
@@ -269,16 +298,12 @@ def main():
 
     ops_per_launch = float(B) * runs * alg_ops_per_iteration(N, 0)
     achieved = ops_per_launch / (kernel_ms * 1e-3) / 1e12
-    traffic = None
-    tp = os.path.join(ROOT, "profiles", "traffic.json")  # HBM bytes per launch from rocprofv3 --pmc passes
-    if os.path.exists(tp):
-        try:
-            with open(tp) as f:
-                tj = json.load(f)
-            if tj.get("states") == B and tj.get("iters") == runs and tj.get("players") == N:
-                traffic = tj.get("hbm_bytes_per_launch")
-        except (OSError, ValueError):
-            traffic = None
+    # counter-based figures: from the committed PMC passes, and only when they were taken on these kernel sources and
+    # this workload (else null: a stale profile is not quoted)
+    pc = profile_counters()
+    if pc and pc.get("workload") != {"states": B, "iters": runs, "players": N}:
+        pc = None
+    traffic = pc.get("hbm_bytes_per_launch") if pc else None
     out = {
         "metric": "Monte Carlo hand evals/sec @100k iters, 6-max preflop", "value": value, "unit": "hand-evals/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -290,10 +315,22 @@ def main():
                                 ("RCCL" if args.backend == "nccl" else args.backend, world * B) if grouped else ""),
                    "states_per_gpu": B, "n_players": N, "iterations": runs, "n_board": 0,
                    "hand_evals_per_step": evals_per_step},
+        # `achieved` / `frac` are MODEL-based: SURVEY 8(d)'s canonical lane-op count per iteration over the measured
+        # kernel time (a kernel that needs fewer instructions than the model scores above 1).  The counter-based
+        # figures beside it come from rocprofv3 PMC passes of the same kernel (profiles/current.json).
         "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_VALU_TOPS, "unit": "Tops/s (int32 lane-ops)",
-                     "frac": achieved / PEAK_VALU_TOPS, "traffic": traffic,
+                     "frac": achieved / PEAK_VALU_TOPS, "frac_basis": "model: 1242 lane-ops per iteration (SURVEY 8d)",
+                     "traffic": traffic,
                      "kernel": "mcq_eval_kernel<0, false>", "kernel_ms": kernel_ms,
                      "alg_ops_per_iteration": alg_ops_per_iteration(N, 0),
+                     "counters": None if not pc else {
+                         "source": "rocprofv3 --pmc, profiles/current.json (same kernel sources)",
+                         "kernel_avg_ms_rocprof": pc.get("kernel_avg_ms_rocprof"),
+                         "valu_busy": pc.get("valu_busy"), "lane_utilisation": pc.get("lane_utilisation"),
+                         "valu_instructions_per_wave_iteration": pc.get("valu_instructions_per_wave_iteration"),
+                         "issued_lane_ops_frac": pc.get("issued_lane_ops_frac_of_peak"),
+                         "lds_bank_conflict_over_lds_active": pc.get("lds_bank_conflict_over_lds_active"),
+                         "hbm_GBps": pc.get("hbm_GBps")},
                      "hbm": {"algorithmic_bytes_per_launch": B * 120,
                              "achieved_GBps": B * 120 / (kernel_ms * 1e-3) / 1e9, "peak_GBps": HBM_PEAK_GBPS}},
     }
@@ -398,6 +435,7 @@ def main():
         out["other_configs"] = extras
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(N, runs)
+        out["cpu_baseline_1thread"] = cpu_baseline(N, runs, seconds=5.0, threads=1)
         ref = cpu_reference_cpp(N)
         if ref:
             out["cpu_baseline_reference_cpp"] = ref

@@ -616,6 +616,23 @@ def test_exact_enumeration_gpu_equals_host_lane_code_and_oracle(eng):
             assert int(got[i][4:].sum()) == int(got[i][2] + got[i][3])
 
 
+def test_exact_enumeration_three_players_on_the_flop_against_the_oracles_own_monte_carlo(eng):
+    """Three players on the flop are too many leaves for the oracle's literal tree walk (7e9), so there the exact
+    enumeration is checked against the ORACLE's Monte-Carlo of the reference itself -- MT19937 + numpy randint + the
+    reference's loops, the code pinned to the reference's fixtures -- at 1.9e8 iterations: sigma of the estimate
+    3.5e-5, bound 2e-4 (> 5 sigma).  Not a comparison of the product with itself."""
+    hero, board, n = ["9C", "8C"], ["7C", "6D", "2S"], 3
+    q = _xq(hero, board, n)
+    ex = eng.exact(q, "reference").view(np.uint64).reshape(-1, 13)[0]
+    exact = (int(ex[2]) + int(ex[3])) / int(ex[0])
+    B, runs = 64, 3_000_000
+    qq = npa.pack_queries([[O.card_id(c) for c in hero]] * B, [[O.card_id(c) for c in board] + [255, 255]] * B, n, runs)
+    t = O.run_batch(O.MODE_MT, qq.view(np.uint8).reshape(-1, 16), 20261004, 0, threads=min(64, os.cpu_count() or 8))
+    mc = float((t[:, 2] + t[:, 3]).sum()) / float(t[:, 0].sum())
+    assert int(t[:, 0].sum()) == B * runs
+    assert abs(mc - exact) < 2e-4, (mc, exact)
+
+
 def test_exact_enumeration_preflop_known_values_and_symmetry(eng):
     """Heads-up preflop = 2.1e9 showdowns.  Uniform law: the textbook all-in equities vs a random hand (ties
     counted half there; here ties are the hero's, so compare win + tie/2), and invariance under relabelling suits.
