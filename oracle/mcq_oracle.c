@@ -569,37 +569,39 @@ static int in_range(const uint32_t *bits, uint8_t a, uint8_t b) {
     return !bits || ((bits[i >> 5] >> (i & 31)) & 1u);
 }
 
-/* one trial of the pair loop: indices on the CURRENT list, r1 in [0,L), r2 in [0,L-1) */
-static int draw_pair(rng_t *rng, int L, uint32_t *r1, uint32_t *r2) {
-    if (rng->kind == 0) {
-        *r1 = np_randint(rng->mt, (uint32_t)L);
-        *r2 = np_randint(rng->mt, (uint32_t)L - 1);
-        return *r1 != *r2;
-    }
-    uint32_t dd = (uint32_t)L - 1, u = xo_next(rng->xo);
-    uint32_t a = (uint32_t)(((uint64_t)u * dd) >> 32), c = (uint32_t)(((uint64_t)(uint32_t)(u * dd) * dd) >> 32);
-    *r1 = a != c ? a : dd;
-    *r2 = c;
-    return 1;
-}
-
-/* mode 0 / 1 as mcqo_run.  hero: two cards, or NULL when hero_range (6 words) is given; known2: a second known
- * hand or NULL; ghost: two cards taken out of the deck or NULL; opp_range: 6 words or NULL (= every class). */
-int mcqo_run_ex(int mode, const uint8_t *hero, const uint32_t *hero_range, const uint8_t *known2, const uint8_t *ghost,
-                const uint8_t *board, int nb, int n_players, uint32_t runs, uint64_t seed, uint64_t qid,
-                const uint32_t *opp_range, uint64_t *out, uint64_t *total_words) {
+/* Extended queries in full (montecarlo_python.py:121-189): `n_known` known hands in the order of
+ * original_player_card_list (known[0] = hero), each either two cards (known_cards[h] < 52) or a set of preflop
+ * classes (known_cards[h][0] == 0xFF, known_ranges[h] = 6 words); ghost: two cards taken out of the deck or NULL;
+ * opp_range: 6 words or NULL (= every class).
+ *
+ * mode 0 (MT19937): the reference's loops, literally -- a range hand looks at deck[r1], deck[r2] on the UNPOPPED list
+ * and leaves by value (l.136-161; a card a LIST hand names that an earlier range hand has already drawn is simply not
+ * there any more: the reference's try/except), a random opponent is tested on the unpopped list and then popped in turn
+ * (l.165-181).
+ *
+ * mode 1 (production, "MCQ-CTR v3x"): the same LAW without index arithmetic.  The reference accepts every ordered
+ * index pair (r1, r2), r1 in [0,L), r2 in [0,L-1), r1 != r2, whose classes are allowed, equally often; as cards that
+ * is every ordered pair (A, B) of distinct cards of the current deck with B not the deck's highest card and
+ * class(A, B) allowed.  Per draw (range hand h, or the opponents) there is a fixed candidate list
+ *     P' = [(a, b) for a in 0..51 for b in 0..51 if a != b and a, b in U and class(a, b) allowed]   (this order)
+ * over U = 52 cards minus ghost, table and the cards of the LIST hands before h (all list hands for the opponents);
+ * a trial takes one word u, (A, B) = P'[mulhi32(u, len(P'))], and is accepted iff A and B are still in the deck and
+ * B is not its highest card; passes counts trials.  A range hand leaves by value; an opponent is dealt A and, as
+ * deck.pop(r1); deck.pop(r2) deal, B if B lies below A, else the card that follows B in the deck.  Table cards as
+ * in the plain mode (two per word, never the highest card).  65536 failed trials in a row = the range cannot be
+ * dealt: -2. */
+#define EX_MAX_TRIALS 65536u
+int mcqo_run_ex2(int mode, int n_known, const uint8_t *known_cards, const uint32_t *known_ranges, const uint8_t *ghost,
+                 const uint8_t *board, int nb, int n_players, uint32_t runs, uint64_t seed, uint64_t qid,
+                 const uint32_t *opp_range, uint64_t *out, uint64_t *total_words) {
     uint64_t seen = 0;
-    const uint8_t *sets[4] = {hero, known2, ghost, board};
-    int lens[4] = {hero ? 2 : 0, known2 ? 2 : 0, ghost ? 2 : 0, nb};
-    int known = 1 + (known2 ? 1 : 0);
-    if (mode < 0 || mode > 1 || nb < 0 || nb > 5 || n_players < known || n_players > 10) return -1;
-    if ((hero == 0) == (hero_range == 0)) return -1;
-    for (int s = 0; s < 4; s++)
-        for (int i = 0; i < lens[s]; i++) {
-            uint8_t c = sets[s][i];
-            if (c >= 52 || (seen >> c) & 1) return -1;
-            seen |= 1ull << c;
-        }
+    if (mode < 0 || mode > 1 || nb < 0 || nb > 5 || n_known < 1 || n_known > 10 || n_players < n_known || n_players > 10) return -1;
+#define EX_SEE(c) do { if ((c) >= 52 || (seen >> (c)) & 1) return -1; seen |= 1ull << (c); } while (0)
+    for (int i = 0; i < nb; i++) EX_SEE(board[i]);
+    if (ghost) { EX_SEE(ghost[0]); EX_SEE(ghost[1]); }
+    for (int h = 0; h < n_known; h++)
+        if (known_cards[2 * h] != 0xFF) { EX_SEE(known_cards[2 * h]); EX_SEE(known_cards[2 * h + 1]); }
+#undef EX_SEE
     mt_t mt;
     xo_t xo;
     rng_t rng = {mode, &mt, &xo};
@@ -609,6 +611,27 @@ int mcqo_run_ex(int mode, const uint8_t *hero, const uint32_t *hero_range, const
     deck_t original;
     deck_init(&original);
     if (ghost) { deck_remove(&original, ghost[0]); deck_remove(&original, ghost[1]); } /* l.206-208 */
+    /* production mode: the candidate lists (index n_known = the opponents') */
+    static __thread uint16_t plist[11][2704];
+    uint32_t pcount[11];
+    if (mode == 1) {
+        uint64_t u = (1ull << 52) - 1;
+        if (ghost) u &= ~((1ull << ghost[0]) | (1ull << ghost[1]));
+        for (int i = 0; i < nb; i++) u &= ~(1ull << board[i]);
+        for (int h = 0; h <= n_known; h++) {
+            const uint32_t *set = h < n_known ? known_ranges + 6 * h : opp_range;
+            const int wanted = h < n_known ? known_cards[2 * h] == 0xFF : n_players > n_known;
+            pcount[h] = 0;
+            if (wanted)
+                for (int a = 0; a < 52; a++)
+                    for (int b = 0; b < 52; b++)
+                        if (a != b && (u >> a) & 1 && (u >> b) & 1 && in_range(set, (uint8_t)a, (uint8_t)b))
+                            plist[h][pcount[h]++] = (uint16_t)(a | (b << 8));
+            if (wanted && pcount[h] == 0) return -2;
+            if (h < n_known && known_cards[2 * h] != 0xFF)
+                u &= ~((1ull << known_cards[2 * h]) | (1ull << known_cards[2 * h + 1]));
+        }
+    }
     for (uint32_t it = 0; it < runs; it++) {
         if (mode == 1 && it % STREAM_ITERS == 0) xo_seed(&xo, seed, qid, it / STREAM_ITERS);
         deck_t d = original;
@@ -616,34 +639,52 @@ int mcqo_run_ex(int mode, const uint8_t *hero, const uint32_t *hero_range, const
         int w = 0; /* table draws of this iteration (CTR: two per word) */
         uint32_t word = 0;
         for (int i = 0; i < nb; i++) { deck_remove(&d, board[i]); table[i] = board[i]; } /* l.126-128 */
-        int p = 0;
-        if (hero_range) { /* l.136-148: both indices on the UNPOPPED list */
-            uint32_t r1, r2;
-            for (;;) {
-                out[1]++;
-                if (draw_pair(&rng, d.n, &r1, &r2) && in_range(hero_range, d.c[r1], d.c[r2])) break;
+        for (int p = 0; p < n_players; p++) {
+            const int is_known = p < n_known, is_list = is_known && known_cards[2 * p] != 0xFF;
+            if (is_list) { /* l.150-161 */
+                hole[p][0] = known_cards[2 * p]; hole[p][1] = known_cards[2 * p + 1];
+                deck_remove(&d, hole[p][0]);
+                deck_remove(&d, hole[p][1]);
+                continue;
             }
-            hole[0][0] = d.c[r1]; hole[0][1] = d.c[r2];
-        } else {
-            hole[0][0] = hero[0]; hole[0][1] = hero[1];
-        }
-        deck_remove(&d, hole[0][0]); /* l.154-161 */
-        deck_remove(&d, hole[0][1]);
-        p = 1;
-        if (known2) {
-            hole[1][0] = known2[0]; hole[1][1] = known2[1];
-            deck_remove(&d, known2[0]);
-            deck_remove(&d, known2[1]);
-            p = 2;
-        }
-        for (; p < n_players; p++) { /* l.165-181: the range test looks at the UNPOPPED list, the deal pops in turn */
-            uint32_t r1, r2;
-            for (;;) {
-                out[1]++;
-                if (draw_pair(&rng, d.n, &r1, &r2) && in_range(opp_range, d.c[r1], d.c[r2])) break;
+            const uint32_t *set = is_known ? known_ranges + 6 * p : opp_range;
+            uint8_t A, B;
+            if (mode == 0) {
+                uint32_t r1, r2;
+                for (uint32_t trial = 0;; trial++) { /* l.136-148 / l.165-176 */
+                    if (trial >= EX_MAX_TRIALS * 16u) return -2;
+                    out[1]++;
+                    r1 = np_randint(&mt, (uint32_t)d.n);
+                    r2 = np_randint(&mt, (uint32_t)d.n - 1);
+                    if (r1 != r2 && in_range(set, d.c[r1], d.c[r2])) break;
+                }
+                if (is_known) { /* the two cards looked at are the hand; they leave by value */
+                    A = d.c[r1]; B = d.c[r2];
+                    deck_remove(&d, A);
+                    deck_remove(&d, B);
+                } else { /* deck.pop(r1); deck.pop(r2) on the shrunk list (l.178-179) */
+                    A = deck_pop(&d, (int)r1);
+                    B = deck_pop(&d, (int)r2);
+                }
+            } else {
+                const int li = is_known ? p : n_known;
+                for (uint32_t trial = 0;; trial++) {
+                    if (trial >= EX_MAX_TRIALS) return -2;
+                    out[1]++;
+                    const uint32_t k = (uint32_t)(((uint64_t)xo_next(&xo) * pcount[li]) >> 32);
+                    A = (uint8_t)(plist[li][k] & 0xFF);
+                    B = (uint8_t)(plist[li][k] >> 8);
+                    int ia = -1, ib = -1;
+                    for (int i = 0; i < d.n; i++) { if (d.c[i] == A) ia = i; if (d.c[i] == B) ib = i; }
+                    if (ia >= 0 && ib >= 0 && ib != d.n - 1) {
+                        if (!is_known && ib > ia) B = d.c[ib + 1]; /* deck.pop(r2) after deck.pop(r1) */
+                        break;
+                    }
+                }
+                deck_remove(&d, A);
+                deck_remove(&d, B);
             }
-            hole[p][0] = deck_pop(&d, (int)r1);
-            hole[p][1] = deck_pop(&d, (int)r2);
+            hole[p][0] = A; hole[p][1] = B;
         }
         for (int k = nb; k < 5; k++, w++) { /* l.186-188 */
             uint32_t n = (uint32_t)d.n - 1, idx;
@@ -661,7 +702,23 @@ int mcqo_run_ex(int mode, const uint8_t *hero, const uint32_t *hero_range, const
         tally(out, hands, n_players);
     }
     if (total_words) *total_words = mode == 0 ? mt.words : 0;
+    (void)rng;
     return 0;
+}
+
+/* the two-hand form of round 1 (hero + at most one further known hand) on top of the general one */
+int mcqo_run_ex(int mode, const uint8_t *hero, const uint32_t *hero_range, const uint8_t *known2, const uint8_t *ghost,
+                const uint8_t *board, int nb, int n_players, uint32_t runs, uint64_t seed, uint64_t qid,
+                const uint32_t *opp_range, uint64_t *out, uint64_t *total_words) {
+    uint8_t cards[4] = {0xFF, 0xFF, 0xFF, 0xFF};
+    uint32_t ranges[12];
+    memset(ranges, 0, sizeof ranges);
+    if ((hero == 0) == (hero_range == 0)) return -1;
+    if (hero) { cards[0] = hero[0]; cards[1] = hero[1]; }
+    else memcpy(ranges, hero_range, 24);
+    if (known2) { cards[2] = known2[0]; cards[3] = known2[1]; }
+    return mcqo_run_ex2(mode, known2 ? 2 : 1, cards, ranges, ghost, board, nb, n_players, runs, seed, qid, opp_range, out,
+                        total_words);
 }
 
 /* ------------------------------------------------------------------------- exact expectation (small cases)

@@ -72,6 +72,9 @@ def lib():
         L.mcqo_run_ex.argtypes = [C.c_int, u8p, u32p, u8p, u8p, u8p, C.c_int, C.c_int, C.c_uint32, C.c_uint64, C.c_uint64,
                                   u32p, u64p, u64p]
         L.mcqo_run_ex.restype = C.c_int
+        L.mcqo_run_ex2.argtypes = [C.c_int, C.c_int, u8p, u32p, u8p, u8p, C.c_int, C.c_int, C.c_uint32, C.c_uint64, C.c_uint64,
+                                   u32p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.mcqo_run_ex2.restype = C.c_int
         L.mcqo_exact.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.mcqo_exact.restype = C.c_int
         _lib = L
@@ -230,26 +233,36 @@ def range_bits(classes):
     return w
 
 
-def run_ex(mode, hero, board, n_players, runs, seed, qid=0, known2=None, ghost=None, opp_range=None):
-    """hero: two cards, or a set/list of class strings (hero range).  opp_range: None (all) or class strings."""
-    hero_is_range = not (len(hero) == 2 and all(isinstance(c, (int, np.integer)) or (isinstance(c, str) and len(c) == 2
-                                                                                       and c[1] in SUITS) for c in hero))
+def _is_cards(hand):
+    return len(hand) == 2 and all(isinstance(c, (int, np.integer)) or (isinstance(c, str) and len(c) == 2 and c[1] in SUITS)
+                                  for c in hand)
+
+
+def run_ex(mode, hero, board, n_players, runs, seed, qid=0, known2=None, ghost=None, opp_range=None, known=None):
+    """Extended query (ranges, ghost cards, several known hands).  hero and every entry of `known` (the further known
+    hands, in the order of original_player_card_list; `known2` = one of them): two cards, or a set/list of class
+    strings (a range).  opp_range: None (all) or class strings."""
+    hands = [hero] + ([known2] if known2 else []) + list(known or [])
+    cards = np.full((len(hands), 2), 255, np.uint8)
+    ranges = np.zeros((len(hands), 6), np.uint32)
+    for i, h in enumerate(hands):
+        if _is_cards(list(h)):
+            cards[i] = _ids(list(h))
+        else:
+            ranges[i] = range_bits(h)
     b = _ids(board)
     bb = np.zeros(5, np.uint8)
     bb[:len(b)] = b
     out = np.zeros(13, np.uint64)
     tw = C.c_uint64(0)
-    h = None if hero_is_range else _ids(hero)
-    hr = range_bits(hero) if hero_is_range else None
-    k2 = _ids(known2) if known2 else None
     gh = _ids(ghost) if ghost else None
     orr = range_bits(opp_range) if opp_range is not None else None
     pp = lambda a, t: _p(a, t) if a is not None else None  # noqa: E731
-    rc = lib().mcqo_run_ex(mode, pp(h, C.c_uint8), pp(hr, C.c_uint32), pp(k2, C.c_uint8), pp(gh, C.c_uint8),
-                           _p(bb, C.c_uint8), len(b), n_players, runs, seed, qid, pp(orr, C.c_uint32),
-                           _p(out, C.c_uint64), C.byref(tw))
+    rc = lib().mcqo_run_ex2(mode, len(hands), _p(cards, C.c_uint8), _p(ranges, C.c_uint32), pp(gh, C.c_uint8),
+                            _p(bb, C.c_uint8), len(b), n_players, runs, seed, qid, pp(orr, C.c_uint32),
+                            _p(out, C.c_uint64), C.byref(tw))
     if rc:
-        raise ValueError("invalid extended query")
+        raise ValueError("invalid extended query" if rc == -1 else "a range cannot be dealt")
     return {"runs": int(out[0]), "passes": int(out[1]), "win": int(out[2]), "tie": int(out[3]),
             "by_type": [int(x) for x in out[4:]], "wins": int(out[2] + out[3]), "mt_words": int(tw.value),
             "tallies": out}

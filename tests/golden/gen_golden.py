@@ -357,6 +357,16 @@ EXT_GRID = [  # (player_card_list, board, n_players, runs, seed, ghost_cards, op
     ([{'AKS', 'KQS', '67S', '78S'}, ['QS', 'QD']], ['2C', '3C', '4C'], 4, 3000, 11, '', 0.8),
     ([['AH', 'KH']], [], 10, 1500, 12, '', 0.9), ([{'AA', 'KK', '72O', '27O', 'AKO'}], [], 10, 1500, 13, '', 0.35),
     ([['AH', 'KH']], [], 2, 3000, 14, '', 0.001),                                      # int(169 * r) == 0 -> every class
+    # any number of known hands, each two cards or a set of classes (montecarlo_python.py:133-163)
+    ([['AH', 'KH'], ['QS', 'QD'], ['7C', '7D']], [], 5, 3000, 15, '', 1),
+    ([['AH', 'KH'], ['QS', 'QD'], ['7C', '7D'], ['2S', '3S']], ['AS', 'KD', '5C'], 4, 3000, 16, '', 1),   # no random opponent
+    ([['TC', 'TD'], {'AA', 'KK', 'QQ', 'AKS', 'AKO'}], [], 3, 3000, 17, '', 0.5),       # a RANGE for the second known hand
+    ([{'AKS', 'AKO', 'AQS'}, {'22', '33', '44', '55', '66'}, ['JS', 'JH']], ['2C', '9D', 'KC'], 5, 2500, 18, '', 0.7),
+    # a list hand BEHIND a range hand that may already have drawn one of its cards (the try/except at :154-161)
+    ([{'AA', 'AKS', 'AKO', 'AQO'}, ['AS', 'KS']], [], 3, 3000, 19, '', 1),
+    ([['9C', '9D'], ['AH', 'AD'], {'KK', 'QQ', 'JJ', 'TT', 'AKS'}, ['5H', '6H']], ['7H', '8H', '2C', 'KD'], 6, 2500, 20,
+     ['AS', 'AC'], 0.4),
+    ([{'72O', '27O', '83O', '38O'}, {'AA'}, {'KK'}], [], 4, 2000, 21, '', {'QQ', 'JJ', 'AKS', 'AQS', 'KQS'}),
 ]
 
 

@@ -210,11 +210,11 @@ def test_ranges_ghost_cards_known_hands_fixture():
     """tests/golden/ext_tallies.json was recorded from seeded reference runs (incl. the inputs of
     tests/test_montecarlo_python.py:215-232)."""
     rows = jload("ext_tallies.json")
-    assert len(rows) >= 15
+    assert len(rows) >= 22 and max(len(t["players"]) for t in rows) >= 4   # incl. several known hands, ranges among them
     for t in rows:
         pl = t["players"]
         r = O.run_ex(O.MODE_MT, pl[0], t["board"], t["n_players"], t["runs"], t["seed"],
-                     known2=pl[1] if len(pl) > 1 else None, ghost=t["ghost"] or None, opp_range=_ext_range(t))
+                     known=pl[1:], ghost=t["ghost"] or None, opp_range=_ext_range(t))
         assert (r["wins"], r["passes"], r["by_type"]) == (t["wins"], t["passes"], t["by_type"]), t
         if t["passes"] < 20 * t["runs"]:  # the recorder counts MT words modulo 624 per iteration: only valid
             assert r["mt_words"] == t["mt_words"], t  # while an iteration consumes fewer than 624 words
@@ -229,6 +229,22 @@ def test_reference_range_tests_statistically():
         a = O.run_ex(mode, ["KS", "KC"], board, 3, 30000, 5, opp_range=rng)
         b = O.run_ex(mode, ["AKO", "AA"], board, 3, 30000, 6, opp_range=rng)
         assert abs(100 * a["wins"] / a["runs"] - 12.8) < 3 and abs(100 * b["wins"] / b["runs"] - 77.8) < 3
+
+
+def test_production_law_of_extended_queries_equals_the_reference_law():
+    """The production sampler of extended queries (MCQ-CTR v3x: rejection from a fixed candidate list, no index
+    arithmetic) must deal the reference's LAW: on cases small enough to see differences of a few 1e-3, its equity
+    agrees with the literal MT19937 walk of the reference's loops within Monte-Carlo noise (both 400k iterations,
+    sigma of the difference 1.1e-3; bound 4.5e-3)."""
+    cases = [(["TC", "TD"], [["AA", "KK", "QQ", "AKS", "AKO"]], ["2C", "7D", "JC", "JD", "3S"], 3, None),
+             (["AA", "AKS", "AKO", "AQO"], [["AS", "KS"]], ["2C", "7D", "JC"], 3, None),
+             (["KS", "KC"], [], ["3D", "9H", "AS", "7S", "QH"], 3, _ext_range(jload("ext_tallies.json")[0])),
+             (["AH", "KH"], [["QS", "QD"], ["7C", "7D"]], ["2S", "8D", "9C", "TD"], 4, ["AA", "KK", "AKS", "QJS", "T9S", "22"])]
+    for hero, known, board, n, rng in cases:
+        a = O.run_ex(O.MODE_MT, hero, board, n, 400000, 3, known=known, opp_range=rng)
+        b = O.run_ex(O.MODE_CTR, hero, board, n, 400000, 4, known=known, opp_range=rng)
+        assert abs(a["wins"] / a["runs"] - b["wins"] / b["runs"]) < 4.5e-3, (hero, known, a["wins"], b["wins"])
+        assert abs(sum(a["by_type"][:3]) - sum(b["by_type"][:3])) / a["runs"] < 4.5e-3
 
 
 def test_single_player_and_invalid():

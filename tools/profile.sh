@@ -33,7 +33,7 @@ row = [r for r in csv.DictReader(open(kt)) if "mcq_eval_kernel" in r["Name"]][0]
 avg_ns = float(row["AverageNs"])
 simds, xcds = 1024, 8
 s = {"kernel_sources_sha256": kernel_source_hash(), "workload": {"states": 4096, "iters": 100000, "players": 6},
-     "kernel": row["Name"].split("(")[0], "kernel_avg_ms_rocprof": avg_ns / 1e6, "launches_timed": int(row["Calls"]),
+     "kernel": __import__("re").search(r"mcq_\w+<[^>]*>", row["Name"]).group(0), "kernel_avg_ms_rocprof": avg_ns / 1e6, "launches_timed": int(row["Calls"]),
      "valu_wave_instructions_per_launch": m.get("SQ_INSTS_VALU"),
      "valu_instructions_per_wave_iteration": m["SQ_INSTS_VALU"] / (4096 * 100000 / 64) if "SQ_INSTS_VALU" in m else None,
      # rocprof's derived VALUBusy: 4 cycles per active VALU instruction, per SIMD, over the GPU-active cycles of one XCD
