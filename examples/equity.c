@@ -14,7 +14,7 @@
 /* the record layouts the Python binding (neuron_poker_amd/_lib.py) and the kernels rely on */
 typedef char query_is_16_bytes[sizeof(mcq_query) == 16 ? 1 : -1];
 typedef char result_is_104_bytes[sizeof(mcq_result) == 104 ? 1 : -1];
-typedef char ext_is_64_bytes[sizeof(mcq_query_ext) == 64 ? 1 : -1];
+typedef char ext_is_304_bytes[sizeof(mcq_query_ext) == 304 && sizeof(mcq_known_hand) == 28 ? 1 : -1];
 typedef char config_is_224_bytes[sizeof(mcq_tables_config) == 224 ? 1 : -1];
 typedef char runs_at_12[offsetof(mcq_query, runs) == 12 ? 1 : -1];
 

@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 #define MCQ_VERSION_MAJOR 0
-#define MCQ_VERSION_MINOR 1
+#define MCQ_VERSION_MINOR 2
 #define MCQ_VERSION_PATCH 0
 
 /* error codes */
@@ -75,21 +75,31 @@ typedef struct mcq_result {
     uint64_t by_type[9];
 } mcq_result;
 
-/* Optional extension of a query (64 bytes) for the rest of run_montecarlo's arguments:
- * ghost_cards (tools/montecarlo_python.py:206-208), a second known hand (collusion player, :133-163), the hero
- * given as a SET of preflop classes instead of two cards (:136-148) and opponents restricted to a range
- * (:165-181 with :36-112).  A range is a 169-bit set of classes; the bit of a class is how
+/* Optional extension of a query (304 bytes) for the rest of run_montecarlo's arguments:
+ * ghost_cards (tools/montecarlo_python.py:206-208), any number of further known hands (collusion players, :133-163),
+ * the hero or any known hand given as a SET of preflop classes instead of two cards (:136-148), and opponents
+ * restricted to a range (:165-181 with :36-112).  A range is a 169-bit set of classes; the bit of a class is how
  * get_two_short_notation (:24-34) names two cards: suited -> 13*min+max, off-suit -> 13*max+min, pair -> 14*rank
- * (rank = index in "23456789TJQKA").  "Every class" = all 169 bits set. */
+ * (rank = index in "23456789TJQKA").  "Every class" = all 169 bits set.
+ * The known hands are dealt in the order of original_player_card_list: hero, known[0], known[1], ...; a hand
+ * given as a range is drawn from the deck as it is at that point (:136-148) -- it may take a card that a LATER hand
+ * names, which then simply is not in the deck any more (the reference's try/except, :154-161). */
+#define MCQ_MAX_KNOWN 9
+typedef struct mcq_known_hand {
+    uint8_t cards[2];   /* the hand, when is_range == 0 */
+    uint8_t is_range;   /* 1: drawn from `range` every iteration, cards ignored */
+    uint8_t reserved;   /* must be 0 */
+    uint32_t range[6];
+} mcq_known_hand;       /* 28 bytes */
+
 typedef struct mcq_query_ext {
     uint8_t ghost[2];      /* two cards taken out of the deck, 0xFF 0xFF = none */
-    uint8_t known2[2];     /* a second known hand, 0xFF 0xFF = none; it counts in n_players */
     uint8_t hero_is_range; /* 1: mcq_query.hole is ignored, hero's hand is drawn from hero_range every iteration */
-    uint8_t reserved[3];   /* must be 0 */
+    uint8_t n_known;       /* further known hands after the hero, 0..MCQ_MAX_KNOWN; they count in n_players */
     uint32_t opp_range[6];
     uint32_t hero_range[6];
-    uint32_t pad[2];
-} mcq_query_ext;
+    mcq_known_hand known[MCQ_MAX_KNOWN];
+} mcq_query_ext;           /* 304 bytes */
 
 typedef struct mcq_ctx mcq_ctx;
 
@@ -113,7 +123,11 @@ MCQ_API int mcq_eval_batch(mcq_ctx *ctx, const mcq_query *q, size_t n, uint64_t 
 MCQ_API int mcq_eval_one(mcq_ctx *ctx, const mcq_query *q, uint64_t seed, int mode, mcq_result *out);
 
 /* mcq_eval_batch with one mcq_query_ext per query (host buffers).  A range that cannot be dealt from the cards
- * left (the reference would loop forever) gives MCQ_EINVAL after a bounded number of attempts. */
+ * left (the reference would loop forever) gives MCQ_EINVAL after a bounded number of attempts.
+ * MCQ_MODE_PHILOX deals the reference's law without its re-draw loops: per range, a list of the ordered card pairs
+ * the range allows is laid out once per query, a trial picks one of them with one random word and is accepted iff
+ * both cards are still in the deck (and the second is not the deck's highest card, which the reference's index
+ * range excludes) -- `passes` counts these trials, not the reference's. */
 MCQ_API int mcq_eval_batch_ext(mcq_ctx *ctx, const mcq_query *q, const mcq_query_ext *ext, size_t n, uint64_t seed,
                        uint64_t first_query_id, int mode, mcq_result *out);
 

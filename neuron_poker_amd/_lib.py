@@ -20,14 +20,16 @@ QUERY_DTYPE = np.dtype([("hole", "u1", (2,)), ("board", "u1", (5,)), ("n_board",
                         ("reserved", "u1", (3,)), ("runs", "<u4")])
 RESULT_DTYPE = np.dtype([("runs", "<u8"), ("passes", "<u8"), ("win", "<u8"), ("tie", "<u8"),
                          ("by_type", "<u8", (9,))])
-QUERY_EXT_DTYPE = np.dtype([("ghost", "u1", (2,)), ("known2", "u1", (2,)), ("hero_is_range", "u1"), ("reserved", "u1", (3,)),
-                            ("opp_range", "<u4", (6,)), ("hero_range", "<u4", (6,)), ("pad", "<u4", (2,))])
+KNOWN_HAND_DTYPE = np.dtype([("cards", "u1", (2,)), ("is_range", "u1"), ("reserved", "u1"), ("range", "<u4", (6,))])
+MAX_KNOWN = 9
+QUERY_EXT_DTYPE = np.dtype([("ghost", "u1", (2,)), ("hero_is_range", "u1"), ("n_known", "u1"), ("opp_range", "<u4", (6,)),
+                            ("hero_range", "<u4", (6,)), ("known", KNOWN_HAND_DTYPE, (MAX_KNOWN,))])
 TABLES_CONFIG_DTYPE = np.dtype([("n_tables", "<u4"), ("n_seats", "<u4"), ("runs", "<u4"), ("max_raises", "<u4"),
                                 ("initial_stacks", "<f8"), ("small_blind", "<f8"), ("big_blind", "<f8"),
                                 ("seed", "<u8"), ("seat_kind", "u1", (10,)), ("reserved", "u1", (6,)),
                                 ("min_call_equity", "<f8", (10,)), ("min_bet_equity", "<f8", (10,))])
 assert TABLES_CONFIG_DTYPE.itemsize == 224
-assert QUERY_DTYPE.itemsize == 16 and RESULT_DTYPE.itemsize == 104 and QUERY_EXT_DTYPE.itemsize == 64
+assert QUERY_DTYPE.itemsize == 16 and RESULT_DTYPE.itemsize == 104 and QUERY_EXT_DTYPE.itemsize == 304
 ALL_CLASSES = np.array([0xFFFFFFFF] * 5 + [0x1FF], np.uint32)  # 169 bits
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -210,15 +212,28 @@ def range_bits(classes):
     return w
 
 
-def pack_query_ext(n, ghost=None, known2=None, hero_range=None, opp_range=None):
-    """n mcq_query_ext records with the same settings: ghost / known2 = two card ids or None, hero_range /
-    opp_range = 6-word sets (range_bits) or None (hero given as cards / every class)."""
+def pack_query_ext(n, ghost=None, known2=None, hero_range=None, opp_range=None, known=None):
+    """n mcq_query_ext records with the same settings.  ghost = two card ids or None; hero_range / opp_range = 6-word
+    sets (range_bits) or None (hero given as cards / every class); known = the further known hands in the order of
+    original_player_card_list, each two card ids or a 6-word set (known2 = one hand of two cards, kept for brevity)."""
     e = np.zeros(n, QUERY_EXT_DTYPE)
     e["ghost"] = 255 if ghost is None else np.asarray(ghost, np.uint8)
-    e["known2"] = 255 if known2 is None else np.asarray(known2, np.uint8)
     e["hero_is_range"] = 0 if hero_range is None else 1
     e["hero_range"] = 0 if hero_range is None else np.asarray(hero_range, np.uint32)
     e["opp_range"] = ALL_CLASSES if opp_range is None else np.asarray(opp_range, np.uint32)
+    hands = ([known2] if known2 is not None else []) + list(known or [])
+    if len(hands) > MAX_KNOWN:
+        raise ValueError("at most %d known hands besides the hero" % MAX_KNOWN)
+    e["n_known"] = len(hands)
+    for k, h in enumerate(hands):
+        h = np.asarray(h)
+        if h.size == 2:
+            e["known"]["cards"][:, k] = h.astype(np.uint8)
+        elif h.size == 6:
+            e["known"]["is_range"][:, k] = 1
+            e["known"]["range"][:, k] = h.astype(np.uint32)
+        else:
+            raise ValueError("a known hand is two card ids or a 6-word range set")
     return e
 
 

@@ -681,21 +681,41 @@ MCQ_HD void mcq_iteration(const McqQueryCtx &qc, Draws &dr, const McqCard *base1
 }
 
 // ================================================================================================ extended queries
-// opponent ranges (montecarlo_python.py:165-181 with :36-112), hero given as a set of preflop
-// classes (:136-148), ghost cards (:206-208) and a second known hand (:133-163).  This path favours
-// simplicity over speed: the deck is the 52-bit mask with the popcount search (mcq_select_pop), cards come
-// from a 52-entry table, the dealt hands' card ids wait in LDS.
+// SURVEY 8f-2, all of run_montecarlo's arguments: opponent ranges (montecarlo_python.py:165-181 with :36-112), ghost
+// cards (:206-208), any number of known hands in the order of original_player_card_list, each two cards or a SET of
+// preflop classes (:133-163).  The deck of an iteration is a 52-bit mask per lane (card-id order = the reference's
+// list order); cards come from a 52-entry table, the dealt hands' card ids wait in LDS.
 //
 // A range is a 169-bit set; the bit of two cards is how get_two_short_notation (:24-34) names them:
 // suited -> 13*min+max, off-suit -> 13*max+min, pair -> 14*rank.
-struct McqExtWords { /* the 64-byte mcq_query_ext record as words */
-    uint32_t w[16];
-    MCQ_HDM uint32_t ghost(uint32_t i) const { return (w[0] >> (8u * i)) & 0xFFu; }        /* 0xFF = none */
-    MCQ_HDM uint32_t known2(uint32_t i) const { return (w[0] >> (16u + 8u * i)) & 0xFFu; } /* 0xFF = none */
-    MCQ_HDM uint32_t hero_is_range() const { return w[1] & 0xFFu; }
-    MCQ_HDM uint32_t reserved() const { return w[1] >> 8; }
-    MCQ_HDM uint32_t opp_range(uint32_t i) const { return w[2 + i]; }
-    MCQ_HDM uint32_t hero_range(uint32_t i) const { return w[8 + i]; }
+//
+// Production mode ("MCQ-CTR v3x") deals the reference's LAW without its index arithmetic and without its re-draw
+// loop over all L(L-1) index pairs.  The reference accepts, equally often, every ordered index pair (r1, r2),
+// r1 in [0,L), r2 in [0,L-1), r1 != r2, whose classes are allowed (:167-176); as cards: every ordered pair (A, B) of
+// distinct cards of the current deck with B not the deck's highest card.  Per range there is a fixed CANDIDATE LIST
+//     P' = [(a, b) for a in 0..51 for b in 0..51 if a != b and a, b in U and class(a, b) allowed]
+// over U = the cards that can still be in the deck at that point whatever was drawn before (52 minus ghost, table and
+// the LIST hands dealt earlier; all list hands for the opponents), laid out once per query by mcq_ext_lists_kernel.
+// A trial: one word u, (A, B) = P'[mulhi32(u, |P'|)], accepted iff A and B are still in the deck and B is not its
+// highest card -- uniform on exactly the reference's accepted set.  A known hand leaves by value (:146-161); an
+// opponent is dealt A and, as deck.pop(r1); deck.pop(r2) deal (:178-179), B if B lies below A, else the card that
+// FOLLOWS B in the deck (the reference's quirk: the range test looks at the unpopped list).  With the top quarter of
+// the classes a trial of the reference's loop succeeds one time in ~25, a trial here three times in four.
+#define MCQ_EXT_WORDS 76u         /* sizeof(mcq_query_ext) / 4 */
+#define MCQ_EXT_MAX_LISTS 11u     /* ten known hands as ranges + the opponents */
+#define MCQ_EXT_LIST_STRIDE 2704u /* entries reserved per candidate list (52 * 52 >= 52 * 51) */
+#define MCQ_EXT_MAX_TRIALS 65536u /* bound of a re-draw loop: a range that cannot be dealt must not hang */
+
+struct McqExtRec { /* the 304-byte mcq_query_ext record as words (any address space) */
+    const uint32_t *w;
+    MCQ_HDM uint32_t ghost(uint32_t i) const { return (w[0] >> (8u * i)) & 0xFFu; } /* 0xFF = none */
+    MCQ_HDM uint32_t hero_is_range() const { return (w[0] >> 16) & 0xFFu; }
+    MCQ_HDM uint32_t n_known() const { return w[0] >> 24; }
+    MCQ_HDM uint32_t known_head(uint32_t k) const { return w[13u + 7u * k]; } /* cards[2], is_range, reserved */
+    /* word offsets of the 6-word sets */
+    MCQ_HDM uint32_t opp_set() const { return 1u; }
+    MCQ_HDM uint32_t hero_set() const { return 7u; }
+    MCQ_HDM uint32_t known_set(uint32_t k) const { return 14u + 7u * k; }
 };
 
 MCQ_HD uint32_t mcq_class_index(uint32_t a, uint32_t b) {
@@ -708,96 +728,141 @@ MCQ_HD bool mcq_in_range(const uint32_t *bits, uint32_t a, uint32_t b) {
     return (bits[i >> 5] >> (i & 31u)) & 1u;
 }
 
-struct McqExtCtx { /* wave-uniform */
-    uint32_t deck_lo, deck_hi;
-    uint32_t k2_lo, k2_hi; /* a second known hand is taken out AFTER a hero range was dealt (loop order of l.133-163:
-                              the hero may even be dealt one of its cards, the reference's try/except swallows it) */
-    uint32_t n_players, n_random, n_deal, runs;
-    bool hero_is_range, has_known2;
-    McqHole hero, known2;
-    McqBoard board;
-};
+/* hand h of the query (0 = hero, 1.. = known[h - 1]): cards a | b << 8 | is_range << 16 */
+MCQ_HD uint32_t mcq_ext_hand(const McqQueryWords &q, const McqExtRec &e, uint32_t h) {
+    if (h == 0) return e.hero_is_range() ? 0x10000u : (q.card(0) | (q.card(1) << 8));
+    const uint32_t hd = e.known_head(h - 1u);
+    return (hd >> 16) & 0xFFu ? 0x10000u : (hd & 0xFFFFu);
+}
+MCQ_HD uint32_t mcq_ext_hand_set(const McqExtRec &e, uint32_t h) { return h == 0 ? e.hero_set() : e.known_set(h - 1u); }
 
-// hole/board/ghost/known2 must be distinct valid cards; a range that is used must not be empty
-MCQ_HD bool mcq_query_ext_valid(const McqQueryWords &q, const McqExtWords &e) {
-    if (q.n_board() > 5 || q.n_players() < 1 || q.n_players() > 10 || q.reserved() != 0 || e.reserved() != 0) return false;
-    if (e.hero_is_range() > 1) return false;
+/* candidate lists of a query: one per known hand given as a range, in hand order, then one for the opponents */
+MCQ_HD uint32_t mcq_ext_n_lists(const McqQueryWords &q, const McqExtRec &e) {
+    uint32_t n = q.n_players() > 1u + e.n_known() ? 1u : 0u;
+    for (uint32_t h = 0; h <= e.n_known(); h++) n += mcq_ext_hand(q, e, h) >> 16;
+    return n;
+}
+
+MCQ_HD uint64_t mcq_ext_base_deck(const McqQueryWords &q, const McqExtRec &e) { /* 52 cards minus ghost and table */
+    uint64_t deck = (1ull << 52) - 1;
+    for (uint32_t i = 0; i < q.n_board(); i++) deck &= ~(1ull << q.card(2u + i));
+    if (e.ghost(0) != 0xFFu) deck &= ~((1ull << e.ghost(0)) | (1ull << e.ghost(1)));
+    return deck;
+}
+
+/* list `li` of the query: the cards U its candidates are made of and the word offset of its class set */
+MCQ_HD void mcq_ext_list_plan(const McqQueryWords &q, const McqExtRec &e, uint32_t li, uint64_t &U, uint32_t &set_off) {
+    U = mcq_ext_base_deck(q, e);
+    set_off = e.opp_set();
+    uint32_t seen = 0;
+    for (uint32_t h = 0; h <= e.n_known(); h++) {
+        const uint32_t hd = mcq_ext_hand(q, e, h);
+        if (hd >> 16) {
+            if (seen == li) { set_off = mcq_ext_hand_set(e, h); return; }
+            seen++;
+        } else {
+            U &= ~((1ull << (hd & 0xFFu)) | (1ull << ((hd >> 8) & 0xFFu)));
+        }
+    }
+}
+
+/* is candidate c = 52 * a + b on a list? */
+MCQ_HD bool mcq_ext_candidate(uint64_t U, const uint32_t *set, uint32_t c) {
+    const uint32_t a = c / 52u, b = c - 52u * a;
+    return c < 2704u && a != b && ((U >> a) & 1u) && ((U >> b) & 1u) && mcq_in_range(set, a, b);
+}
+
+// every card named twice is an error; a range that is used must not be empty
+MCQ_HD bool mcq_query_ext_valid(const McqQueryWords &q, const McqExtRec &e) {
+    if (q.n_board() > 5 || q.n_players() < 1 || q.n_players() > 10 || q.reserved() != 0) return false;
+    if (e.hero_is_range() > 1 || e.n_known() > MCQ_MAX_KNOWN || q.n_players() < 1u + e.n_known()) return false;
     uint64_t seen = 0;
     bool ok = true;
-    const bool g = e.ghost(0) != 0xFFu || e.ghost(1) != 0xFFu, k2 = e.known2(0) != 0xFFu || e.known2(1) != 0xFFu;
-    for (uint32_t i = 0; i < 11; i++) {
-        uint32_t c;
-        bool used;
-        if (i < 2) { c = q.card(i); used = !e.hero_is_range(); }
-        else if (i < 7) { c = q.card(i); used = i - 2 < q.n_board(); }
-        else if (i < 9) { c = e.ghost(i - 7); used = g; }
-        else { c = e.known2(i - 9); used = k2; }
-        if (!used) continue;
+    for (uint32_t i = 0; i < q.n_board(); i++) {
+        const uint32_t c = q.card(2u + i);
         ok = ok && c < 52 && !((seen >> (c & 63u)) & 1);
         seen |= 1ull << (c & 63u);
     }
-    const uint32_t known = 1u + (k2 ? 1u : 0u);
-    if (q.n_players() < known) return false;
-    uint32_t any_opp = 0, any_hero = 0;
-    for (uint32_t i = 0; i < 6; i++) { any_opp |= e.opp_range(i); any_hero |= e.hero_range(i); }
-    if (q.n_players() > known && any_opp == 0) return false;
-    if (e.hero_is_range() && any_hero == 0) return false;
+    if (e.ghost(0) != 0xFFu || e.ghost(1) != 0xFFu)
+        for (uint32_t i = 0; i < 2; i++) {
+            const uint32_t c = e.ghost(i);
+            ok = ok && c < 52 && !((seen >> (c & 63u)) & 1);
+            seen |= 1ull << (c & 63u);
+        }
+    for (uint32_t h = 0; h <= e.n_known(); h++) {
+        if (h > 0) {
+            const uint32_t hd = e.known_head(h - 1u);
+            if (((hd >> 16) & 0xFFu) > 1u || (hd >> 24) != 0u) return false;
+        }
+        const uint32_t hd = mcq_ext_hand(q, e, h);
+        if (hd >> 16) {
+            const uint32_t off = mcq_ext_hand_set(e, h);
+            uint32_t any = 0;
+            for (uint32_t i = 0; i < 6; i++) any |= e.w[off + i];
+            ok = ok && any != 0;
+        } else {
+            for (uint32_t i = 0; i < 2; i++) {
+                const uint32_t c = (hd >> (8u * i)) & 0xFFu;
+                ok = ok && c < 52 && !((seen >> (c & 63u)) & 1);
+                seen |= 1ull << (c & 63u);
+            }
+        }
+    }
+    if (q.n_players() > 1u + e.n_known()) {
+        uint32_t any = 0;
+        for (uint32_t i = 0; i < 6; i++) any |= e.w[e.opp_set() + i];
+        ok = ok && any != 0;
+    }
     return ok;
 }
 
-MCQ_HD void mcq_ext_ctx(const McqQueryWords &q, const McqExtWords &e, McqExtCtx &c) {
-    uint64_t deck = (1ull << 52) - 1;
+struct McqExtCtx { /* wave-uniform */
+    uint32_t deck_lo, deck_hi;            /* 52 cards minus ghost and table */
+    uint32_t n_players, n_hands, n_deal, runs; /* n_hands = 1 + n_known */
+    McqBoard board;
+};
+struct McqExtWaveCtx { /* per wave, in LDS: what the iteration indexes at run time */
+    uint32_t hand[10];                  /* mcq_ext_hand of every known hand */
+    uint32_t cnt[MCQ_EXT_MAX_LISTS];    /* sizes of the candidate lists */
+    uint32_t pad_[3];
+};
+
+MCQ_HD void mcq_ext_ctx(const McqQueryWords &q, const McqExtRec &e, McqExtCtx &c) {
+    const uint64_t deck = mcq_ext_base_deck(q, e);
     c.board.clear();
-    for (uint32_t i = 0; i < q.n_board(); i++) {
-        const uint32_t cd = q.card(2u + i);
-        deck &= ~(1ull << cd);
-        c.board.add(mcq_card(cd));
-    }
-    c.hero_is_range = e.hero_is_range() != 0;
-    c.has_known2 = e.known2(0) != 0xFFu;
-    if (!c.hero_is_range) {
-        deck &= ~(1ull << q.card(0));
-        deck &= ~(1ull << q.card(1));
-        c.hero.set(mcq_card(q.card(0)), mcq_card(q.card(1)));
-    }
-    c.k2_lo = c.k2_hi = 0;
-    if (c.has_known2) {
-        const uint64_t k2 = (1ull << e.known2(0)) | (1ull << e.known2(1));
-        if (c.hero_is_range) {
-            c.k2_lo = (uint32_t)k2;
-            c.k2_hi = (uint32_t)(k2 >> 32);
-        } else {
-            deck &= ~k2;
-        }
-        c.known2.set(mcq_card(e.known2(0)), mcq_card(e.known2(1)));
-    }
-    if (e.ghost(0) != 0xFFu) {
-        deck &= ~(1ull << e.ghost(0));
-        deck &= ~(1ull << e.ghost(1));
-    }
+    for (uint32_t i = 0; i < q.n_board(); i++) c.board.add(mcq_card(q.card(2u + i)));
     c.deck_lo = (uint32_t)deck;
     c.deck_hi = (uint32_t)(deck >> 32);
     c.n_players = q.n_players();
-    c.n_random = q.n_players() - (c.hero_is_range ? 0u : 1u) - (c.has_known2 ? 1u : 0u);
+    c.n_hands = 1u + e.n_known();
     c.n_deal = 5u - q.n_board();
     c.runs = q.runs();
 }
 
-#define MCQ_EXT_MAX_TRIALS 65536u /* bound of the range re-draw loop: a range that cannot be dealt must not hang */
+/* deck mask helpers (52 bits in two words) */
+MCQ_HD bool mcq_deck_has(uint32_t lo, uint32_t hi, uint32_t c) { return (((c & 32u) ? hi : lo) >> (c & 31u)) & 1u; }
+MCQ_HD void mcq_deck_take(uint32_t &lo, uint32_t &hi, uint32_t c) {
+    const uint32_t bit = 1u << (c & 31u);
+    lo &= (c & 32u) ? 0xFFFFFFFFu : ~bit;
+    hi &= (c & 32u) ? ~bit : 0xFFFFFFFFu;
+}
+MCQ_HD uint32_t mcq_deck_top(uint32_t lo, uint32_t hi) { /* highest card, deck not empty */
+    return hi ? 63u - mcq_clz(hi) : 31u - mcq_clz(lo | 1u);
+}
+MCQ_HD uint32_t mcq_deck_next(uint32_t lo, uint32_t hi, uint32_t c) { /* the card that follows c; c is not the top */
+    const uint64_t above = ((((uint64_t)hi << 32) | lo) >> c) >> 1; /* cards above c, bit 0 = c + 1 */
+    const uint32_t alo = (uint32_t)above, ahi = (uint32_t)(above >> 32);
+    const uint32_t low = alo ? alo & (0u - alo) : ahi & (0u - ahi);
+    return c + 1u + (alo ? 31u - mcq_clz(low | 1u) : 63u - mcq_clz(low | 1u));
+}
 
-// Draw policies with run-time draw numbers (the extended path is not unrolled).
+// Draw policies (the extended path is not unrolled).
 struct McqExtCtrDraws {
     static constexpr bool kReplay = false;
     McqXoshiro rng;
     uint32_t w;
-    MCQ_HDM void pair(uint32_t L, uint32_t &r1, uint32_t &r2) { /* MCQ-CTR v3, plain indices */
-        const uint32_t dd = L - 1u;
-        const uint32_t u = rng.next();
-        const uint32_t a = mcq_mulhi(u, dd);
-        const uint32_t c = mcq_mulhi(u * dd, dd);
-        r1 = a == c ? dd : a;
-        r2 = c;
-    }
+    MCQ_HDM uint32_t pick(uint32_t n) { return mcq_mulhi(rng.next(), n); } /* a candidate of a list of n */
+    MCQ_HDM void pair(uint32_t &, uint32_t &) {}
     MCQ_HDM uint32_t table(uint32_t k, uint32_t n) {
         if ((k & 1u) == 0) {
             const uint32_t u = rng.next();
@@ -811,7 +876,8 @@ struct McqExtReplayDraws { /* accepted draws from the host, all in list.pop orde
     static constexpr bool kReplay = true;
     const uint8_t *p;
     uint64_t stride;
-    MCQ_HDM void pair(uint32_t, uint32_t &r1, uint32_t &r2) {
+    MCQ_HDM uint32_t pick(uint32_t) { return 0; }
+    MCQ_HDM void pair(uint32_t &r1, uint32_t &r2) {
         r1 = p[0] & 0x7Fu; /* the host stores every draw as r | 0x80 */
         r2 = p[stride] & 0x7Fu;
         p += 2 * stride;
@@ -824,50 +890,48 @@ struct McqExtReplayDraws { /* accepted draws from the host, all in list.pop orde
 };
 
 // One iteration of an extended query.  ids: this lane's slot array (stride `ids_stride` words) for the dealt
-// hands; cards: the 52-entry card table; hero_set / opp_set: 6-word range sets.  Returns false when a range could
-// not be dealt within MCQ_EXT_MAX_TRIALS attempts.
+// hands; cards: the 52-entry card table; lists: the query's candidate lists (MCQ_EXT_LIST_STRIDE entries each),
+// wc: the known hands and the list sizes.  Returns false when a range could not be dealt within
+// MCQ_EXT_MAX_TRIALS attempts.
 template <class Draws>
-MCQ_HD bool mcq_iteration_ext(const McqExtCtx &qc, Draws &dr, const McqCard *cards, const uint32_t *sel8,
-                              const uint32_t *hero_set, const uint32_t *opp_set, uint32_t *ids, uint32_t ids_stride,
+MCQ_HD bool mcq_iteration_ext(const McqExtCtx &qc, const McqExtWaveCtx &wc, Draws &dr, const McqCard *cards,
+                              const uint32_t *sel8, const uint16_t *lists, uint32_t *ids, uint32_t ids_stride,
                               const uint32_t *tf, const uint32_t *tops, const uint32_t *sd, McqLaneAcc &acc) {
     uint32_t dlo = qc.deck_lo, dhi = qc.deck_hi;
     bool dealt = true;
-    for (uint32_t h = 0; h < qc.n_random; h++) {
-        const bool is_hero = qc.hero_is_range && h == 0;
-        const uint32_t L = mcq_popc(dlo) + mcq_popc(dhi);
-        uint32_t r1 = 0, r2 = 0, c1, c2;
-        if (Draws::kReplay) {
-            dr.pair(L, r1, r2);
+    uint32_t li = 0; /* candidate list of the next known hand given as a range; the opponents' comes after them */
+    for (uint32_t h = 0; h < qc.n_players; h++) {
+        const bool known = h < qc.n_hands;
+        const uint32_t hd = known ? wc.hand[h] : 0x10000u;
+        uint32_t c1, c2;
+        if (!(hd >> 16)) { /* two cards: they leave by value, if they are still there (l.150-161) */
+            c1 = hd & 0xFFu;
+            c2 = (hd >> 8) & 0xFFu;
+        } else if (Draws::kReplay) {
+            uint32_t r1, r2;
+            dr.pair(r1, r2);
             c1 = mcq_select_pop(dlo, dhi, r1, sel8);
             c2 = mcq_select_pop(dlo, dhi, r2, sel8);
         } else {
-            const uint32_t *set = is_hero ? hero_set : opp_set;
+            const uint32_t n = wc.cnt[li];
+            const uint16_t *list = lists + li * MCQ_EXT_LIST_STRIDE;
+            const uint32_t top = mcq_deck_top(dlo, dhi);
             bool ok = false;
             c1 = c2 = 0;
             for (uint32_t trial = 0; trial < MCQ_EXT_MAX_TRIALS && !ok; trial++) {
                 acc.passes++;
-                dr.pair(L, r1, r2);
-                uint32_t tl = dlo, th = dhi;
-                c1 = mcq_select_pop(tl, th, r1, sel8); /* deck[r1] */
-                tl = dlo; th = dhi;
-                c2 = mcq_select_pop(tl, th, r2, sel8); /* deck[r2] on the UNPOPPED list (l.142, l.173) */
-                ok = mcq_in_range(set, c1, c2);
+                const uint32_t e = list[dr.pick(n)];
+                c1 = e & 0xFFu;
+                c2 = e >> 8;
+                ok = mcq_deck_has(dlo, dhi, c1) && mcq_deck_has(dlo, dhi, c2) && c2 != top;
             }
             dealt = dealt && ok;
-            if (is_hero) { /* the two cards looked at are the hand; they leave the deck by value (l.146-161) */
-                const uint64_t m = ~((1ull << c1) | (1ull << c2));
-                dlo &= (uint32_t)m;
-                dhi &= (uint32_t)(m >> 32);
-            } else { /* deck.pop(r1); deck.pop(r2) on the shrunk list (l.178-179) */
-                c1 = mcq_select_pop(dlo, dhi, r1, sel8);
-                c2 = mcq_select_pop(dlo, dhi, r2, sel8);
-            }
+            if (!known && ok && c2 > c1) c2 = mcq_deck_next(dlo, dhi, c2); /* deck.pop(r2) after deck.pop(r1), l.178-179 */
         }
+        if (known && (hd >> 16)) li++;
+        mcq_deck_take(dlo, dhi, c1 < 52u ? c1 : 0u);
+        mcq_deck_take(dlo, dhi, c2 < 52u ? c2 : 0u);
         ids[h * ids_stride] = c1 | (c2 << 8);
-        if (is_hero) {
-            dlo &= ~qc.k2_lo;
-            dhi &= ~qc.k2_hi;
-        }
     }
     McqBoard b = qc.board;
     for (uint32_t k = 0; k < qc.n_deal; k++) {
@@ -877,26 +941,14 @@ MCQ_HD bool mcq_iteration_ext(const McqExtCtx &qc, Draws &dr, const McqCard *car
     }
     McqFlushSel fs;
     fs.from_board(b);
-    uint32_t hk, best = 0, h0 = 0;
-    if (qc.hero_is_range) {
-        const uint32_t v = ids[0];
-        McqHole hh;
-        hh.set(cards[v & 0xFFu], cards[(v >> 8) & 0xFFu]);
-        hk = mcq_eval_key(b, fs, hh, tf, tops, sd);
-        h0 = 1;
-    } else {
-        hk = mcq_eval_key(b, fs, qc.hero, tf, tops, sd);
-    }
-    if (qc.has_known2) {
-        const uint32_t k = mcq_eval_key(b, fs, qc.known2, tf, tops, sd);
-        best = k > best ? k : best;
-    }
-    for (uint32_t h = h0; h < qc.n_random; h++) {
+    uint32_t hk = 0, best = 0;
+    for (uint32_t h = 0; h < qc.n_players; h++) {
         const uint32_t v = ids[h * ids_stride];
         McqHole hh;
         hh.set(cards[v & 0xFFu], cards[(v >> 8) & 0xFFu]);
         const uint32_t k = mcq_eval_key(b, fs, hh, tf, tops, sd);
-        best = k > best ? k : best;
+        if (h == 0) hk = k;
+        else best = k > best ? k : best;
     }
     uint64_t won = hk >= best ? 1u : 0u;
     acc.types += won << (6u * (hk >> MCQ_KEY_SHIFT));

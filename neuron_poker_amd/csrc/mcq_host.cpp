@@ -356,7 +356,7 @@ void mcq_destroy(mcq_ctx *c) {
     McqDeviceScope dev_(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *db[] = {&c->d_q, &c->d_res, &c->d_draws, &c->d_off, &c->d_hands, &c->d_win, &c->d_wt, &c->d_keys, &c->d_ext,
-                    &c->d_mt};
+                    &c->d_mt, &c->d_lists, &c->d_cnts};
     for (auto &sc : c->scratch) {
         sc.prefix.release();
         if (sc.done) (void)hipEventDestroy(sc.done);
@@ -692,15 +692,18 @@ int mcq_eval_batch_ext(mcq_ctx *c, const mcq_query *q, const mcq_query_ext *ext,
     if (!q || !ext || !out) return mcq_fail(MCQ_EINVAL, "mcq_eval_batch_ext: null buffer");
     if (n > 0x7fffffffu) return mcq_fail(MCQ_EINVAL, "mcq_eval_batch_ext: n too large");
     uint64_t total_tasks = 0;
+    uint32_t lists_stride = 1; /* candidate lists per query of the production mode: the batch's maximum */
     for (size_t i = 0; i < n; i++) {
-        McqExtWords ew;
-        memcpy(ew.w, &ext[i], 64);
-        if (!mcq_query_ext_valid(mcq_query_words(q[i]), ew)) {
-            char buf[200];
-            snprintf(buf, sizeof buf, "extended query %zu invalid (distinct card ids < 52 among hole/table/ghost/known2, "
-                     "n_players >= known hands, used ranges not empty)", i);
+        const McqExtRec er = {reinterpret_cast<const uint32_t *>(&ext[i])};
+        const McqQueryWords qw = mcq_query_words(q[i]);
+        if (!mcq_query_ext_valid(qw, er)) {
+            char buf[220];
+            snprintf(buf, sizeof buf, "extended query %zu invalid (distinct card ids < 52 among hole/table/ghost/known hands, "
+                     "at most 9 further known hands, n_players >= known hands, used ranges not empty)", i);
             return mcq_fail(MCQ_EINVAL, buf);
         }
+        const uint32_t nl = mcq_ext_n_lists(qw, er);
+        if (nl > lists_stride) lists_stride = nl;
         total_tasks += tasks_of(q[i]);
     }
     if (total_tasks > 0xfffffff0ull) return mcq_fail(MCQ_EINVAL, "mcq_eval_batch_ext: too many iterations in one call");
@@ -763,11 +766,21 @@ int mcq_eval_batch_ext(mcq_ctx *c, const mcq_query *q, const mcq_query_ext *ext,
     }
     HIP_TRY(mcq_launch_prep_ext((const mcq_query *)c->d_q.p, (const mcq_query_ext *)c->d_ext.p, (uint32_t)n,
                                 (mcq_result *)c->d_res.p, (uint64_t *)c->scratch[0].prefix.p, c->stream));
+    if (mode == MCQ_MODE_PHILOX) { /* the candidate lists of the ranges, once per query */
+        HIP_TRY(c->d_lists.reserve(n * (size_t)lists_stride * MCQ_EXT_LIST_STRIDE * sizeof(uint16_t)));
+        HIP_TRY(c->d_cnts.reserve(n * (size_t)lists_stride * sizeof(uint32_t)));
+        HIP_TRY(mcq_launch_ext_lists((const mcq_query *)c->d_q.p, (const mcq_query_ext *)c->d_ext.p, (uint32_t)n, lists_stride,
+                                     (uint16_t *)c->d_lists.p, (uint32_t *)c->d_cnts.p, c->stream));
+    }
+    const int slot = (int)(c->n_timed % mcq_ctx::kRing);
     HIP_TRY(mcq_launch_eval_ext(mode, (const mcq_query *)c->d_q.p, (const mcq_query_ext *)c->d_ext.p, (uint32_t)n,
                                 (const uint64_t *)c->scratch[0].prefix.p, (mcq_result *)c->d_res.p, seed, first_query_id, c->d_luts,
-                                (const uint8_t *)c->d_draws.p, (const uint64_t *)c->d_off.p, grid, block, c->stream));
+                                (const uint8_t *)c->d_draws.p, (const uint64_t *)c->d_off.p, (const uint16_t *)c->d_lists.p,
+                                (const uint32_t *)c->d_cnts.p, lists_stride, grid, block, c->stream, c->ev0[slot], c->ev1[slot]));
+    c->n_timed++;
     HIP_TRY(hipMemcpyAsync(c->h_res.p, c->d_res.p, n * sizeof(mcq_result), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (mcq_kernel_times(c, &c->last_ms, 1) != 1) c->last_ms = 0.f;
     const mcq_result *hr = (const mcq_result *)c->h_res.p;
     for (size_t i = 0; i < n; i++)
         if (hr[i].runs != q[i].runs)

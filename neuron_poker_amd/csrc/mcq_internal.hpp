@@ -22,10 +22,15 @@ hipError_t mcq_launch_showdown(const uint8_t *d_hands, uint32_t n_tables, uint32
                                uint8_t *d_winner, uint8_t *d_wtype, uint32_t *d_keys, hipStream_t s);
 hipError_t mcq_launch_prep_ext(const mcq_query *d_q, const mcq_query_ext *d_ext, uint32_t n, mcq_result *d_res,
                                uint64_t *d_prefix, hipStream_t s);
+/* production mode of the extended queries: lays out the candidate lists (lists_stride per query, MCQ_EXT_LIST_STRIDE
+ * uint16 entries each) and their lengths */
+hipError_t mcq_launch_ext_lists(const mcq_query *d_q, const mcq_query_ext *d_ext, uint32_t n, uint32_t lists_stride,
+                                uint16_t *d_lists, uint32_t *d_cnts, hipStream_t s);
 hipError_t mcq_launch_eval_ext(int mode, const mcq_query *d_q, const mcq_query_ext *d_ext, uint32_t n,
                                const uint64_t *d_prefix, mcq_result *d_res, uint64_t seed, uint64_t first_qid,
-                               const McqTables *d_luts, const uint8_t *d_draws, const uint64_t *d_draw_off, uint32_t grid,
-                               uint32_t block, hipStream_t s);
+                               const McqTables *d_luts, const uint8_t *d_draws, const uint64_t *d_draw_off,
+                               const uint16_t *d_lists, const uint32_t *d_cnts, uint32_t lists_stride, uint32_t grid,
+                               uint32_t block, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 /* dst[i] += src[i], i < n (tally matrices of two shards on one device, both 16-byte aligned) */
 hipError_t mcq_launch_add_u64(uint64_t *d_dst, const uint64_t *d_src, uint64_t n, hipStream_t s);
 /* parity mode: one wave per query parses np.random.seed(seed32 + i)'s MT19937 stream into d_draws (+ passes into the

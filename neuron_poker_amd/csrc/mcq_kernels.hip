@@ -503,8 +503,10 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_direct_kernel(const uint4 
 }
 
 // ---------------------------------------------------------------------------------------------- extended queries
-// SURVEY 8f-2 (ranges, hero range, ghost cards, second known hand): same slicing and tallying as above, the
-// simpler mask-based iteration of mcq_iteration_ext.  A range that could not be dealt zeroes the row's `runs`.
+// SURVEY 8f-2 (ranges, ghost cards, any number of known hands, each two cards or a range): same slicing and tallying
+// as above, the mask-based iteration of mcq_iteration_ext.  Production mode draws from candidate lists that
+// mcq_ext_lists_kernel lays out once per query (mcq_device.hpp).  A range that could not be dealt zeroes the row's
+// `runs`.
 __global__ __launch_bounds__(1024) void mcq_prep_ext_kernel(const mcq_query *__restrict__ q,
                                                             const mcq_query_ext *__restrict__ ext, uint32_t n,
                                                             mcq_result *__restrict__ res, uint64_t *__restrict__ prefix) {
@@ -517,10 +519,8 @@ __global__ __launch_bounds__(1024) void mcq_prep_ext_kernel(const mcq_query *__r
         if (i < n) {
             const uint4 raw = reinterpret_cast<const uint4 *>(q)[i];
             const McqQueryWords qq = {raw.x, raw.y, raw.z, raw.w};
-            McqExtWords ew;
-#pragma unroll
-            for (int k = 0; k < 16; k++) ew.w[k] = reinterpret_cast<const uint32_t *>(ext + i)[k];
-            bool ok = mcq_query_ext_valid(qq, ew);
+            const McqExtRec er = {reinterpret_cast<const uint32_t *>(ext + i)};
+            bool ok = mcq_query_ext_valid(qq, er);
             cost = ok ? (uint64_t)mcq_task_count(qq) * (3u * mcq_task_weight(qq)) : 0ull;
             uint64_t *r = reinterpret_cast<uint64_t *>(res + i);
             r[0] = ok ? qq.runs() : 0ull;
@@ -536,6 +536,58 @@ __global__ __launch_bounds__(1024) void mcq_prep_ext_kernel(const mcq_query *__r
     if (tid == 0) prefix[n] = carry;
 }
 
+// The candidate lists of the production mode: one block per query; list li of the query = all ordered pairs (a, b) of
+// cards of U_li whose class its range allows, in the order of 52 * a + b (the specification's order: the oracle builds
+// the same list).  Every thread looks at eleven consecutive candidates; a block scan of the counts puts the survivors
+// in order.  cnts[query * lists_stride + li] = the list's length (0 for a query that is invalid).
+constexpr int kListBlock = 256;
+__global__ __launch_bounds__(kListBlock) void mcq_ext_lists_kernel(const mcq_query *__restrict__ q,
+                                                                   const mcq_query_ext *__restrict__ ext, uint32_t lists_stride,
+                                                                   uint16_t *__restrict__ lists, uint32_t *__restrict__ cnts) {
+    __shared__ uint32_t wave_tot[kListBlock / 64];
+    const uint32_t qi = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint4 raw = reinterpret_cast<const uint4 *>(q)[qi];
+    const McqQueryWords qq = {raw.x, raw.y, raw.z, raw.w};
+    const McqExtRec er = {reinterpret_cast<const uint32_t *>(ext + qi)};
+    const bool valid = mcq_query_ext_valid(qq, er);
+    const uint32_t n_lists = valid ? mcq_ext_n_lists(qq, er) : 0u;
+    for (uint32_t li = 0; li < lists_stride; li++) {
+        if (li >= n_lists) { /* block-uniform */
+            if (tid == 0) cnts[(size_t)qi * lists_stride + li] = 0;
+            continue;
+        }
+        uint64_t U;
+        uint32_t set_off;
+        mcq_ext_list_plan(qq, er, li, U, set_off);
+        constexpr uint32_t kPer = (2704u + kListBlock - 1) / kListBlock; /* 11 */
+        uint32_t mask = 0;
+        for (uint32_t k = 0; k < kPer; k++)
+            if (mcq_ext_candidate(U, er.w + set_off, tid * kPer + k)) mask |= 1u << k;
+        const uint32_t mine = (uint32_t)__popc(mask);
+        uint32_t inc = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(inc, off, 64);
+            if (lane >= (uint32_t)off) inc += o;
+        }
+        __syncthreads(); /* wave_tot of the previous list has been read */
+        if (lane == 63u) wave_tot[wv] = inc;
+        __syncthreads();
+        uint32_t at = inc - mine, total = 0;
+        for (uint32_t k = 0; k < kListBlock / 64; k++) {
+            at += k < wv ? wave_tot[k] : 0u;
+            total += wave_tot[k];
+        }
+        uint16_t *dst = lists + ((size_t)qi * lists_stride + li) * MCQ_EXT_LIST_STRIDE;
+        for (uint32_t k = 0; k < kPer; k++)
+            if ((mask >> k) & 1u) {
+                const uint32_t c = tid * kPer + k, a = c / 52u;
+                dst[at++] = (uint16_t)(a | ((c - 52u * a) << 8));
+            }
+        if (tid == 0) cnts[(size_t)qi * lists_stride + li] = total;
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(kExtBlock) void mcq_eval_ext_kernel(const mcq_query *__restrict__ queries,
                                                                  const mcq_query_ext *__restrict__ ext, uint32_t n,
@@ -543,10 +595,12 @@ __global__ __launch_bounds__(kExtBlock) void mcq_eval_ext_kernel(const mcq_query
                                                                  mcq_result *__restrict__ res, uint64_t seed,
                                                                  uint64_t first_qid, const McqTables *__restrict__ g_tab,
                                                                  const uint8_t *__restrict__ draws,
-                                                                 const uint64_t *__restrict__ draw_off) {
+                                                                 const uint64_t *__restrict__ draw_off,
+                                                                 const uint16_t *__restrict__ lists,
+                                                                 const uint32_t *__restrict__ cnts, uint32_t lists_stride) {
     __shared__ __attribute__((aligned(16))) LdsTablesEval tab;
     __shared__ McqCard cards[64];
-    __shared__ uint32_t sets[(kExtBlock / 64) * 12]; /* per wave: hero_range[6], opp_range[6] */
+    __shared__ McqExtWaveCtx wave_ctx[kExtBlock / 64];
     __shared__ uint32_t ids[(MCQ_MAX_OPP + 1) * kExtBlock];
     if (threadIdx.x < 64) cards[threadIdx.x] = mcq_card(threadIdx.x < 52 ? threadIdx.x : 0u);
     load_tables(tab, g_tab);
@@ -558,7 +612,7 @@ __global__ __launch_bounds__(kExtBlock) void mcq_eval_ext_kernel(const mcq_query
     const uint64_t total = prefix[n];
     const uint64_t lo = total * wave / n_waves, hi = total * (wave + 1ull) / n_waves;
     if (lo >= hi) return;
-    uint32_t *my_sets = sets + (threadIdx.x >> 6) * 12;
+    McqExtWaveCtx &wc = wave_ctx[threadIdx.x >> 6];
     uint32_t *my_ids = ids + threadIdx.x;
 
     uint32_t a = 0, b = n;
@@ -570,6 +624,7 @@ __global__ __launch_bounds__(kExtBlock) void mcq_eval_ext_kernel(const mcq_query
     uint32_t task = 0, n_tasks = 0, weight = 1;
     uint64_t pfx = 0;
     McqExtCtx qc;
+    const uint16_t *my_lists = lists;
     WaveTally tally;
     tally.clear();
     bool failed = false, fresh = true;
@@ -579,23 +634,33 @@ __global__ __launch_bounds__(kExtBlock) void mcq_eval_ext_kernel(const mcq_query
             const uint4 raw = reinterpret_cast<const uint4 *>(queries)[qi];
             const McqQueryWords q = {raw.x, raw.y, raw.z, raw.w};
             pfx = prefix[qi];
-            const bool ok = prefix[qi + 1] > pfx;
-            n_tasks = ok ? mcq_task_count(q) : 0u;
+            bool ok = prefix[qi + 1] > pfx;
             weight = 3u * mcq_task_weight(q);
             task = 0;
             if (pfx < lo) task = (uint32_t)((lo - pfx + weight - 1) / weight);
             fresh = false;
             if (ok) {
-                McqExtWords ew;
-#pragma unroll
-                for (int k = 0; k < 16; k++) ew.w[k] = reinterpret_cast<const uint32_t *>(ext + qi)[k];
-                mcq_ext_ctx(q, ew, qc);
+                const McqExtRec er = {reinterpret_cast<const uint32_t *>(ext + qi)};
+                mcq_ext_ctx(q, er, qc);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                if (lane < 12) /* words 8..13 = hero_range, 2..7 = opp_range */
-                    my_sets[lane] = reinterpret_cast<const uint32_t *>(ext + qi)[lane < 6 ? 8u + lane : lane - 4u];
+                if (lane < 10u) wc.hand[lane] = lane < qc.n_hands ? mcq_ext_hand(q, er, lane) : 0u;
+                if (MODE == MCQ_MODE_PHILOX) {
+                    const uint32_t n_lists = mcq_ext_n_lists(q, er);
+                    uint32_t c = 1;
+                    if (lane < MCQ_EXT_MAX_LISTS) {
+                        c = lane < n_lists ? cnts[(size_t)qi * lists_stride + lane] : 1u;
+                        wc.cnt[lane] = c;
+                    }
+                    if (__any(c == 0u)) { /* a range no pair of cards can satisfy: nothing to deal from */
+                        failed = true;
+                        ok = false;
+                    }
+                    my_lists = lists + (size_t)qi * lists_stride * MCQ_EXT_LIST_STRIDE;
+                }
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
+            n_tasks = ok ? mcq_task_count(q) : 0u;
         }
         if (task >= n_tasks) {
             if (__any(failed)) {
@@ -619,8 +684,8 @@ __global__ __launch_bounds__(kExtBlock) void mcq_eval_ext_kernel(const mcq_query
                 dr.rng.seed(seed, first_qid + qi, stream);
                 const uint32_t cnt = (uint32_t)min((uint64_t)MCQ_STREAM_ITERS, (uint64_t)qc.runs - it0);
                 for (uint32_t j = 0; j < cnt && !failed; j++)
-                    failed = !mcq_iteration_ext(qc, dr, cards, tab.sel8, my_sets, my_sets + 6, my_ids, kExtBlock, g_tab->tf,
-                                                tab.tops, tab.sd, acc);
+                    failed = !mcq_iteration_ext(qc, wc, dr, cards, tab.sel8, my_lists, my_ids, kExtBlock, g_tab->tf, tab.tops,
+                                                tab.sd, acc);
             }
         } else {
             const uint64_t stride = (qc.runs + 63u) & ~63ull;
@@ -629,8 +694,7 @@ __global__ __launch_bounds__(kExtBlock) void mcq_eval_ext_kernel(const mcq_query
                 const uint64_t it = (uint64_t)task * MCQ_TASK_ITERS + j * MCQ_WAVE + lane;
                 if (it < qc.runs) {
                     McqExtReplayDraws dr = {dbase + it, stride};
-                    mcq_iteration_ext(qc, dr, cards, tab.sel8, my_sets, my_sets + 6, my_ids, kExtBlock, g_tab->tf, tab.tops,
-                                      tab.sd, acc);
+                    mcq_iteration_ext(qc, wc, dr, cards, tab.sel8, my_lists, my_ids, kExtBlock, g_tab->tf, tab.tops, tab.sd, acc);
                 }
             }
             acc.passes = 0;
@@ -814,16 +878,24 @@ hipError_t mcq_launch_prep_ext(const mcq_query *d_q, const mcq_query_ext *d_ext,
     return hipGetLastError();
 }
 
+hipError_t mcq_launch_ext_lists(const mcq_query *d_q, const mcq_query_ext *d_ext, uint32_t n, uint32_t lists_stride,
+                                uint16_t *d_lists, uint32_t *d_cnts, hipStream_t s) {
+    if (n == 0 || lists_stride == 0) return hipSuccess;
+    hipLaunchKernelGGL(mcq_ext_lists_kernel, dim3(n), dim3(kListBlock), 0, s, d_q, d_ext, lists_stride, d_lists, d_cnts);
+    return hipGetLastError();
+}
+
 hipError_t mcq_launch_eval_ext(int mode, const mcq_query *d_q, const mcq_query_ext *d_ext, uint32_t n,
                                const uint64_t *d_prefix, mcq_result *d_res, uint64_t seed, uint64_t first_qid,
-                               const McqTables *d_luts, const uint8_t *d_draws, const uint64_t *d_draw_off, uint32_t grid,
-                               uint32_t block, hipStream_t s) {
+                               const McqTables *d_luts, const uint8_t *d_draws, const uint64_t *d_draw_off,
+                               const uint16_t *d_lists, const uint32_t *d_cnts, uint32_t lists_stride, uint32_t grid,
+                               uint32_t block, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
     if (mode == MCQ_MODE_PHILOX)
-        hipLaunchKernelGGL(mcq_eval_ext_kernel<MCQ_MODE_PHILOX>, dim3(grid), dim3(block), 0, s, d_q, d_ext, n, d_prefix,
-                           d_res, seed, first_qid, d_luts, d_draws, d_draw_off);
+        hipExtLaunchKernelGGL(mcq_eval_ext_kernel<MCQ_MODE_PHILOX>, dim3(grid), dim3(block), 0, s, t0, t1, 0, d_q, d_ext, n,
+                              d_prefix, d_res, seed, first_qid, d_luts, d_draws, d_draw_off, d_lists, d_cnts, lists_stride);
     else
-        hipLaunchKernelGGL(mcq_eval_ext_kernel<MCQ_MODE_REPLAY_MT19937>, dim3(grid), dim3(block), 0, s, d_q, d_ext, n,
-                           d_prefix, d_res, seed, first_qid, d_luts, d_draws, d_draw_off);
+        hipExtLaunchKernelGGL(mcq_eval_ext_kernel<MCQ_MODE_REPLAY_MT19937>, dim3(grid), dim3(block), 0, s, t0, t1, 0, d_q, d_ext,
+                              n, d_prefix, d_res, seed, first_qid, d_luts, d_draws, d_draw_off, d_lists, d_cnts, lists_stride);
     return hipGetLastError();
 }
 

@@ -98,10 +98,10 @@ static inline uint64_t mcq_replay_parse(const mcq_query &q, uint32_t seed32, uin
 }
 
 // ------------------------------------------------------------------------------------------------ extended queries
-// Ranges / hero range / ghost cards / second known hand: the range tests depend on the cards, so
-// the host walks the reference's loop literally on an explicit deck list (montecarlo_python.py:121-189) and
-// emits the ACCEPTED draws, all converted to list.pop order: for a hero range the two looked-at cards
-// deck[r1], deck[r2] (both on the unpopped list, l.142-148) become pops r1 and r2 - (r2 > r1).
+// Ranges / ghost cards / any number of known hands, each two cards or a range: the range tests depend on
+// the cards, so the host walks the reference's loop literally on an explicit deck list (montecarlo_python.py:121-189)
+// and emits the ACCEPTED draws, all converted to list.pop order: for a known hand given as a range the two looked-at
+// cards deck[r1], deck[r2] (both on the unpopped list, l.142-148) become pops r1 and r2 - (r2 > r1).
 struct McqExtDeck {
     uint8_t c[52];
     int n;
@@ -123,9 +123,11 @@ static inline bool mcq_ext_in_range(const uint32_t *bits, uint8_t a, uint8_t b) 
     return (bits[i >> 5] >> (i & 31)) & 1u;
 }
 
+/* draws per iteration: two per hand that is not given as cards (range hands and random opponents), then the table */
 static inline uint32_t mcq_ext_draws_per_iteration(const mcq_query &q, const mcq_query_ext &e) {
-    uint32_t fixed = (e.hero_is_range ? 0u : 1u) + (e.known2[0] != 0xFF ? 1u : 0u);
-    return 2u * (q.n_players - fixed) + (5u - q.n_board);
+    uint32_t lists = e.hero_is_range ? 0u : 1u;
+    for (uint32_t k = 0; k < e.n_known; k++) lists += e.known[k].is_range ? 0u : 1u;
+    return 2u * (q.n_players - lists) + (5u - q.n_board);
 }
 
 // returns passes, or UINT64_MAX when a range could not be dealt within max_trials attempts
@@ -135,49 +137,42 @@ static inline uint64_t mcq_replay_parse_ext(const mcq_query &q, const mcq_query_
     original.n = 52;
     for (int i = 0; i < 52; i++) original.c[i] = (uint8_t)i;
     if (e.ghost[0] != 0xFF) { original.remove(e.ghost[0]); original.remove(e.ghost[1]); }
-    const bool has_k2 = e.known2[0] != 0xFF;
-    const uint32_t n_random = q.n_players - (e.hero_is_range ? 0u : 1u) - (has_k2 ? 1u : 0u), n_deal = 5u - q.n_board;
+    const uint32_t n_hands = 1u + e.n_known, n_deal = 5u - q.n_board;
     uint64_t passes = 0;
     for (uint32_t it = 0; it < q.runs; it++) {
         McqExtDeck d = original;
         uint8_t *p = draws + it;
         for (uint32_t i = 0; i < q.n_board; i++) d.remove(q.board[i]);
-        uint32_t h = 0;
-        if (e.hero_is_range) {
+        for (uint32_t h = 0; h < q.n_players; h++) {
+            const bool known = h < n_hands;
+            const bool is_range = known ? (h == 0 ? e.hero_is_range != 0 : e.known[h - 1].is_range != 0) : true;
+            if (!is_range) { /* l.150-161: by value, if it is still there */
+                const uint8_t *cd = h == 0 ? q.hole : e.known[h - 1].cards;
+                d.remove(cd[0]);
+                d.remove(cd[1]);
+                continue;
+            }
+            const uint32_t *set = !known ? e.opp_range : (h == 0 ? e.hero_range : e.known[h - 1].range);
             uint32_t r1, r2, trial = 0;
-            for (;;) {
+            for (;;) { /* l.136-148 / l.165-176: both indices on the UNPOPPED list */
                 if (trial++ >= max_trials) return ~0ull;
                 passes++;
                 r1 = mcq_np_randint(g, (uint32_t)d.n);
                 r2 = mcq_np_randint(g, (uint32_t)d.n - 1);
-                if (r1 != r2 && mcq_ext_in_range(e.hero_range, d.c[r1], d.c[r2])) break;
+                if (r1 != r2 && mcq_ext_in_range(set, d.c[r1], d.c[r2])) break;
             }
             p[0] = (uint8_t)(r1 | 0x80u);
-            p[stride] = (uint8_t)((r2 - (r2 > r1 ? 1u : 0u)) | 0x80u);
-            p += 2 * stride;
-            const uint8_t a = d.c[r1], b = d.c[r2];
-            d.remove(a);
-            d.remove(b);
-            h = 1;
-        } else {
-            d.remove(q.hole[0]);
-            d.remove(q.hole[1]);
-        }
-        if (has_k2) { d.remove(e.known2[0]); d.remove(e.known2[1]); }
-        for (; h < n_random; h++) {
-            uint32_t r1, r2, trial = 0;
-            for (;;) {
-                if (trial++ >= max_trials) return ~0ull;
-                passes++;
-                r1 = mcq_np_randint(g, (uint32_t)d.n);
-                r2 = mcq_np_randint(g, (uint32_t)d.n - 1);
-                if (r1 != r2 && mcq_ext_in_range(e.opp_range, d.c[r1], d.c[r2])) break;
+            if (known) { /* the two cards looked at leave by value: as pops, r1 and then r2 - (r2 > r1) */
+                p[stride] = (uint8_t)((r2 - (r2 > r1 ? 1u : 0u)) | 0x80u);
+                const uint8_t a = d.c[r1], b = d.c[r2];
+                d.remove(a);
+                d.remove(b);
+            } else { /* deck.pop(r1); deck.pop(r2) on the shrunk list (l.178-179) */
+                p[stride] = (uint8_t)(r2 | 0x80u);
+                d.pop((int)r1);
+                d.pop((int)r2);
             }
-            p[0] = (uint8_t)(r1 | 0x80u);
-            p[stride] = (uint8_t)(r2 | 0x80u);
             p += 2 * stride;
-            d.pop((int)r1);
-            d.pop((int)r2);
         }
         for (uint32_t k = 0; k < n_deal; k++) {
             const uint32_t idx = mcq_np_randint(g, (uint32_t)d.n - 1);

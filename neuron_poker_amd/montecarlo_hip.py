@@ -18,10 +18,10 @@ Deliberate differences:
     mode 'replay' a call after seed(s) returns exactly what the reference returns after np.random.seed(s);
   * a hero card that is also on the table is rejected with ValueError (the reference silently swallows it,
     montecarlo_python.py:154-161);
-  * opponent ranges (a fraction of the 169 preflop classes or an explicit set), a hero given as a set of
-    classes, ghost cards and ONE additional known hand are supported (tools/montecarlo_python.py:36-112, 133-181,
-    206-208; bit-exact in mode 'replay'); more than two known hands raise NotImplementedError.  A range that
-    cannot be dealt from the remaining cards raises ValueError where the reference would loop forever.
+  * all of run_montecarlo's arguments are supported: opponent ranges (a fraction of the 169 preflop classes or an
+    explicit set), ghost cards, and any number of known hands, each two cards or a set of classes
+    (tools/montecarlo_python.py:36-112, 133-181, 206-208; bit-exact in mode 'replay').  A range that cannot be
+    dealt from the remaining cards raises ValueError where the reference would loop forever.
 """
 import json
 import os
@@ -130,12 +130,10 @@ class MonteCarlo(object):
         eng = self._engine or _lib.default_engine()
         m = _state["mode"] if mode is None else _MODES[mode]
         players = list(original_player_card_list)
-        if not 1 <= len(players) <= 2:
-            raise NotImplementedError("one or two known hands are supported (hero and one collusion hand)")
+        if not 1 <= len(players) <= 1 + _lib.MAX_KNOWN:
+            raise ValueError("between one and ten known hands")
         hero = players[0]
         hero_is_range = isinstance(hero, (set, frozenset))
-        if len(players) == 2 and isinstance(players[1], (set, frozenset)):
-            raise NotImplementedError("only the first hand may be given as a range")
         opp_bits = _opponent_range_bits(opponent_range)
         plain = not hero_is_range and len(players) == 1 and opp_bits is None and (ghost_cards == '' or ghost_cards is None)
         q = _query(["2C", "2D"] if hero_is_range else list(hero), list(original_table_card_list), player_amount, maxRuns)
@@ -151,8 +149,8 @@ class MonteCarlo(object):
             ghost = None
             if ghost_cards != '' and ghost_cards is not None:
                 ghost = [card_id(ghost_cards[0]), card_id(ghost_cards[1])]
-            ext = _lib.pack_query_ext(1, ghost=ghost,
-                                      known2=[card_id(c) for c in players[1]] if len(players) == 2 else None,
+            known = [_lib.range_bits(h) if isinstance(h, (set, frozenset)) else [card_id(c) for c in h] for h in players[1:]]
+            ext = _lib.pack_query_ext(1, ghost=ghost, known=known,
                                       hero_range=_lib.range_bits(hero) if hero_is_range else None, opp_range=opp_bits)
             s, first = _take_ids(1) if seed is None else (int(seed), 0)
             res = eng.eval_batch_ext(q, ext, s, first_query_id=first, mode=m)[0]

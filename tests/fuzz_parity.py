@@ -43,34 +43,40 @@ CLASSES = [a + a for a in RANKS] + [RANKS[i] + RANKS[j] + t for i in range(13) f
 
 
 def ext_round(g, eng):
-    """Extended queries (opponent range, hero range, ghost cards, second known hand), a batch per call, both modes."""
+    """Extended queries (opponent range, ghost cards, up to four further known hands -- cards or ranges --, hero as
+    a range), a batch per call, both modes."""
     from neuron_poker_amd import _lib
     n = int(g.integers(1, 40))
     q = np.zeros(n, npa.QUERY_DTYPE)
     e = np.zeros(n, npa.QUERY_EXT_DTYPE)
     spec = []
+
+    def some_range(lo, hi):
+        return sorted(g.choice(CLASSES, size=int(g.integers(lo, hi)), replace=False))
+
     for i in range(n):
         nb = int(g.choice([0, 3, 4, 5]))
-        c = [int(x) for x in g.permutation(52)[:8 + nb]]
-        hero_range = sorted(g.choice(CLASSES, size=int(g.integers(25, 90)), replace=False)) if g.random() < 0.3 else None
-        opp = sorted(g.choice(CLASSES, size=int(g.integers(70, 169)), replace=False)) if g.random() < 0.6 else None
+        c = [int(x) for x in g.permutation(52)[:14 + nb]]
+        hero_range = some_range(25, 90) if g.random() < 0.3 else None
+        opp = some_range(70, 169) if g.random() < 0.6 else None
         ghost = c[2:4] if g.random() < 0.3 else None
-        known2 = c[4:6] if g.random() < 0.3 else None
-        npl = int(g.integers(2, 7))
+        n_known = int(g.choice([0, 0, 1, 1, 2, 3, 4]))
+        known = [some_range(30, 100) if g.random() < 0.35 else c[4 + 2 * k:6 + 2 * k] for k in range(n_known)]
+        npl = int(g.integers(max(2, 1 + n_known), 8))
         runs = int(g.choice([1, 64, 65, 300, 1024, 1100]))
-        q[i] = _lib.pack_queries([[0, 1] if hero_range else c[:2]], [c[8:] + [255] * (5 - nb)], npl, runs)[0]
+        q[i] = _lib.pack_queries([[0, 1] if hero_range else c[:2]], [c[14:] + [255] * (5 - nb)], npl, runs)[0]
         if hero_range:
             q["hole"][i] = 0
-        e[i] = _lib.pack_query_ext(1, ghost=ghost, known2=known2,
+        e[i] = _lib.pack_query_ext(1, ghost=ghost, known=[h if isinstance(h[0], int) else _lib.range_bits(h) for h in known],
                                    hero_range=_lib.range_bits(hero_range) if hero_range else None,
                                    opp_range=_lib.range_bits(opp) if opp else None)[0]
-        spec.append((hero_range if hero_range else c[:2], c[8:], npl, runs, known2, ghost, opp))
+        spec.append((hero_range if hero_range else c[:2], c[14:], npl, runs, known, ghost, opp))
     seed, first = int(g.integers(0, 2 ** 31)), int(g.integers(0, 2 ** 20))
     for mode, om in ((npa.MODE_PHILOX, O.MODE_CTR), (npa.MODE_REPLAY_MT19937, O.MODE_MT)):
         got = eng.eval_batch_ext(q, e, seed, first_query_id=first, mode=mode).view(np.uint64).reshape(-1, 13)
-        for i, (hero, board, npl, runs, known2, ghost, opp) in enumerate(spec):
+        for i, (hero, board, npl, runs, known, ghost, opp) in enumerate(spec):
             s_i = (seed + first + i) & 0xFFFFFFFF if om == O.MODE_MT else seed
-            want = O.run_ex(om, hero, board, npl, runs, s_i, qid=first + i, known2=known2, ghost=ghost, opp_range=opp)["tallies"]
+            want = O.run_ex(om, hero, board, npl, runs, s_i, qid=first + i, known=known, ghost=ghost, opp_range=opp)["tallies"]
             assert np.array_equal(got[i], want), ("ext", mode, i, spec[i])
     return n, int(q["runs"].astype(np.int64).sum())
 

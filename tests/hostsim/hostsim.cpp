@@ -162,17 +162,30 @@ void hs_mt_words(uint32_t seed, uint32_t n, uint32_t *out) {
 }
 
 // ---- extended queries (ranges, hero range, ghost cards, second known hand)
-static void ext_words(const mcq_query_ext *e, McqExtWords &w) { memcpy(w.w, e, 64); }
 
 extern "C" int hs_run_ext(int replay, const mcq_query *q, const mcq_query_ext *e, uint64_t seed, uint64_t qid,
                           mcq_result *out) {
-    McqExtWords ew;
-    ext_words(e, ew);
+    const McqExtRec er = {reinterpret_cast<const uint32_t *>(e)};
     const McqQueryWords qw = mcq_query_words(*q);
-    if (!mcq_query_ext_valid(qw, ew)) return MCQ_EINVAL;
+    if (!mcq_query_ext_valid(qw, er)) return MCQ_EINVAL;
     const McqTables &t = luts();
     McqExtCtx qc;
-    mcq_ext_ctx(qw, ew, qc);
+    mcq_ext_ctx(qw, er, qc);
+    McqExtWaveCtx wc;
+    memset(&wc, 0, sizeof wc);
+    for (uint32_t h = 0; h < qc.n_hands; h++) wc.hand[h] = mcq_ext_hand(qw, er, h);
+    /* the candidate lists, as mcq_ext_lists_kernel lays them out */
+    const uint32_t n_lists = mcq_ext_n_lists(qw, er);
+    std::vector<uint16_t> lists((size_t)(n_lists ? n_lists : 1) * MCQ_EXT_LIST_STRIDE);
+    for (uint32_t li = 0; li < n_lists; li++) {
+        uint64_t U;
+        uint32_t set_off, cnt = 0;
+        mcq_ext_list_plan(qw, er, li, U, set_off);
+        for (uint32_t c = 0; c < 2704u; c++)
+            if (mcq_ext_candidate(U, er.w + set_off, c)) lists[(size_t)li * MCQ_EXT_LIST_STRIDE + cnt++] = (uint16_t)((c / 52u) | ((c % 52u) << 8));
+        wc.cnt[li] = cnt;
+        if (cnt == 0 && !replay) return MCQ_EINVAL;
+    }
     McqCard cards[64];
     for (uint32_t c = 0; c < 64; c++) cards[c] = mcq_card(c < 52 ? c : 0);
     memset(out, 0, sizeof(*out));
@@ -189,7 +202,7 @@ extern "C" int hs_run_ext(int replay, const mcq_query *q, const mcq_query_ext *e
         for (uint32_t it = 0; it < q->runs; it++) {
             McqExtReplayDraws dr = {draws.data() + it, stride};
             McqLaneAcc acc = {0, 0, 0};
-            mcq_iteration_ext(qc, dr, cards, t.sel8, ew.w + 8, ew.w + 2, ids, 1, t.tf, t.tops, t.sd, acc);
+            mcq_iteration_ext(qc, wc, dr, cards, t.sel8, lists.data(), ids, 1, t.tf, t.tops, t.sd, acc);
             acc.passes = 0;
             fold(acc, out);
         }
@@ -203,7 +216,7 @@ extern "C" int hs_run_ext(int replay, const mcq_query *q, const mcq_query_ext *e
         McqLaneAcc acc = {0, 0, 0};
         for (uint32_t j = 0; j < MCQ_STREAM_ITERS; j++) {
             if ((uint64_t)s * MCQ_STREAM_ITERS + j >= q->runs) break;
-            if (!mcq_iteration_ext(qc, dr, cards, t.sel8, ew.w + 8, ew.w + 2, ids, 1, t.tf, t.tops, t.sd, acc))
+            if (!mcq_iteration_ext(qc, wc, dr, cards, t.sel8, lists.data(), ids, 1, t.tf, t.tops, t.sd, acc))
                 return MCQ_EINVAL;
         }
         fold(acc, out);

@@ -292,9 +292,8 @@ def test_dropin_module_matches_reference_call_surface(eng):
         mh.get_equity({"AS", "KS"}, {"AS", "2C", "3C"}, 2, 100)
     with pytest.raises(ValueError):
         mh.get_equity({"AS", "Kx"}, set(), 2, 100)
-    with pytest.raises(NotImplementedError):
-        mh.MonteCarlo(eng).run_montecarlo([["AS", "KS"], ["2C", "2D"], ["3C", "3D"]], [], 4, 1, maxRuns=10, timeout=0,
-                                          ghost_cards="")
+    with pytest.raises(ValueError):   # eleven known hands
+        mh.MonteCarlo(eng).run_montecarlo([["AS", "KS"]] + [["2C", "2D"]] * 10, [], 10, 1, maxRuns=10, timeout=0, ghost_cards="")
 
 
 def test_numpy_stream_coupling_on_gpu(eng):
@@ -350,7 +349,7 @@ def test_ranges_ghost_cards_known_hands(eng):
     with open(os.path.join(os.path.dirname(G), "..", "neuron_poker_amd", "preflop_classes.json")) as f:
         order = json.load(f)
     for t in rows:
-        pl = [set(p) if (i == 0 and t["hero_is_range"]) else p for i, p in enumerate(t["players"])]
+        pl = [p if O._is_cards(p) else set(p) for p in t["players"]]
         rng = set(t["opponent_range"]) if isinstance(t["opponent_range"], list) else t["opponent_range"]
         sim = mh.MonteCarlo(eng)
         eq, _ = sim.run_montecarlo(pl, t["board"], t["n_players"], 1, maxRuns=t["runs"], timeout=0,
@@ -365,9 +364,8 @@ def test_ranges_ghost_cards_known_hands(eng):
         else:
             take = int(169 * rng)
             opp = None if take == 0 or take >= 169 else order[-take:]
-        exp = O.run_ex(O.MODE_CTR, t["players"][0], t["board"], t["n_players"], 1500, 31,
-                       known2=t["players"][1] if len(t["players"]) > 1 else None, ghost=t["ghost"] or None,
-                       opp_range=opp)["tallies"]
+        exp = O.run_ex(O.MODE_CTR, t["players"][0], t["board"], t["n_players"], 1500, 31, known=t["players"][1:],
+                       ghost=t["ghost"] or None, opp_range=opp)["tallies"]
         assert np.array_equal(np.frombuffer(sim.result.tobytes(), np.uint64), exp), t
     # tests/test_montecarlo_python.py:215-232: 12.8 % and 77.8 % within 3 points
     board = ["3D", "9H", "AS", "7S", "QH"]

@@ -151,16 +151,17 @@ def _ext_case(t):
     if t["hero_is_range"]:
         q = q.copy()
         q[0:2] = 0
-    ext = npa.pack_query_ext(1, ghost=[O.card_id(c) for c in t["ghost"]] if t["ghost"] else None,
-                             known2=[O.card_id(c) for c in pl[1]] if len(pl) > 1 else None,
+    known = [[O.card_id(c) for c in h] if O._is_cards(h) else npa.range_bits(h) for h in pl[1:]]
+    ext = npa.pack_query_ext(1, ghost=[O.card_id(c) for c in t["ghost"]] if t["ghost"] else None, known=known,
                              hero_range=npa.range_bits(pl[0]) if t["hero_is_range"] else None,
                              opp_range=npa.range_bits(opp) if opp is not None else None)
-    kw = dict(known2=pl[1] if len(pl) > 1 else None, ghost=t["ghost"] or None, opp_range=opp)
+    kw = dict(known=pl[1:], ghost=t["ghost"] or None, opp_range=opp)
     return q, ext, kw
 
 
 def test_extended_queries_replay_equals_reference_and_ctr_equals_oracle():
-    """ranges, hero range, ghost cards, second known hand through the product's lane code."""
+    """ranges, ghost cards, any number of known hands (cards or ranges) through the product's lane code:
+    parity mode == the reference's own seeded runs, production mode == the oracle's implementation of MCQ-CTR v3x."""
     with open(os.path.join(G, "ext_tallies.json")) as f:
         rows = json.load(f)
     for t in rows:
