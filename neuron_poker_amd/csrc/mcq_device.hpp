@@ -701,6 +701,8 @@ MCQ_HD void mcq_iteration(const McqQueryCtx &qc, Draws &dr, const McqCard *base1
 // opponent is dealt A and, as deck.pop(r1); deck.pop(r2) deal (:178-179), B if B lies below A, else the card that
 // FOLLOWS B in the deck (the reference's quirk: the range test looks at the unpopped list).  With the top quarter of
 // the classes a trial of the reference's loop succeeds one time in ~25, a trial here three times in four.
+// Opponents to whom every class is allowed are dealt by index exactly as the plain path deals them (MCQ-CTR v3, one
+// word per pair), so an extension record that restricts nothing gives the plain path's tallies bit for bit.
 #define MCQ_EXT_WORDS 76u         /* sizeof(mcq_query_ext) / 4 */
 #define MCQ_EXT_MAX_LISTS 11u     /* ten known hands as ranges + the opponents */
 #define MCQ_EXT_LIST_STRIDE 2704u /* entries reserved per candidate list (52 * 52 >= 52 * 51) */
@@ -736,9 +738,17 @@ MCQ_HD uint32_t mcq_ext_hand(const McqQueryWords &q, const McqExtRec &e, uint32_
 }
 MCQ_HD uint32_t mcq_ext_hand_set(const McqExtRec &e, uint32_t h) { return h == 0 ? e.hero_set() : e.known_set(h - 1u); }
 
-/* candidate lists of a query: one per known hand given as a range, in hand order, then one for the opponents */
+/* opponents unrestricted (every one of the 169 classes allowed)? */
+MCQ_HD bool mcq_ext_opp_all(const McqExtRec &e) {
+    uint32_t all = e.w[e.opp_set() + 5u] | ~0x1FFu;
+    for (uint32_t i = 0; i < 5; i++) all &= e.w[e.opp_set() + i];
+    return all == 0xFFFFFFFFu;
+}
+
+/* candidate lists of a query: one per known hand given as a range, in hand order, then one for the opponents
+ * unless every class is allowed to them (they are then dealt by index, exactly as the plain path deals) */
 MCQ_HD uint32_t mcq_ext_n_lists(const McqQueryWords &q, const McqExtRec &e) {
-    uint32_t n = q.n_players() > 1u + e.n_known() ? 1u : 0u;
+    uint32_t n = q.n_players() > 1u + e.n_known() && !mcq_ext_opp_all(e) ? 1u : 0u;
     for (uint32_t h = 0; h <= e.n_known(); h++) n += mcq_ext_hand(q, e, h) >> 16;
     return n;
 }
@@ -819,6 +829,7 @@ MCQ_HD bool mcq_query_ext_valid(const McqQueryWords &q, const McqExtRec &e) {
 struct McqExtCtx { /* wave-uniform */
     uint32_t deck_lo, deck_hi;            /* 52 cards minus ghost and table */
     uint32_t n_players, n_hands, n_deal, runs; /* n_hands = 1 + n_known */
+    bool opp_all;                         /* every class allowed to the opponents: dealt by index as in the plain path */
     McqBoard board;
 };
 struct McqExtWaveCtx { /* per wave, in LDS: what the iteration indexes at run time */
@@ -837,6 +848,7 @@ MCQ_HD void mcq_ext_ctx(const McqQueryWords &q, const McqExtRec &e, McqExtCtx &c
     c.n_hands = 1u + e.n_known();
     c.n_deal = 5u - q.n_board();
     c.runs = q.runs();
+    c.opp_all = mcq_ext_opp_all(e);
 }
 
 /* deck mask helpers (52 bits in two words) */
@@ -863,6 +875,14 @@ struct McqExtCtrDraws {
     uint32_t w;
     MCQ_HDM uint32_t pick(uint32_t n) { return mcq_mulhi(rng.next(), n); } /* a candidate of a list of n */
     MCQ_HDM void pair(uint32_t &, uint32_t &) {}
+    MCQ_HDM void index_pair(uint32_t L, uint32_t &r1, uint32_t &r2) { /* MCQ-CTR v3 as the plain path: McqCtrDrawsT::pair */
+        const uint32_t dd = L - 1u;
+        const uint32_t u = rng.next();
+        const uint32_t a = mcq_mulhi(u, dd);
+        const uint32_t c = mcq_mulhi(u * dd, dd);
+        r1 = a == c ? dd : a;
+        r2 = c;
+    }
     MCQ_HDM uint32_t table(uint32_t k, uint32_t n) {
         if ((k & 1u) == 0) {
             const uint32_t u = rng.next();
@@ -877,6 +897,7 @@ struct McqExtReplayDraws { /* accepted draws from the host, all in list.pop orde
     const uint8_t *p;
     uint64_t stride;
     MCQ_HDM uint32_t pick(uint32_t) { return 0; }
+    MCQ_HDM void index_pair(uint32_t, uint32_t &, uint32_t &) {}
     MCQ_HDM void pair(uint32_t &r1, uint32_t &r2) {
         r1 = p[0] & 0x7Fu; /* the host stores every draw as r | 0x80 */
         r2 = p[stride] & 0x7Fu;
@@ -910,6 +931,12 @@ MCQ_HD bool mcq_iteration_ext(const McqExtCtx &qc, const McqExtWaveCtx &wc, Draw
         } else if (Draws::kReplay) {
             uint32_t r1, r2;
             dr.pair(r1, r2);
+            c1 = mcq_select_pop(dlo, dhi, r1, sel8);
+            c2 = mcq_select_pop(dlo, dhi, r2, sel8);
+        } else if (!known && qc.opp_all) { /* no range to respect: one word, never re-drawn, popped in turn (l.178-179) */
+            uint32_t r1, r2;
+            acc.passes++;
+            dr.index_pair(mcq_popc(dlo) + mcq_popc(dhi), r1, r2);
             c1 = mcq_select_pop(dlo, dhi, r1, sel8);
             c2 = mcq_select_pop(dlo, dhi, r2, sel8);
         } else {

@@ -588,8 +588,9 @@ static int in_range(const uint32_t *bits, uint8_t a, uint8_t b) {
  * a trial takes one word u, (A, B) = P'[mulhi32(u, len(P'))], and is accepted iff A and B are still in the deck and
  * B is not its highest card; passes counts trials.  A range hand leaves by value; an opponent is dealt A and, as
  * deck.pop(r1); deck.pop(r2) deal, B if B lies below A, else the card that follows B in the deck.  Table cards as
- * in the plain mode (two per word, never the highest card).  65536 failed trials in a row = the range cannot be
- * dealt: -2. */
+ * in the plain mode (two per word, never the highest card).  Opponents to whom every class is allowed are dealt by
+ * index exactly as the plain mode deals them (one word per pair, never re-drawn), so a query that restricts nothing
+ * gives the plain mode's tallies.  65536 failed trials in a row = the range cannot be dealt: -2. */
 #define EX_MAX_TRIALS 65536u
 int mcqo_run_ex2(int mode, int n_known, const uint8_t *known_cards, const uint32_t *known_ranges, const uint8_t *ghost,
                  const uint8_t *board, int nb, int n_players, uint32_t runs, uint64_t seed, uint64_t qid,
@@ -611,6 +612,13 @@ int mcqo_run_ex2(int mode, int n_known, const uint8_t *known_cards, const uint32
     deck_t original;
     deck_init(&original);
     if (ghost) { deck_remove(&original, ghost[0]); deck_remove(&original, ghost[1]); } /* l.206-208 */
+    /* opponents to whom every class is allowed are dealt by index, as the plain mode deals them */
+    int opp_all = opp_range == 0;
+    if (opp_range) {
+        uint32_t all = opp_range[5] | ~0x1FFu;
+        for (int i = 0; i < 5; i++) all &= opp_range[i];
+        opp_all = all == 0xFFFFFFFFu;
+    }
     /* production mode: the candidate lists (index n_known = the opponents') */
     static __thread uint16_t plist[11][2704];
     uint32_t pcount[11];
@@ -620,7 +628,7 @@ int mcqo_run_ex2(int mode, int n_known, const uint8_t *known_cards, const uint32
         for (int i = 0; i < nb; i++) u &= ~(1ull << board[i]);
         for (int h = 0; h <= n_known; h++) {
             const uint32_t *set = h < n_known ? known_ranges + 6 * h : opp_range;
-            const int wanted = h < n_known ? known_cards[2 * h] == 0xFF : n_players > n_known;
+            const int wanted = h < n_known ? known_cards[2 * h] == 0xFF : (n_players > n_known && !opp_all);
             pcount[h] = 0;
             if (wanted)
                 for (int a = 0; a < 52; a++)
@@ -666,6 +674,12 @@ int mcqo_run_ex2(int mode, int n_known, const uint8_t *known_cards, const uint32
                     A = deck_pop(&d, (int)r1);
                     B = deck_pop(&d, (int)r2);
                 }
+            } else if (!is_known && opp_all) { /* MCQ-CTR v3, one word, never re-drawn */
+                uint32_t dd = (uint32_t)d.n - 1, u = xo_next(&xo);
+                uint32_t a = (uint32_t)(((uint64_t)u * dd) >> 32), c = (uint32_t)(((uint64_t)(uint32_t)(u * dd) * dd) >> 32);
+                out[1]++;
+                A = deck_pop(&d, (int)(a != c ? a : dd));
+                B = deck_pop(&d, (int)c);
             } else {
                 const int li = is_known ? p : n_known;
                 for (uint32_t trial = 0;; trial++) {

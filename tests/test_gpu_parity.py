@@ -375,6 +375,12 @@ def test_ranges_ghost_cards_known_hands(eng):
     b.run_montecarlo([{"AKO", "AA"}], board, 3, 1, maxRuns=100000, timeout=0, ghost_cards="", opponent_range=0.25, seed=2)
     assert abs(100 * a.equity - 12.8) < 3 and abs(100 * b.equity - 77.8) < 3
     assert abs(sum(b.winnerCardTypeList.values()) - b.equity) < 1e-4
+    # an extension record that restricts nothing gives the plain path's tallies (unrestricted opponents are dealt by
+    # index exactly as there); with ghost cards / known hands the unrestricted opponents still cost one word each
+    g = np.random.default_rng(8)
+    cards = np.array([g.permutation(52)[:7] for _ in range(64)], np.uint8)
+    q = npa.pack_queries(cards[:, :2], np.full((64, 5), 255, np.uint8), 1 + np.arange(64) % 10, 1 + 37 * np.arange(64))
+    assert np.array_equal(u64(eng.eval_batch_ext(q, npa.pack_query_ext(64), 9, first_query_id=3)), u64(eng.eval_batch(q, 9, first_query_id=3)))
     # a range that cannot be dealt (both remaining aces are dead) raises instead of hanging
     with pytest.raises(ValueError):
         mh.MonteCarlo(eng).run_montecarlo([["AS", "AH"]], ["AD", "AC", "2C"], 2, 1, maxRuns=100, timeout=0,
