@@ -366,6 +366,27 @@ def main():
             extras["configs[2]_replay"] = {"call_ms_host_buffers": 1e3 * dt, "kernel_ms_parse_plus_eval": eng.last_kernel_ms,
                                            "hand_evals_per_s": 4096 * 3 * 50000 / dt,
                                            "mt19937_words_per_s": 4096 * 50000 * 12.8 / dt}
+        # run_montecarlo's other arguments: opponents restricted to the top quarter of the preflop classes
+        # (the range the reference's own test uses, tests/test_montecarlo_python.py:215-222), 2048 states x 6 players x
+        # 20k iterations through mcq_eval_batch_ext / mcq_eval_ext_kernel (candidate lists instead of the re-draw loop)
+        with open(os.path.join(ROOT, "neuron_poker_amd", "preflop_classes.json")) as f:
+            order = json.load(f)
+        qx = npa.pack_queries(hole[:2048], board[:2048], 6, 20000) if B >= 2048 else None
+        if qx is not None:
+            ex = npa.pack_query_ext(2048, opp_range=npa.range_bits(order[-int(169 * 0.25):]))
+            eng.eval_batch_ext(qx, ex, 1)
+            t1 = time.perf_counter()
+            for i in range(3):
+                eng.eval_batch_ext(qx, ex, i)
+            dt = (time.perf_counter() - t1) / 3
+            kms = eng.last_kernel_ms
+            ops = 2048.0 * 20000 * alg_ops_per_iteration(6, 0)
+            extras["ext_opponents_top25pct_2048x6x20k"] = {
+                "call_ms_host_buffers": 1e3 * dt, "kernel_ms": kms, "hand_evals_per_s": 2048 * 6 * 20000 / dt,
+                "roofline": {"bound": "valu", "kernel": "mcq_eval_ext_kernel<0>", "achieved": ops / (kms * 1e-3) / 1e12,
+                             "peak": PEAK_VALU_TOPS, "unit": "Tops/s (int32 lane-ops)",
+                             "frac": ops / (kms * 1e-3) / 1e12 / PEAK_VALU_TOPS,
+                             "frac_basis": "model: the plain path's 1242 lane-ops per iteration (SURVEY 8d)"}}
         # BASELINE configs[3] (the 8-GPU config) on this one GPU: 65 536 states, flop / turn tables alternating, 6 players,
         # 20k iterations, host buffers; one rank of 8 would take an eighth of the queries
         g3 = np.random.default_rng(65536)

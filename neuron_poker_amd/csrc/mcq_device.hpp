@@ -603,23 +603,44 @@ MCQ_HD uint32_t mcq_draw_opp(uint32_t rp, uint32_t (&H)[5]) {
     return mcq_opaque(k); /* materialise k so that the table address is one shift-add */
 }
 
-// table draw number K (0..4): scans the opponents' holes (NREGS registers) and the K earlier table holes.
+// Count only: k += number of holes of the register with t <= r (the register is not updated).
+MCQ_HD void mcq_hole_count(uint32_t rb, uint32_t h, uint32_t &k) {
+#ifdef MCQ_ABLATE_HOLES /* diagnostic timing build: wrong results */
+    k += (rb ^ h) & 1u;
+    return;
+#endif
+    k = mcq_popc((rb - h) & 0x80808080u) + k; /* v_sub, v_and, v_bcnt (with its add) */
+}
+
+// table draw number K (0..4).  Two levels, because the table is dealt after ALL opponents (l.215-217): the K earlier
+// table holes live in their own register hb, in coordinates of the current list, and are counted and moved as in
+// mcq_hole_reg; that gives the draw's position p in the list as it was when the opponents had been dealt -- and in
+// THAT list the opponents' holes (NREGS registers) have fixed coordinates from here on: they are only counted
+// against p (3 instructions per register instead of 5) and never moved again.
 // NREGS is a template parameter: with a run-time bound the compiler scans all five registers and discards the
 // unused ones with selects (7 instructions per register instead of 0).
 template <int K, int NREGS>
-MCQ_HD uint32_t mcq_draw_table(uint32_t rp, uint32_t (&H)[5], uint32_t &hb) {
-    uint32_t k = rp;
-    const uint32_t rb = mcq_splat_byte(rp);
+MCQ_HD uint32_t mcq_draw_table(uint32_t rp, const uint32_t (&H)[5], uint32_t &hb) {
+    uint32_t p = rp; /* r | 0x80 */
+    if (K > 0) {
+        const uint32_t rb = mcq_splat_byte(rp);
+        mcq_hole_reg(rb, hb, p);
+        if (K < 4) mcq_hole_put<K>(hb, rb); /* the hole of a fifth table card is never looked at */
+    } else {
+        mcq_hole_put<0>(hb, rp);
+    }
+    uint32_t k = p; /* position among the cards the opponents left, still | 0x80 */
+    if (NREGS > 0) {
+        const uint32_t pb = mcq_splat_byte(p);
 #pragma unroll
-    for (int i = 0; i < NREGS; i++) mcq_hole_reg(rb, H[i], k);
-    if (K > 0) mcq_hole_reg(rb, hb, k);
-    if (K < 4) mcq_hole_put<K>(hb, rb); /* the hole of a fifth table card is never looked at */
+        for (int i = 0; i < NREGS; i++) mcq_hole_count(pb, H[i], k);
+    }
     return mcq_opaque(k);
 }
 
 // the missing table cards (montecarlo_python.py:185-189) after opponents whose holes fill NREGS registers
 template <int NREGS, class Draws>
-MCQ_HD void mcq_deal_table(const McqQueryCtx &qc, Draws &dr, const McqCard *base128, uint32_t (&H)[5], uint32_t L,
+MCQ_HD void mcq_deal_table(const McqQueryCtx &qc, Draws &dr, const McqCard *base128, const uint32_t (&H)[5], uint32_t L,
                            McqBoard &b) {
     uint32_t hb = MCQ_HOLE_SENTINEL;
     const uint32_t n_deal = mcq_opaque_uniform(qc.n_deal); /* scalar compares, no lane masks kept in SGPR pairs */
