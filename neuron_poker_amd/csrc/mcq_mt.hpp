@@ -62,7 +62,10 @@ __device__ __forceinline__ uint32_t mcq_mt_shfl(uint32_t v, uint32_t idx) {
 template <class T>
 static inline uint64_t mcq_mt_host_ballot(const T (&a)[64]) {
     uint64_t m = 0;
-    for (uint32_t i = 0; i < 64; i++) m |= (uint64_t)(a[i] ? 1u : 0u) << i;
+    for (uint32_t i = 0; i < 64; i++) {
+        const uint64_t bit = a[i] ? 1u : 0u; /* (in one expression, g++ 11 -fsanitize=shift,bounds yields all ones) */
+        m |= bit << i;
+    }
     return m;
 }
 #endif
