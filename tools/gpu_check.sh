@@ -14,7 +14,7 @@ try:
     d = [json.loads(l) for l in open("gpurun_out/bench_$TAG.json") if l.startswith("{")][-1]
     print("value %.4g evals/s  ms/step %.3f  kernel_ms %.3f  frac %.3f" % (d["value"], d["ms_per_step"], d["roofline"]["kernel_ms"], d["roofline"]["frac"]))
     for k, v in d.get("other_configs", {}).items():
-        print(k, {a: round(b, 4) for a, b in v.items()})
+        print(k, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in v.items() if not isinstance(b, dict)})
 except Exception as e:
     print("bench parse failed", e)
     print(open("gpurun_out/bench_$TAG.err").read()[-2000:])
