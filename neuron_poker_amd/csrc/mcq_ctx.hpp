@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/mcq.h"
+#include "mcq_layout.hpp"
 
 struct McqTables;
 
@@ -132,8 +133,8 @@ struct mcq_ctx {
     DevBuf d_done;                /* block counter of the one-launch path */
     uint32_t direct_ticket = 0;   /* value the kernel raises the flag in h_flag to */
     bool direct_poll = true;      /* pick the rows up at the flag instead of synchronising the stream (MCQ_DIRECT_POLL) */
-    std::vector<uint8_t> direct_lg; /* scratch of the one-launch path's layout */
-    std::vector<uint32_t> direct_fill, direct_sorted;
+    McqDirectLayout direct_layout;      /* the one-launch path's layout of the current call */
+    std::vector<uint64_t> direct_cost;
 };
 
 /* shared between the translation units (defined in mcq_host.cpp) */

@@ -530,55 +530,26 @@ static int eval_host_philox(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t s
          * about 16 waves per CU in all, every query a power-of-two number of them in proportion to its cost (so all
          * waves carry about the same work), the waves of a query side by side in one block. */
         const uint32_t mode = c->law == MCQ_LAW_UNIFORM ? MCQ_INTERNAL_MODE_UNIFORM : MCQ_MODE_PHILOX;
-        const uint64_t want_waves = 16ull * (uint64_t)c->n_cu;
-        std::vector<uint8_t> &lg = c->direct_lg;
-        lg.resize(n);
-        uint64_t waves = 0;
-        size_t count[5] = {0, 0, 0, 0, 0};
-        for (size_t i = 0; i < n; i++) {
-            const uint64_t ci = (i + 1 < n ? prefix[i + 1] : cost) - prefix[i];
-            uint32_t l = 0;
-            while (l < c->split_max && (2ull << l) * cost <= ci * want_waves) l++; /* 2^l <= share of the waves */
-            if (ci == 0) l = 0;
-            lg[i] = (uint8_t)l;
-            count[l]++;
-            waves += 1ull << l;
-        }
-        /* Blocks: as many as there are CUs (or queries).  The queries, sorted by descending wave count, are dealt to
-         * the blocks in turn: every block carries about the same number of waves, and inside a block the groups come
-         * in descending order, hence aligned to their size and never across a round's 16 waves. */
-        const uint32_t grid = (uint32_t)(n < (size_t)c->n_cu ? n : (size_t)c->n_cu);
-        std::vector<uint32_t> &sorted = c->direct_sorted, &fill = c->direct_fill;
-        sorted.resize(n);
-        {
-            size_t at[5], pos = 0;
-            for (int l = 4; l >= 0; l--) { at[l] = pos; pos += count[l]; }
-            for (size_t i = 0; i < n; i++) sorted[at[lg[i]]++] = (uint32_t)i; /* counting sort, wide queries first */
-        }
-        fill.assign(grid, 0u); /* waves placed in each block */
-        for (size_t k = 0; k < n; k++) fill[k % grid] += 1u << lg[sorted[k]];
-        uint32_t most = 0;
-        for (uint32_t b = 0; b < grid; b++) most = fill[b] > most ? fill[b] : most;
-        const uint32_t rounds = (most + 15u) / 16u;
-        const size_t a_words = (size_t)rounds * grid * 16u;
+        std::vector<uint64_t> &qcost = c->direct_cost;
+        qcost.resize(n);
+        for (size_t i = 0; i < n; i++) qcost[i] = (i + 1 < n ? prefix[i + 1] : cost) - prefix[i];
+        McqDirectLayout &lay = c->direct_layout;
+        mcq_direct_layout(qcost.data(), n, (uint32_t)c->n_cu, c->split_max, lay);
+        const uint32_t grid = lay.grid, rounds = lay.rounds;
+        const size_t a_words = lay.slot_qi.size();
         if (a_words > a_cap) return mcq_fail(MCQ_EDEVICE, who, "internal: wave layout larger than its bound");
         /* behind the caller's records and the prefix: one record copy per wave (its reserved bytes carry log2 of the
          * query's wave count and the wave's cut number), then one query index per wave */
         mcq_query *work_rec = reinterpret_cast<mcq_query *>(static_cast<char *>(c->h_q.p) + a_off);
         uint32_t *work_qi = reinterpret_cast<uint32_t *>(work_rec + a_words);
-        for (size_t k = 0; k < a_words; k++) work_qi[k] = MCQ_DIRECT_IDLE;
-        fill.assign(grid, 0u);
-        for (size_t k = 0; k < n; k++) {
-            const uint32_t i = sorted[k], l = lg[i], b = (uint32_t)(k % grid), at = fill[b];
-            fill[b] = at + (1u << l);
-            const size_t dst = ((size_t)(at >> 4) * grid + b) * 16u + (at & 15u); /* round at / 16, wave at % 16 */
-            for (uint32_t sub = 0; sub < (1u << l); sub++) {
-                mcq_query r = q[i];
-                r.reserved[0] = (uint8_t)l;
-                r.reserved[1] = (uint8_t)sub;
-                work_rec[dst + sub] = r;
-                work_qi[dst + sub] = i;
-            }
+        memcpy(work_qi, lay.slot_qi.data(), a_words * sizeof(uint32_t));
+        for (size_t k = 0; k < a_words; k++) {
+            const uint32_t i = lay.slot_qi[k];
+            if (i == MCQ_LAYOUT_IDLE) continue;
+            mcq_query r = q[i];
+            r.reserved[0] = lay.lg[i];
+            r.reserved[1] = lay.slot_sub[k];
+            work_rec[k] = r;
         }
         if (!c->h_flag.p) {
             HIP_TRY(c->h_flag.reserve(64));
@@ -586,7 +557,8 @@ static int eval_host_philox(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t s
             HIP_TRY(c->d_done.reserve(64));
             HIP_TRY(hipMemsetAsync(c->d_done.p, 0, 64, c->stream));
         }
-        const uint32_t ticket = ++c->direct_ticket;
+        if (++c->direct_ticket == 0u) c->direct_ticket = 1u; /* 0 is the flag's resting value */
+        const uint32_t ticket = c->direct_ticket;
         const int slot = (int)(c->n_timed % mcq_ctx::kRing);
         c->last_ms = 0.f;
         static const bool trace = getenv("MCQ_TRACE") != nullptr; /* phase times of this path on stderr (tuning) */
@@ -594,7 +566,7 @@ static int eval_host_philox(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t s
         const char *dev_rec = static_cast<const char *>(c->h_q.dev) + a_off;
         HIP_TRY(mcq_launch_eval_direct((int)mode, dev_rec,
                                        reinterpret_cast<const uint32_t *>(dev_rec + a_words * sizeof(mcq_query)), rounds,
-                                       count[0] != n ? 1u : 0u, (mcq_result *)c->h_res.dev, seed, first_query_id, c->d_luts, grid,
+                                       lay.merge ? 1u : 0u, (mcq_result *)c->h_res.dev, seed, first_query_id, c->d_luts, grid,
                                        (uint32_t *)c->d_done.p, (uint32_t *)c->h_flag.dev, ticket, c->stream, c->ev0[slot],
                                        c->ev1[slot]));
         c->n_timed++;
@@ -621,7 +593,7 @@ static int eval_host_philox(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t s
             float kms = 0.f;
             (void)mcq_kernel_times(c, &kms, 1);
             fprintf(stderr, "mcq direct n=%zu waves=%llu grid=%u rounds=%u: launch %.1f us, wait %.1f us (%s), copy out %.1f us, "
-                    "kernel %.1f us\n", n, (unsigned long long)waves, grid, rounds, us(t0, t1), us(t1, t2),
+                    "kernel %.1f us\n", n, (unsigned long long)lay.waves, grid, rounds, us(t0, t1), us(t1, t2),
                     seen ? "flag" : "stream sync", us(t2, std::chrono::steady_clock::now()), 1e3 * kms);
         }
         return MCQ_OK;

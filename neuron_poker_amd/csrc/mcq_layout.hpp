@@ -1,0 +1,72 @@
+// mcq_layout.hpp -- the host's layout of a batch of small queries for mcq_eval_direct_kernel (pure host code, no
+// HIP: tests/hostsim checks its invariants where no GPU exists).
+//
+// Every query gets a power-of-two number of waves in proportion to its cost, about `want_waves` in all, so that all
+// waves carry about the same work whatever the mix of players and table cards; the waves of a query sit side by side
+// in one block.  The queries, sorted by descending wave count, are dealt to the blocks in turn: every block carries
+// about the same number of waves, and inside a block the groups come in descending order, hence aligned to their
+// size and never across a round's 16 waves.  Wave `v` of block `b` in round `r` works on slot (r * grid + b) * 16 + v.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include <vector>
+
+#define MCQ_LAYOUT_IDLE 0xFFFFFFFFu
+#define MCQ_LAYOUT_WAVES 16u /* waves of a block */
+
+struct McqDirectLayout {
+    uint32_t grid = 0, rounds = 0;
+    bool merge = false;            /* some query has more than one wave */
+    uint64_t waves = 0;
+    std::vector<uint8_t> lg;       /* per query: log2 of its wave count */
+    std::vector<uint32_t> slot_qi; /* per slot: query index or MCQ_LAYOUT_IDLE */
+    std::vector<uint8_t> slot_sub; /* per slot: the wave's cut number within its query */
+    std::vector<uint32_t> sorted, fill; /* scratch */
+};
+
+/* cost[i]: scheduling cost of query i (0 = nothing to do); max_lg: finest cut allowed (waves per query <= 2^max_lg <= 16) */
+static inline void mcq_direct_layout(const uint64_t *cost, size_t n, uint32_t n_cu, uint32_t max_lg, McqDirectLayout &L) {
+    const uint64_t want_waves = (uint64_t)MCQ_LAYOUT_WAVES * n_cu;
+    uint64_t total = 0;
+    for (size_t i = 0; i < n; i++) total += cost[i];
+    if (max_lg > 4u) max_lg = 4u;
+    L.lg.resize(n);
+    L.waves = 0;
+    size_t count[5] = {0, 0, 0, 0, 0};
+    for (size_t i = 0; i < n; i++) {
+        uint32_t l = 0;
+        while (l < max_lg && (2ull << l) * total <= cost[i] * want_waves) l++; /* 2^l <= the query's share of the waves */
+        if (cost[i] == 0) l = 0;
+        L.lg[i] = (uint8_t)l;
+        count[l]++;
+        L.waves += 1ull << l;
+    }
+    L.merge = count[0] != n;
+    L.grid = (uint32_t)(n < (size_t)n_cu ? n : (size_t)n_cu);
+    if (L.grid == 0) { L.rounds = 0; L.slot_qi.clear(); L.slot_sub.clear(); return; }
+    L.sorted.resize(n);
+    {
+        size_t at[5], pos = 0;
+        for (int l = 4; l >= 0; l--) { at[l] = pos; pos += count[l]; }
+        for (size_t i = 0; i < n; i++) L.sorted[at[L.lg[i]]++] = (uint32_t)i; /* counting sort, wide queries first */
+    }
+    L.fill.assign(L.grid, 0u);
+    for (size_t k = 0; k < n; k++) L.fill[k % L.grid] += 1u << L.lg[L.sorted[k]];
+    uint32_t most = 0;
+    for (uint32_t b = 0; b < L.grid; b++) most = L.fill[b] > most ? L.fill[b] : most;
+    L.rounds = (most + MCQ_LAYOUT_WAVES - 1u) / MCQ_LAYOUT_WAVES;
+    const size_t slots = (size_t)L.rounds * L.grid * MCQ_LAYOUT_WAVES;
+    L.slot_qi.assign(slots, MCQ_LAYOUT_IDLE);
+    L.slot_sub.assign(slots, 0);
+    L.fill.assign(L.grid, 0u);
+    for (size_t k = 0; k < n; k++) {
+        const uint32_t i = L.sorted[k], l = L.lg[i], b = (uint32_t)(k % L.grid), at = L.fill[b];
+        L.fill[b] = at + (1u << l);
+        const size_t dst = ((size_t)(at / MCQ_LAYOUT_WAVES) * L.grid + b) * MCQ_LAYOUT_WAVES + at % MCQ_LAYOUT_WAVES;
+        for (uint32_t sub = 0; sub < (1u << l); sub++) {
+            L.slot_qi[dst + sub] = i;
+            L.slot_sub[dst + sub] = (uint8_t)sub;
+        }
+    }
+}

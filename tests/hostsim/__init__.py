@@ -12,6 +12,7 @@ _SRCS = [os.path.join(_HERE, "hostsim.cpp"),
          os.path.join(_HERE, "..", "..", "neuron_poker_amd", "csrc", "mcq_replay.hpp"),
          os.path.join(_HERE, "..", "..", "neuron_poker_amd", "csrc", "mcq_exact.hpp"),
          os.path.join(_HERE, "..", "..", "neuron_poker_amd", "csrc", "mcq_mt.hpp"),
+         os.path.join(_HERE, "..", "..", "neuron_poker_amd", "csrc", "mcq_layout.hpp"),
          os.path.join(_HERE, "..", "..", "include", "mcq.h")]
 _lib = None
 
@@ -140,3 +141,20 @@ def mt_wave_words(seed32, n):
 def mt_magic_ok():
     lib().hs_mt_magic_ok.restype = C.c_uint32
     return bool(lib().hs_mt_magic_ok())
+
+
+def direct_layout(cost, n_cu=256, max_lg=4):
+    """The host's wave layout for the one-launch path (mcq_layout.hpp) -> (grid, rounds, lg[n], slot_qi, slot_sub)."""
+    cost = np.ascontiguousarray(cost, np.uint64)
+    n = len(cost)
+    cap = n * 16 + 80 * n_cu * 16 + 64
+    lg = np.zeros(max(n, 1), np.uint8)
+    qi = np.zeros(cap, np.uint32)
+    sub = np.zeros(cap, np.uint8)
+    grid = C.c_uint32(0)
+    lib().hs_direct_layout.restype = C.c_uint32
+    rounds = lib().hs_direct_layout(_p(cost, C.c_uint64), C.c_size_t(n), C.c_uint32(n_cu), C.c_uint32(max_lg), C.byref(grid),
+                                    _p(lg, C.c_uint8), _p(qi, C.c_uint32), _p(sub, C.c_uint8), C.c_size_t(cap))
+    assert rounds != 0xFFFFFFFF
+    slots = rounds * grid.value * 16
+    return grid.value, rounds, lg[:n], qi[:slots], sub[:slots]

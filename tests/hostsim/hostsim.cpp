@@ -11,6 +11,7 @@
 
 #include "../../neuron_poker_amd/csrc/mcq_device.hpp"
 #include "../../neuron_poker_amd/csrc/mcq_exact.hpp"
+#include "../../neuron_poker_amd/csrc/mcq_layout.hpp"
 #include "../../neuron_poker_amd/csrc/mcq_mt.hpp"
 #include "../../neuron_poker_amd/csrc/mcq_replay.hpp"
 
@@ -299,4 +300,17 @@ extern "C" uint32_t hs_mt_magic_ok(void) { /* (p * magic) >> 16 == p / D for eve
         for (uint32_t p = 0; p < 128u; p++)
             if (((p * mcq_mt_magic(D)) >> 16) != p / D) return 0;
     return 1;
+}
+
+// ---- the host's wave layout of the one-launch path (mcq_layout.hpp): slot_qi / slot_sub / lg out, returns rounds
+extern "C" uint32_t hs_direct_layout(const uint64_t *cost, size_t n, uint32_t n_cu, uint32_t max_lg, uint32_t *grid,
+                                     uint8_t *lg, uint32_t *slot_qi, uint8_t *slot_sub, size_t slot_cap) {
+    McqDirectLayout L;
+    mcq_direct_layout(cost, n, n_cu, max_lg, L);
+    *grid = L.grid;
+    if (L.slot_qi.size() > slot_cap) return 0xFFFFFFFFu;
+    memcpy(lg, L.lg.data(), n);
+    memcpy(slot_qi, L.slot_qi.data(), L.slot_qi.size() * sizeof(uint32_t));
+    memcpy(slot_sub, L.slot_sub.data(), L.slot_sub.size());
+    return L.rounds;
 }

@@ -239,3 +239,36 @@ def test_wave_cooperative_mt19937_parse_equals_the_sequential_walk():
         d1, p1 = H.mt_parse(q, seed)
         d2, p2 = H.mt_parse(q, seed, reference=True)
         assert p1 == p2 and np.array_equal(d1, d2), (nb, npl, runs, seed)
+
+
+def test_one_launch_layout_invariants():
+    """mcq_layout.hpp (host side of mcq_eval_direct_kernel): every query owns 2^lg consecutive, size-aligned waves of
+    ONE block and round with cut numbers 0 .. 2^lg - 1 in order; no slot is used twice; waves follow cost (within a
+    factor of two of the query's share, at most 16); blocks carry about the same number of waves; the slot count
+    stays inside the bound the host reserves for it."""
+    g = np.random.default_rng(3)
+    for n, n_cu, max_lg in [(1, 256, 4), (2, 256, 4), (17, 256, 4), (257, 256, 4), (1000, 256, 4), (1024, 256, 2), (5000, 256, 4),
+                            (70000, 256, 4), (300, 8, 4), (64, 256, 0)]:
+        cost = g.integers(1, 40, n).astype(np.uint64) * g.choice([1, 1, 1, 8], n).astype(np.uint64) * 1000
+        cost[g.random(n) < 0.05] = 0
+        if cost.sum() == 0:
+            cost[0] = 5
+        grid, rounds, lg, qi, sub = H.direct_layout(cost, n_cu, max_lg)
+        assert grid == min(n, n_cu) and len(qi) == rounds * grid * 16 <= n + 96 * n_cu + 64
+        used = qi != 0xFFFFFFFF
+        assert np.array_equal(np.bincount(qi[used], minlength=n), 1 << lg.astype(np.int64))      # 2^lg slots each
+        first = {}
+        for k in np.nonzero(used)[0]:
+            first.setdefault(int(qi[k]), int(k))
+        for i, k in first.items():
+            w = 1 << int(lg[i])
+            assert k % w == 0 and k // 16 == (k + w - 1) // 16                   # aligned, inside one block-round
+            assert np.all(qi[k:k + w] == i) and np.array_equal(sub[k:k + w], np.arange(w))
+        assert lg.max() <= max_lg
+        share = cost.astype(np.float64) * 16 * n_cu / cost.sum()
+        want = np.clip(np.floor(np.log2(np.maximum(share, 1))), 0, max_lg)
+        assert np.array_equal(lg[cost > 0], want[cost > 0].astype(np.uint8))
+        per_block = np.zeros(grid, np.int64)
+        blocks = (np.arange(len(qi)) // 16) % grid
+        np.add.at(per_block, blocks[used], 1)
+        assert per_block.max() - per_block.min() <= 31
