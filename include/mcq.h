@@ -205,7 +205,9 @@ typedef struct mcq_tables_config {
     uint64_t seed;
     uint8_t seat_kind[10];
     uint8_t reserved[6];            /* [0]: host threads stepping the tables (0 = automatic); [1]: 1 = do not split
-                                     * the tables into two halves on two streams (mcq_tables_run); rest 0 */
+                                     * the tables into two halves on two streams (mcq_tables_run); [2]: 1 = three more
+                                     * equity queries per observation, answers unused, as HoldemTable(calculate_equity=
+                                     * True) issues them (gym_env/env.py:248-256); rest 0 */
     double min_call_equity[10], min_bet_equity[10];
 } mcq_tables_config;
 

@@ -446,7 +446,7 @@ class Tables:
     The tables are independent (own generator each): results do not depend on `threads`."""
 
     def __init__(self, engine, n_tables, seats, runs=1000, initial_stacks=100, small_blind=1, big_blind=2,
-                 max_raises=2, seed=0, threads=0, overlap=True):
+                 max_raises=2, seed=0, threads=0, overlap=True, calculate_equity=False):
         self._lib = load_library()
         self._engine = engine
         cfg = np.zeros(1, TABLES_CONFIG_DTYPE)
@@ -455,6 +455,7 @@ class Tables:
         cfg["seed"] = int(seed) & (2 ** 64 - 1)
         cfg["reserved"][0, 0] = threads          # host threads stepping the tables; 0 = automatic
         cfg["reserved"][0, 1] = 0 if overlap else 1   # run(): two halves on two streams (same results either way)
+        cfg["reserved"][0, 2] = 1 if calculate_equity else 0   # three more queries per observation (env.py:248-256)
         if len(seats) > 10:
             raise ValueError("at most 10 seats")
         for i, s in enumerate(seats):

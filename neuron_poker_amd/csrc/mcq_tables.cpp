@@ -59,6 +59,8 @@ struct Table {
     int n;
     double initial_stacks, small_blind, big_blind;
     int max_raises;
+    int extra_queries = 0; /* HoldemTable(calculate_equity=True): three more equity calls per observation (env.py:248-256) */
+    int extra_left = -1;   /* of the observation in hand; -1 = no observation begun */
     const uint8_t *seat_kind;
     const double *min_call_eq, *min_bet_eq;
     McqXoshiro rng;
@@ -327,8 +329,11 @@ struct Table {
 
     // ---- observation = one equity query (env.py:224-281)
     void observe(mcq_query &q, uint32_t runs) {
-        if (!done) legal_moves();
-        if (current < 0) current = winner_ix;
+        if (extra_left < 0) { /* a new observation */
+            if (!done) legal_moves();
+            if (current < 0) current = winner_ix;
+            extra_left = extra_queries;
+        }
         if (!issued) { /* asking again for the same pending query does not count twice */
             queries++;
             ep_queries++;
@@ -369,6 +374,11 @@ struct Table {
     // advance after the pending query was answered; afterwards the next query is pending (or the episode ended)
     void resume(double equity) {
         issued = false;
+        if (extra_left > 0) { /* one of the extra calls of calculate_equity: its number only goes into the observation */
+            extra_left--;
+            return;
+        }
+        extra_left = -1;
         legal_moves(); /* second half of _get_environment (env.py:272) */
         if (phase == PH_FIRST || phase == PH_B) {
             if (done) { finish_episode(); return; }
@@ -544,6 +554,8 @@ mcq_tables *mcq_tables_create(mcq_ctx *ctx, const mcq_tables_config *cfg) {
             tb.small_blind = cfg->small_blind;
             tb.big_blind = cfg->big_blind;
             tb.max_raises = (int)cfg->max_raises;
+            tb.extra_queries = cfg->reserved[2] ? 3 : 0;
+            tb.extra_left = -1;
             tb.seat_kind = t->kind;
             tb.min_call_eq = t->min_call;
             tb.min_bet_eq = t->min_bet;

@@ -147,8 +147,9 @@ class TableSim:
     and expects the equity (float) to be sent back; it returns when the episode is over (env.py:138-168 reset)."""
 
     def __init__(self, policies, initial_stacks=100, small_blind=1, big_blind=2, max_raises=2, showdown=None,
-                 randint=None):
+                 randint=None, calculate_equity=False):
         self.policies = list(policies)
+        self.calculate_equity = bool(calculate_equity)   # HoldemTable(calculate_equity=True): env.py:248-256
         self.n = len(self.policies)
         self.initial_stacks = initial_stacks
         self.small_blind, self.big_blind, self.max_raises = small_blind, big_blind, max_raises
@@ -205,6 +206,12 @@ class TableSim:
         self.queries += 1
         hole = list(self.cards[self.current])
         alive = self.cycle.n_alive()
+        if self.calculate_equity:                                # env.py:248-256: three more calls with the same
+            for _ in range(3):                                   # arguments; their numbers only go into the observation
+                self.queries += 1
+                extra = yield (hole, list(self.table_cards), alive)
+                if self.log is not None:
+                    self.log.append(["q", sorted(hole), sorted(self.table_cards), alive, 1000, extra])
         equity = yield (hole, list(self.table_cards), alive)
         if self.log is not None:
             self.log.append(["q", sorted(hole), sorted(self.table_cards), alive, 1000, equity])

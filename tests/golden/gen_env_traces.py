@@ -65,8 +65,8 @@ def cid(s):
     return 4 * RANKS.index(s[0]) + SUITS.index(s[1])
 
 
-def run_episode(seed, policies, stacks=100):
-    env = HoldemTable(initial_stacks=stacks, funds_plot=False)
+def run_episode(seed, policies, stacks=100, calculate_equity=False):
+    env = HoldemTable(initial_stacks=stacks, funds_plot=False, calculate_equity=calculate_equity)
     events = []
     real = mp.get_equity
 
@@ -92,7 +92,8 @@ def run_episode(seed, policies, stacks=100):
     env.reset(seed=seed)
     assert env.done
     fh = env.funds_history.reset_index(drop=True).values.tolist()
-    return {"seed": seed, "policies": policies, "stacks": stacks, "events": events, "winner": int(env.winner_ix),
+    return {"seed": seed, "policies": policies, "stacks": stacks, "calculate_equity": bool(calculate_equity),
+            "events": events, "winner": int(env.winner_ix),
             "final_stacks": [float(p.stack) for p in env.players], "funds_history": fh,
             "np_next_words": [int(x) for x in np.random.randint(0, 2 ** 32, size=2, dtype=np.uint32)]}
 
@@ -110,6 +111,11 @@ if __name__ == "__main__":
         print("seed", seed, "seats", len(pol), "queries", nq, "actions", na, "hands", len(ep["funds_history"]),
               "winner", ep["winner"])
         out.append(ep)
+    # calculate_equity=True: three more equity calls per observation (gym_env/env.py:248-256)
+    ep = run_episode(13, MIXED[:4], calculate_equity=True)
+    print("seed 13 calculate_equity queries", sum(e[0] == "q" for e in ep["events"]), "actions",
+          sum(e[0] == "a" for e in ep["events"]), "winner", ep["winner"])
+    out.append(ep)
     with open(os.path.join(HERE, "env_traces.json"), "w") as f:
         json.dump(out, f)
     print("env_traces:", len(out))
