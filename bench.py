@@ -336,130 +336,140 @@ def main():
     }
     if world == 1 and not args.no_extras:  # single-GPU side measurements; never delay the other ranks' teardown
         extras = {}
-        # BASELINE configs[1]: single query AhKh heads-up 100k iterations (latency-bound: 98 wave tasks)
-        q1 = npa.pack_queries([[npa.card_id("AH"), npa.card_id("KH")]], [[255] * 5], 2, 100000)
-        for _ in range(3):
-            eng.eval_batch(q1, seed=1)
-        t1 = time.perf_counter()
-        for i in range(20):
-            eng.eval_batch(q1, seed=i)
-        dt = (time.perf_counter() - t1) / 20
-        extras["configs[1]_single_query_100k"] = {"call_ms_host_buffers": 1e3 * dt, "kernel_ms": eng.last_kernel_ms,
-                                                 "hand_evals_per_s": 2e5 / dt}
-        # BASELINE configs[2]: 4096 preflop states x 3 players x 50k iterations, host buffers (PCIe-inclusive)
-        q3 = npa.pack_queries(hole[:4096], board[:4096], 3, 50000) if B >= 4096 else None
-        if q3 is not None:
-            eng.eval_batch(q3, seed=1)
+
+        def side_measurements():  # a failure here must never cost the headline line
+            # BASELINE configs[1]: single query AhKh heads-up 100k iterations (latency-bound: 98 wave tasks)
+            q1 = npa.pack_queries([[npa.card_id("AH"), npa.card_id("KH")]], [[255] * 5], 2, 100000)
+            for _ in range(3):
+                eng.eval_batch(q1, seed=1)
             t1 = time.perf_counter()
-            for i in range(5):
-                eng.eval_batch(q3, seed=i)
-            dt = (time.perf_counter() - t1) / 5
-            extras["configs[2]_4096x3x50k"] = {"call_ms_host_buffers": 1e3 * dt, "kernel_ms": eng.last_kernel_ms,
-                                               "hand_evals_per_s": 4096 * 3 * 50000 / dt}
-            # the same batch in the PARITY mode (bit-exact replay of np.random.seed(s) per query): MT19937 walked on
-            # the device, one wave per query, then the evaluation kernel on the draws it left in HBM
-            eng.eval_batch(q3, seed=1, mode=npa.MODE_REPLAY_MT19937)
+            for i in range(20):
+                eng.eval_batch(q1, seed=i)
+            dt = (time.perf_counter() - t1) / 20
+            extras["configs[1]_single_query_100k"] = {"call_ms_host_buffers": 1e3 * dt, "kernel_ms": eng.last_kernel_ms,
+                                                     "hand_evals_per_s": 2e5 / dt}
+            # BASELINE configs[2]: 4096 preflop states x 3 players x 50k iterations, host buffers (PCIe-inclusive)
+            q3 = npa.pack_queries(hole[:4096], board[:4096], 3, 50000) if B >= 4096 else None
+            if q3 is not None:
+                eng.eval_batch(q3, seed=1)
+                t1 = time.perf_counter()
+                for i in range(5):
+                    eng.eval_batch(q3, seed=i)
+                dt = (time.perf_counter() - t1) / 5
+                extras["configs[2]_4096x3x50k"] = {"call_ms_host_buffers": 1e3 * dt, "kernel_ms": eng.last_kernel_ms,
+                                                   "hand_evals_per_s": 4096 * 3 * 50000 / dt}
+                # the same batch in the PARITY mode (bit-exact replay of np.random.seed(s) per query): MT19937 walked on
+                # the device, one wave per query, then the evaluation kernel on the draws it left in HBM
+                eng.eval_batch(q3, seed=1, mode=npa.MODE_REPLAY_MT19937)
+                t1 = time.perf_counter()
+                for i in range(3):
+                    eng.eval_batch(q3, seed=i, mode=npa.MODE_REPLAY_MT19937)
+                dt = (time.perf_counter() - t1) / 3
+                extras["configs[2]_replay"] = {"call_ms_host_buffers": 1e3 * dt, "kernel_ms_parse_plus_eval": eng.last_kernel_ms,
+                                               "hand_evals_per_s": 4096 * 3 * 50000 / dt,
+                                               "mt19937_words_per_s": 4096 * 50000 * 12.8 / dt}
+            # run_montecarlo's other arguments: opponents restricted to the top quarter of the preflop classes
+            # (the range the reference's own test uses, tests/test_montecarlo_python.py:215-222), 2048 states x 6 players x
+            # 20k iterations through mcq_eval_batch_ext / mcq_eval_ext_kernel (candidate lists instead of the re-draw loop)
+            with open(os.path.join(ROOT, "neuron_poker_amd", "preflop_classes.json")) as f:
+                order = json.load(f)
+            qx = npa.pack_queries(hole[:2048], board[:2048], 6, 20000) if B >= 2048 else None
+            if qx is not None:
+                ex = npa.pack_query_ext(2048, opp_range=npa.range_bits(order[-int(169 * 0.25):]))
+                eng.eval_batch_ext(qx, ex, 1)
+                t1 = time.perf_counter()
+                for i in range(3):
+                    eng.eval_batch_ext(qx, ex, i)
+                dt = (time.perf_counter() - t1) / 3
+                kms = eng.last_kernel_ms
+                ops = 2048.0 * 20000 * alg_ops_per_iteration(6, 0)
+                extras["ext_opponents_top25pct_2048x6x20k"] = {
+                    "call_ms_host_buffers": 1e3 * dt, "kernel_ms": kms, "hand_evals_per_s": 2048 * 6 * 20000 / dt,
+                    "roofline": {"bound": "valu", "kernel": "mcq_eval_ext_kernel<0>", "achieved": ops / (kms * 1e-3) / 1e12,
+                                 "peak": PEAK_VALU_TOPS, "unit": "Tops/s (int32 lane-ops)",
+                                 "frac": ops / (kms * 1e-3) / 1e12 / PEAK_VALU_TOPS,
+                                 "frac_basis": "model: the plain path's 1242 lane-ops per iteration (SURVEY 8d)"}}
+            # BASELINE configs[3] (the 8-GPU config) on this one GPU: 65 536 states, flop / turn tables alternating, 6 players,
+            # 20k iterations, host buffers; one rank of 8 would take an eighth of the queries
+            g3 = np.random.default_rng(65536)
+            keys = g3.random((65536, 52)).argsort(axis=1)[:, :6].astype(np.uint8)   # 6 distinct cards per state
+            b3 = np.full((65536, 5), 255, np.uint8)
+            b3[:, :3] = keys[:, 2:5]
+            b3[1::2, 3] = keys[1::2, 5]
+            q4 = npa.pack_queries(keys[:, :2], b3, 6, 20000)
+            eng.eval_batch(q4, seed=1)  # warm-up at full size: the pinned staging buffers grow once
             t1 = time.perf_counter()
-            for i in range(3):
-                eng.eval_batch(q3, seed=i, mode=npa.MODE_REPLAY_MT19937)
-            dt = (time.perf_counter() - t1) / 3
-            extras["configs[2]_replay"] = {"call_ms_host_buffers": 1e3 * dt, "kernel_ms_parse_plus_eval": eng.last_kernel_ms,
-                                           "hand_evals_per_s": 4096 * 3 * 50000 / dt,
-                                           "mt19937_words_per_s": 4096 * 50000 * 12.8 / dt}
-        # run_montecarlo's other arguments: opponents restricted to the top quarter of the preflop classes
-        # (the range the reference's own test uses, tests/test_montecarlo_python.py:215-222), 2048 states x 6 players x
-        # 20k iterations through mcq_eval_batch_ext / mcq_eval_ext_kernel (candidate lists instead of the re-draw loop)
-        with open(os.path.join(ROOT, "neuron_poker_amd", "preflop_classes.json")) as f:
-            order = json.load(f)
-        qx = npa.pack_queries(hole[:2048], board[:2048], 6, 20000) if B >= 2048 else None
-        if qx is not None:
-            ex = npa.pack_query_ext(2048, opp_range=npa.range_bits(order[-int(169 * 0.25):]))
-            eng.eval_batch_ext(qx, ex, 1)
-            t1 = time.perf_counter()
-            for i in range(3):
-                eng.eval_batch_ext(qx, ex, i)
-            dt = (time.perf_counter() - t1) / 3
-            kms = eng.last_kernel_ms
-            ops = 2048.0 * 20000 * alg_ops_per_iteration(6, 0)
-            extras["ext_opponents_top25pct_2048x6x20k"] = {
-                "call_ms_host_buffers": 1e3 * dt, "kernel_ms": kms, "hand_evals_per_s": 2048 * 6 * 20000 / dt,
-                "roofline": {"bound": "valu", "kernel": "mcq_eval_ext_kernel<0>", "achieved": ops / (kms * 1e-3) / 1e12,
-                             "peak": PEAK_VALU_TOPS, "unit": "Tops/s (int32 lane-ops)",
-                             "frac": ops / (kms * 1e-3) / 1e12 / PEAK_VALU_TOPS,
-                             "frac_basis": "model: the plain path's 1242 lane-ops per iteration (SURVEY 8d)"}}
-        # BASELINE configs[3] (the 8-GPU config) on this one GPU: 65 536 states, flop / turn tables alternating, 6 players,
-        # 20k iterations, host buffers; one rank of 8 would take an eighth of the queries
-        g3 = np.random.default_rng(65536)
-        keys = g3.random((65536, 52)).argsort(axis=1)[:, :6].astype(np.uint8)   # 6 distinct cards per state
-        b3 = np.full((65536, 5), 255, np.uint8)
-        b3[:, :3] = keys[:, 2:5]
-        b3[1::2, 3] = keys[1::2, 5]
-        q4 = npa.pack_queries(keys[:, :2], b3, 6, 20000)
-        eng.eval_batch(q4, seed=1)  # warm-up at full size: the pinned staging buffers grow once
-        t1 = time.perf_counter()
-        eng.eval_batch(q4, seed=2)
-        dt = time.perf_counter() - t1
-        extras["configs[3]_65536x6x20k_on_one_gpu"] = {"call_ms_host_buffers": 1e3 * dt, "kernel_ms": eng.last_kernel_ms,
-                                                       "hand_evals_per_s": 65536 * 6 * 20000 / dt}
-        # the same batch through the single-process multi-GPU entry of the C ABI (mcq_multi_*: shards -> ONE
-        # ncclAllReduce of the tally matrix): 1 shard, and the 8-way partition of configs[3] with all 8 shards on this
-        # one device (what 8 GPUs run side by side, serialised here); the communicator has one rank on a 1-GPU box
-        ref4 = eng.eval_batch(q4, seed=2)
-        for shards in (1, 8):
-            me = npa.MultiEngine([local_rank] * shards)
-            me.eval_batch(q4, seed=1)
-            t1 = time.perf_counter()
-            r4 = me.eval_batch(q4, seed=2)
+            eng.eval_batch(q4, seed=2)
             dt = time.perf_counter() - t1
-            tm = me.last_times_ms
-            extras["configs[3]_native_multi_%d_shard%s_on_one_gpu" % (shards, "s" if shards > 1 else "")] = {
-                "call_ms_host_buffers": 1e3 * dt, "kernel_max_ms": tm["kernel_max"], "all_reduce_ms": tm["all_reduce"],
-                "hand_evals_per_s": 65536 * 6 * 20000 / dt, "rccl_version": me.info["rccl_version"],
-                "equals_single_context": bool(np.array_equal(r4, ref4))}
-            me.close()
-        # BASELINE configs[4], equity side only: one lock-step of 512 six-seat tables issues <= 2 x 512 queries of 1000
-        # runs (gym_env/env.py:22,261-262) in ONE call; state mix as observed in reference episodes (SURVEY 8c F5:
-        # table cards 0/3/4/5 = 59/19/11/10 %, players alive 2..6 = 41/28/17/9/6 %).  The table logic itself is
-        # not part of this number; the whole loop is measured below.
-        g = np.random.default_rng(512)
-        nb = g.choice([0, 3, 4, 5], size=1024, p=[0.59, 0.19, 0.11, 0.11])
-        npl = g.choice([2, 3, 4, 5, 6], size=1024, p=[0.41, 0.28, 0.17, 0.09, 0.05])
-        hq, bq = [], []
-        for i in range(1024):
-            cards = g.choice(52, 2 + nb[i], replace=False)
-            hq.append(cards[:2])
-            bq.append(list(cards[2:]) + [255] * (5 - nb[i]))
-        q5 = npa.pack_queries(hq, bq, npl, 1000)
-        for _ in range(3):
-            eng.eval_batch(q5, seed=1)
-        t1 = time.perf_counter()
-        for i in range(50):
-            eng.eval_batch(q5, seed=i)
-        dt = (time.perf_counter() - t1) / 50
-        extras["configs[4]_equity_side_only_1024x1000"] = {"call_ms_host_buffers": 1e3 * dt, "kernel_ms": eng.last_kernel_ms,
-                                                           "hand_evals_per_s": float((npl * 1000).sum()) / dt,
-                                                           "lock_steps_per_s": 1.0 / dt}
-        # BASELINE configs[4], the whole loop: 512 six-seat tables (seats as main.py:142-145 + two random seats) driven
-        # by the native lock-step driver (mcq_tables_run): table rules on the host, ONE equity batch per lock-step
-        seats = [("equity", .5, -.5), ("equity", .8, -.8), ("equity", .7, -.7), ("equity", .2, -.3), ("random",), ("random",)]
-        tb = npa.Tables(eng, 512, seats, runs=1000, initial_stacks=100, small_blind=1, big_blind=2, seed=5)
-        tb.run(50)
-        s0 = tb.stats()
-        t1 = time.perf_counter()
-        tb.run(2000)
-        dt = time.perf_counter() - t1
-        s1 = tb.stats()
-        extras["configs[4]_native_driver_512_tables"] = {"lock_steps": 2000, "ms_per_lock_step": 1e3 * dt / 2000,
-                                                         "env_steps_per_s": (s1["env_steps"] - s0["env_steps"]) / dt,
-                                                         "equity_queries_per_s": (s1["queries"] - s0["queries"]) / dt}
-        tb.close()
+            extras["configs[3]_65536x6x20k_on_one_gpu"] = {"call_ms_host_buffers": 1e3 * dt, "kernel_ms": eng.last_kernel_ms,
+                                                           "hand_evals_per_s": 65536 * 6 * 20000 / dt}
+            # the same batch through the single-process multi-GPU entry of the C ABI (mcq_multi_*: shards -> ONE
+            # ncclAllReduce of the tally matrix): 1 shard, and the 8-way partition of configs[3] with all 8 shards on this
+            # one device (what 8 GPUs run side by side, serialised here); the communicator has one rank on a 1-GPU box
+            ref4 = eng.eval_batch(q4, seed=2)
+            for shards in (1, 8):
+                me = npa.MultiEngine([local_rank] * shards)
+                me.eval_batch(q4, seed=1)
+                t1 = time.perf_counter()
+                r4 = me.eval_batch(q4, seed=2)
+                dt = time.perf_counter() - t1
+                tm = me.last_times_ms
+                extras["configs[3]_native_multi_%d_shard%s_on_one_gpu" % (shards, "s" if shards > 1 else "")] = {
+                    "call_ms_host_buffers": 1e3 * dt, "kernel_max_ms": tm["kernel_max"], "all_reduce_ms": tm["all_reduce"],
+                    "hand_evals_per_s": 65536 * 6 * 20000 / dt, "rccl_version": me.info["rccl_version"],
+                    "equals_single_context": bool(np.array_equal(r4, ref4))}
+                me.close()
+            # BASELINE configs[4], equity side only: one lock-step of 512 six-seat tables issues <= 2 x 512 queries of 1000
+            # runs (gym_env/env.py:22,261-262) in ONE call; state mix as observed in reference episodes (SURVEY 8c F5:
+            # table cards 0/3/4/5 = 59/19/11/10 %, players alive 2..6 = 41/28/17/9/6 %).  The table logic itself is
+            # not part of this number; the whole loop is measured below.
+            g = np.random.default_rng(512)
+            nb = g.choice([0, 3, 4, 5], size=1024, p=[0.59, 0.19, 0.11, 0.11])
+            npl = g.choice([2, 3, 4, 5, 6], size=1024, p=[0.41, 0.28, 0.17, 0.09, 0.05])
+            hq, bq = [], []
+            for i in range(1024):
+                cards = g.choice(52, 2 + nb[i], replace=False)
+                hq.append(cards[:2])
+                bq.append(list(cards[2:]) + [255] * (5 - nb[i]))
+            q5 = npa.pack_queries(hq, bq, npl, 1000)
+            for _ in range(3):
+                eng.eval_batch(q5, seed=1)
+            t1 = time.perf_counter()
+            for i in range(50):
+                eng.eval_batch(q5, seed=i)
+            dt = (time.perf_counter() - t1) / 50
+            extras["configs[4]_equity_side_only_1024x1000"] = {"call_ms_host_buffers": 1e3 * dt, "kernel_ms": eng.last_kernel_ms,
+                                                               "hand_evals_per_s": float((npl * 1000).sum()) / dt,
+                                                               "lock_steps_per_s": 1.0 / dt}
+            # BASELINE configs[4], the whole loop: 512 six-seat tables (seats as main.py:142-145 + two random seats) driven
+            # by the native lock-step driver (mcq_tables_run): table rules on the host, ONE equity batch per lock-step
+            seats = [("equity", .5, -.5), ("equity", .8, -.8), ("equity", .7, -.7), ("equity", .2, -.3), ("random",), ("random",)]
+            tb = npa.Tables(eng, 512, seats, runs=1000, initial_stacks=100, small_blind=1, big_blind=2, seed=5)
+            tb.run(50)
+            s0 = tb.stats()
+            t1 = time.perf_counter()
+            tb.run(2000)
+            dt = time.perf_counter() - t1
+            s1 = tb.stats()
+            extras["configs[4]_native_driver_512_tables"] = {"lock_steps": 2000, "ms_per_lock_step": 1e3 * dt / 2000,
+                                                             "env_steps_per_s": (s1["env_steps"] - s0["env_steps"]) / dt,
+                                                             "equity_queries_per_s": (s1["queries"] - s0["queries"]) / dt}
+            tb.close()
+
+        try:
+            side_measurements()
+        except Exception as e:  # noqa: BLE001 -- recorded in the line, the headline stands
+            extras["error"] = "%s: %s" % (type(e).__name__, e)
         out["other_configs"] = extras
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(N, runs)
-        out["cpu_baseline_1thread"] = cpu_baseline(N, runs, seconds=5.0, threads=1)
-        ref = cpu_reference_cpp(N)
-        if ref:
-            out["cpu_baseline_reference_cpp"] = ref
+        try:
+            out["cpu_baseline"] = cpu_baseline(N, runs)
+            out["cpu_baseline_1thread"] = cpu_baseline(N, runs, seconds=5.0, threads=1)
+            ref = cpu_reference_cpp(N)
+            if ref:
+                out["cpu_baseline_reference_cpp"] = ref
+        except Exception as e:  # noqa: BLE001 -- the oracle is test infrastructure: its absence must not cost the line
+            out["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
     print(json.dumps(out), file=JSON_OUT, flush=True)
     if grouped:
         dist.destroy_process_group()
