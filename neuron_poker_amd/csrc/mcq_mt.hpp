@@ -12,9 +12,10 @@
 // depends only on the draw's POSITION in the iteration, and whether a word is accepted hardly depends on that
 // position (neighbouring bounds differ by one).  So a wave parses 64 words at a time by fixed-point iteration:
 //   guess every lane's position p  ->  accept bit of every word under its guessed bound  ->  positions again as
-//   p0 + (accepted words before the lane) - 2 * (re-drawn pairs before the lane)  ->  repeat until nothing moves.
-// Every round makes at least one more lane final (lane 0 always is), so the result is the sequential parse; two or
-// three rounds are typical.  Accepted draws go, as r | 0x80 bytes, to a per-wave ring in LDS laid out like the
+//   p0 + (accepted words before the lane)  ->  repeat until nothing moves.
+// Every round makes at least one more lane final (lane 0 always is), so the result is the sequential parse; four or
+// five rounds are typical.  A pair that has to be drawn again (r1 == r2, one in fifty) ends the batch at its second
+// word: the position rewinds by two, the words behind go back into the stream.  Accepted draws go, as r | 0x80 bytes, to a per-wave ring in LDS laid out like the
 // draw-major global buffer and are flushed 64 iterations at a time with full-row stores; the evaluation kernel
 // (mcq_eval_kernel<MCQ_MODE_REPLAY_MT19937>) consumes that buffer exactly as it consumed the host's.
 //
@@ -222,9 +223,8 @@ MCQ_HD void mcq_mt_parse_query(W &w, McqMtState &st, uint32_t L0, uint32_t n_opp
         MCQ_PL(uint32_t, itr);
         MCQ_PL(bool, acc);
         MCQ_PL(bool, isr2);
-        MCQ_PL(bool, red);
-        uint64_t M = 0, R = 0;
-        for (;;) {
+        uint64_t M = 0;
+        for (;;) { /* positions of the words as if no pair were ever drawn again (that is settled afterwards) */
             MCQ_FOR_LANES(l) {
                 const uint32_t q = (MCQ_L(p) * magic) >> 16;
                 const uint32_t d = MCQ_L(p) - q * D;
@@ -236,22 +236,9 @@ MCQ_HD void mcq_mt_parse_query(W &w, McqMtState &st, uint32_t L0, uint32_t n_opp
                 MCQ_L(acc) = l < cnt && MCQ_L(v) <= (e & 0xFFu) && q < left; /* words past the last iteration stay unread */
             }
             M = MCQ_BALLOT(acc);
-            MCQ_PL(uint32_t, prev_ix);
-            MCQ_FOR_LANES(l) {
-                const uint64_t below = M & (((uint64_t)1 << l) - 1u);
-                MCQ_L(prev_ix) = below ? mcq_mt_top64(below) : 64u;
-            }
-            MCQ_FOR_LANES(l) {
-                const uint32_t sv = MCQ_AT(v, MCQ_L(prev_ix)); /* unconditional: every lane takes part in the exchange */
-                const uint32_t vp = MCQ_L(prev_ix) < 64u ? sv : st.v_last;
-                MCQ_L(red) = MCQ_L(acc) && MCQ_L(isr2) && MCQ_L(v) == vp; /* r1 == r2: the pair is drawn again (l.171-176) */
-            }
-            R = MCQ_BALLOT(red);
             MCQ_PL(bool, moved);
             MCQ_FOR_LANES(l) {
-                /* a guess that is not final yet may hold re-draws that never happen: keep it a valid position */
-                const int32_t ps = (int32_t)(st.d0 + MCQ_COUNT_BELOW(M, l)) - 2 * (int32_t)MCQ_COUNT_BELOW(R, l);
-                const uint32_t pn = ps < 0 ? 0u : (uint32_t)ps;
+                const uint32_t pn = st.d0 + MCQ_COUNT_BELOW(M, l);
                 MCQ_L(moved) = pn != MCQ_L(p);
                 MCQ_L(p) = pn;
             }
@@ -260,25 +247,44 @@ MCQ_HD void mcq_mt_parse_query(W &w, McqMtState &st, uint32_t L0, uint32_t n_opp
 #endif
             if (MCQ_BALLOT(moved) == 0) break;
         }
-        /* accepted draws that survive go to the ring; a re-drawn pair (this lane, or the r1 whose r2 follows as the
-         * next accepted word of this batch) is dropped -- its slots are written by the pair drawn again */
+        /* r1 == r2: the pair is drawn again (l.171-176) -- about one pair in fifty.  The parse is right up to and
+         * including the first such word; the batch ends there (the words behind it go back), the position rewinds by
+         * the pair, and the two draws of the pair are dropped: their slots are written by the pair drawn again. */
+        MCQ_PL(uint32_t, prev_ix);
         MCQ_FOR_LANES(l) {
-            const uint64_t above = l < 63u ? M & ~(((uint64_t)2 << l) - 1u) : 0;
-            const bool dropped = MCQ_L(red) || (above && ((R >> mcq_mt_low64(above)) & 1u));
-            if (MCQ_L(acc) && !dropped)
+            const uint64_t below = M & (((uint64_t)1 << l) - 1u);
+            MCQ_L(prev_ix) = below ? mcq_mt_top64(below) : 64u;
+        }
+        MCQ_PL(bool, red);
+        MCQ_FOR_LANES(l) {
+            const uint32_t sv = MCQ_AT(v, MCQ_L(prev_ix)); /* unconditional: every lane takes part in the exchange */
+            const uint32_t vp = MCQ_L(prev_ix) < 64u ? sv : st.v_last;
+            MCQ_L(red) = MCQ_L(acc) && MCQ_L(isr2) && MCQ_L(v) == vp;
+        }
+        const uint64_t R = MCQ_BALLOT(red);
+        uint32_t used = cnt, rewind = 0, drop_a = 64u, drop_b = 64u; /* words of the batch that count; lanes dropped */
+        if (R) {
+            drop_b = mcq_mt_low64(R);
+            drop_a = MCQ_AT_UNIFORM(prev_ix, drop_b);
+            used = drop_b + 1u;
+            rewind = 2u;
+            M &= ((uint64_t)2 << drop_b) - 1u;
+        }
+        MCQ_FOR_LANES(l) {
+            if (MCQ_L(acc) && l < used && l != drop_a && l != drop_b)
                 w.ring[MCQ_L(dd) * MCQ_MT_RING + ((st.it_done + MCQ_L(itr)) & (MCQ_MT_RING - 1u))] = (uint8_t)(MCQ_L(v) | 0x80u);
         }
         MCQ_PL(bool, pass);
-        MCQ_FOR_LANES(l) { MCQ_L(pass) = MCQ_L(acc) && MCQ_L(isr2); } /* one accepted r2 per attempt (l.168) */
+        MCQ_FOR_LANES(l) { MCQ_L(pass) = MCQ_L(acc) && MCQ_L(isr2) && l < used; } /* one accepted r2 per attempt (l.168) */
         st.passes += mcq_mt_popc64(MCQ_BALLOT(pass));
-        const uint32_t p_end = st.d0 + mcq_mt_popc64(M) - 2u * mcq_mt_popc64(R);
+        const uint32_t p_end = st.d0 + mcq_mt_popc64(M) - rewind;
         const uint32_t it_add = (p_end * magic) >> 16;
         st.d0 = p_end - it_add * D;
         st.it_done += it_add;
         if (M) st.v_last = MCQ_AT_UNIFORM(v, mcq_mt_top64(M));
-        /* words consumed: everything up to the last accepted word, and the rejected words behind it unless the
-         * stream of this query ends there (the last iteration is complete) */
-        st.pos += st.it_done < runs ? cnt : (M ? mcq_mt_top64(M) + 1u : 0u);
+        /* words consumed: up to the re-drawn pair, else everything up to the last accepted word and the rejected words
+         * behind it unless the stream of this query ends there (the last iteration is complete) */
+        st.pos += R ? used : (st.it_done < runs ? cnt : (M ? mcq_mt_top64(M) + 1u : 0u));
         MCQ_WAVE_SYNC();
         while (st.it_done - st.flushed >= 64u) mcq_mt_flush(w, st, D, 64u, draws, stride);
     }
