@@ -25,6 +25,7 @@ Deliberate differences:
 """
 import json
 import os
+import struct
 import threading
 from collections import Counter
 
@@ -166,12 +167,46 @@ class MonteCarlo(object):
         return self.equity, self.winTypesDict
 
 
+_CARD_ID = {r + s: 4 * i + j for i, r in enumerate("23456789TJQKA") for j, s in enumerate("CDHS")}
+_fast = threading.local()   # per thread: (engine, ctypes query buffer, ctypes result buffer)
+
+
 def get_equity(player_cards, table_cards, players, runs):
-    """Get equity from a Monte-Carlo run -- tools/montecarlo_python.py:401-406, on the GPU."""
-    simulation = MonteCarlo()
-    simulation.run_montecarlo([list(player_cards)], list(table_cards), players, 1, maxRuns=runs, timeout=0,
-                              ghost_cards='', opponent_range=1)
-    return simulation.equity
+    """Get equity from a Monte-Carlo run -- tools/montecarlo_python.py:401-406, on the GPU.
+
+    This is the call gym_env/env.py:261-262 makes at every step, so it does not go through MonteCarlo() and numpy: the
+    16-byte record is packed into a reusable ctypes buffer and mcq_eval_batch is called directly (what
+    run_montecarlo([list(player_cards)], list(table_cards), players, 1, maxRuns=runs, ...) computes, same streams)."""
+    if _state["mode"] != _lib.MODE_PHILOX or _state["couple_numpy"]:
+        simulation = MonteCarlo()
+        simulation.run_montecarlo([list(player_cards)], list(table_cards), players, 1, maxRuns=runs, timeout=0,
+                                  ghost_cards='', opponent_range=1)
+        return simulation.equity
+    try:
+        hole = [_CARD_ID[c] for c in player_cards]
+        board = [_CARD_ID[c] for c in table_cards]
+    except (KeyError, TypeError):
+        raise ValueError("a card is not in the deck: %r %r" % (player_cards, table_cards)) from None
+    nb, runs, players = len(board), int(runs), int(players)
+    if len(hole) != 2 or nb > 5:
+        raise ValueError("player_cards must hold exactly two cards, table_cards at most five")
+    if runs < 1:
+        raise ValueError("runs must be >= 1")
+    st = getattr(_fast, "st", None)
+    eng = _lib.default_engine()
+    if st is None or st[0] is not eng:
+        import ctypes
+        st = _fast.st = (eng, ctypes.create_string_buffer(16), (ctypes.c_uint64 * 13)())
+    try:
+        struct.pack_into("<2B5BBB3xI", st[1], 0, hole[0], hole[1], *(board + [0] * (5 - nb)), nb, players, runs)
+    except struct.error as e:
+        raise ValueError("n_players or runs out of range: %s" % e) from None
+    s, first = _take_ids(1)
+    rc = eng._lib.mcq_eval_batch(eng._ctx, st[1], 1, s, first, _lib.MODE_PHILOX, st[2])
+    if rc:
+        _lib._raise(rc)
+    out = st[2]
+    return (out[2] + out[3]) / out[0]
 
 
 def get_equity_batch(hole, board, n_players, runs, seed=None, first_query_id=0, mode=None, engine=None):

@@ -49,6 +49,20 @@ def main():
             return eng.last_kernel_ms
         dt, k = timeit(host, 200)
         print("%-26s host entry: call %7.1f us  kernel %7.1f us  %.3g evals/s   [%s]" % (name, dt * 1e6, k * 1e3, evals / dt, tag))
+    from neuron_poker_amd import montecarlo_hip as mh
+    mh.seed(1)
+    hole, board = {"AH", "KH"}, {"2C", "7D", "JS"}
+    for _ in range(20):
+        mh.get_equity(hole, board, 4, 1000)
+    t0 = time.perf_counter()
+    for _ in range(2000):
+        mh.get_equity(hole, board, 4, 1000)
+    print("montecarlo_hip.get_equity(set, set, 4, 1000) as gym_env/env.py:261 calls it: %.1f us per call" % ((time.perf_counter() - t0) / 2000 * 1e6))
+    sim = mh.MonteCarlo()
+    t0 = time.perf_counter()
+    for _ in range(500):
+        sim.run_montecarlo([["AH", "KH"]], ["2C", "7D", "JS"], 4, 1, maxRuns=1000, timeout=0, ghost_cards="")
+    print("MonteCarlo().run_montecarlo(..., maxRuns=1000): %.1f us per call" % ((time.perf_counter() - t0) / 500 * 1e6))
     try:
         import torch
         dev = torch.device("cuda", 0)
