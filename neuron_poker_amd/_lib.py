@@ -273,7 +273,7 @@ class Engine:
         part=(p, n): only share p of n of every query's iterations (mcq_eval_batch_part; the rows of all shares
         add up to the unsplit result)."""
         q = np.ascontiguousarray(queries, dtype=QUERY_DTYPE).reshape(-1)
-        out = np.zeros(len(q), RESULT_DTYPE)
+        out = np.empty(len(q), RESULT_DTYPE)   # every row is written by the library on success; on failure we raise
         if part is not None:
             if mode != MODE_PHILOX:
                 raise ValueError("only the production mode can split the iterations of a query")
