@@ -479,13 +479,17 @@ struct mcq_tables {
     uint64_t calls;
     bool failed = false; /* a lock-step died half way: the tables are out of step with the query ids, nothing more may run */
     Pool *pool = nullptr;
-    Pool *pool2 = nullptr; /* the helper thread's pool in the two-stream schedule */
-    mcq_ctx *ctx2 = nullptr; /* second stream + buffers: the upper half of the tables is stepped by a helper thread
-                                while the lower half's batch is on the GPU, and vice versa (mcq_tables_run) */
+    /* further streams + buffers (and thread pools) of the multi-stream schedule: group g of the tables is stepped by
+     * helper thread g while the other groups' batches are on the GPU (mcq_tables_run); [0] unused */
+    static constexpr size_t kGroups = 4;
+    Pool *pool_g[kGroups] = {nullptr, nullptr, nullptr, nullptr};
+    mcq_ctx *ctx_g[kGroups] = {nullptr, nullptr, nullptr, nullptr};
     ~mcq_tables() {
         delete pool;
-        delete pool2;
-        if (ctx2) mcq_destroy(ctx2);
+        for (size_t g = 1; g < kGroups; g++) {
+            delete pool_g[g];
+            if (ctx_g[g]) mcq_destroy(ctx_g[g]);
+        }
     }
     template <class F>
     void for_tables(F &&f) { /* f(begin, end) */
@@ -644,42 +648,54 @@ int mcq_tables_run(mcq_tables *t, uint32_t lock_steps, uint64_t *stats) {
 }
 
 static int tables_run_impl(mcq_tables *t, uint32_t lock_steps, uint64_t *stats) {
+    constexpr size_t kMaxGroups = mcq_tables::kGroups;
     const size_t n = t->tables.size();
     const uint32_t runs = t->cfg.runs;
     if (lock_steps && mcq_tables_begin(t, t->q.data()) == 0) return MCQ_EINVAL;
-    /* Two halves on two streams.  While one half's batch is on the GPU the other half's tables are stepped on the
-     * host (by its own thread pool when the table count is large); per-query ids, hence all results, are as in
-     * one batch per step. */
-    if (n >= 64 && lock_steps >= 4 && t->cfg.reserved[1] == 0) {
-        if (!t->ctx2) t->ctx2 = mcq_ctx_clone(t->ctx);
-        if (t->ctx2 && t->pool && !t->pool2) t->pool2 = new (std::nothrow) Pool(t->pool->parts() - 1u);
-        if (t->ctx2 && (!t->pool || t->pool2)) {
-            std::string err2;
-            int rc2 = MCQ_OK;
-            std::thread helper([&] {
-                try {
-                    rc2 = run_range(t, t->ctx2, t->pool2, n / 2, n, lock_steps, &err2);
-                } catch (const std::exception &ex) {
-                    rc2 = MCQ_EDEVICE;
-                    err2 = std::string("mcq_tables_run (helper thread): ") + ex.what();
-                } catch (...) {
-                    rc2 = MCQ_EDEVICE;
-                    err2 = "mcq_tables_run (helper thread): unexpected exception";
-                }
-            });
-            int rc1;
+    /* Groups of tables on streams of their own (two for a few hundred tables, up to four beyond).  While one group's
+     * batch is on the GPU the other groups' tables are stepped on the host (each by its own thread, and its own thread
+     * pool when the table count is large); per-query ids, hence all results, are as in one batch per step. */
+    size_t groups = n >= 2048 ? 4 : 2;
+    if (const char *e = getenv("MCQ_TABLES_GROUPS")) groups = (size_t)atoi(e);
+    if (groups > kMaxGroups) groups = kMaxGroups;
+    if (n >= 64 && lock_steps >= 4 && t->cfg.reserved[1] == 0 && groups >= 2) {
+        bool ready = true;
+        for (size_t g = 1; g < groups; g++) {
+            if (!t->ctx_g[g]) t->ctx_g[g] = mcq_ctx_clone(t->ctx);
+            if (t->ctx_g[g] && t->pool && !t->pool_g[g]) t->pool_g[g] = new (std::nothrow) Pool(t->pool->parts() - 1u);
+            ready = ready && t->ctx_g[g] && (!t->pool || t->pool_g[g]);
+        }
+        if (ready) {
+            std::string err[kMaxGroups];
+            int rc[kMaxGroups] = {0, 0, 0, 0};
+            std::vector<std::thread> helpers;
+            auto join_all = [&] { for (auto &h : helpers) if (h.joinable()) h.join(); };
             try {
-                rc1 = run_range(t, t->ctx, t->pool, 0, n / 2, lock_steps, nullptr);
+                for (size_t g = 1; g < groups; g++)
+                    helpers.emplace_back([&, g] {
+                        try {
+                            rc[g] = run_range(t, t->ctx_g[g], t->pool_g[g], n * g / groups, n * (g + 1) / groups, lock_steps, &err[g]);
+                        } catch (const std::exception &ex) {
+                            rc[g] = MCQ_EDEVICE;
+                            err[g] = std::string("mcq_tables_run (helper thread): ") + ex.what();
+                        } catch (...) {
+                            rc[g] = MCQ_EDEVICE;
+                            err[g] = "mcq_tables_run (helper thread): unexpected exception";
+                        }
+                    });
+                rc[0] = run_range(t, t->ctx, t->pool, 0, n / groups, lock_steps, nullptr);
             } catch (...) {
-                helper.join(); /* never leave the helper running (or joinable: std::terminate) behind an exception */
+                join_all(); /* never leave a helper running (or joinable: std::terminate) behind an exception */
                 throw;
             }
-            helper.join();
-            /* a failed half leaves its tables at the step it reached while the other half went on: the halves are out
-             * of step with each other and with the query ids -- the driver is marked failed and refuses further calls */
-            if (rc1 || rc2) t->failed = true;
-            if (rc1) return rc1;
-            if (rc2) { mcq_tables_set_error(err2.c_str()); return rc2; }
+            join_all();
+            /* a failed group leaves its tables at the step it reached while the others went on: the groups are out of
+             * step with each other and with the query ids -- the driver is marked failed and refuses further calls */
+            for (size_t g = 0; g < groups; g++)
+                if (rc[g]) t->failed = true;
+            if (rc[0]) return rc[0];
+            for (size_t g = 1; g < groups; g++)
+                if (rc[g]) { mcq_tables_set_error(err[g].c_str()); return rc[g]; }
             t->calls += (uint64_t)lock_steps * n;
             if (stats) mcq_tables_stats(t, stats);
             return MCQ_OK;
