@@ -188,9 +188,9 @@ MCQ_API float mcq_last_kernel_ms(mcq_ctx *ctx);
  * q[i]) and returns n_tables; mcq_tables_resume takes their equities ((win + tie) / runs) and advances every
  * table to its next query.  mcq_tables_run does `lock_steps` rounds of begin -> ONE mcq_eval_batch
  * (MCQ_MODE_PHILOX, seed cfg.seed, query ids counting up across calls) -> resume, and needs a context; it
- * runs the two halves of the tables on two streams so that the host steps one half while the
- * other half's batch is on the GPU -- every query keeps the id it has in the one-batch schedule, so the results
- * are the same.
+ * runs the tables in two or three groups on streams (and host threads) of their own so that the host steps one
+ * group while the other groups' batches are on the GPU -- every query keeps the id it has in the one-batch schedule,
+ * so the results are the same.
  * begin/resume alone need no GPU (ctx may be NULL): that is how the CPU tests pin the rules.
  * seat_kind: 0 = equity agent (agents/agent_consider_equity.py:25-56 with min_call_equity / min_bet_equity of
  * the seat), 1 = random agent (agents/agent_random.py:21-29, drawing from the table's own generator).
@@ -205,7 +205,7 @@ typedef struct mcq_tables_config {
     uint64_t seed;
     uint8_t seat_kind[10];
     uint8_t reserved[6];            /* [0]: host threads stepping the tables (0 = automatic); [1]: 1 = do not split
-                                     * the tables into two halves on two streams (mcq_tables_run); [2]: 1 = three more
+                                     * the tables into groups on streams of their own (mcq_tables_run); [2]: 1 = three more
                                      * equity queries per observation, answers unused, as HoldemTable(calculate_equity=
                                      * True) issues them (gym_env/env.py:248-256); rest 0 */
     double min_call_equity[10], min_bet_equity[10];
