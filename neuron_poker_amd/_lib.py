@@ -454,7 +454,7 @@ class Tables:
         cfg["initial_stacks"], cfg["small_blind"], cfg["big_blind"] = initial_stacks, small_blind, big_blind
         cfg["seed"] = int(seed) & (2 ** 64 - 1)
         cfg["reserved"][0, 0] = threads          # host threads stepping the tables; 0 = automatic
-        cfg["reserved"][0, 1] = 0 if overlap else 1   # run(): two halves on two streams (same results either way)
+        cfg["reserved"][0, 1] = 0 if overlap else 1   # run(): groups of tables on streams of their own (same results either way)
         cfg["reserved"][0, 2] = 1 if calculate_equity else 0   # three more queries per observation (env.py:248-256)
         if len(seats) > 10:
             raise ValueError("at most 10 seats")
