@@ -115,7 +115,11 @@ MCQ_API void mcq_destroy(mcq_ctx *ctx);
 /* Evaluate n queries held in HOST memory; blocks until out[0..n) is written.  The caller owns q and out.
  * Query i uses query id first_query_id + i, so a batch split into shards (other ranks, other calls) with
  * the matching first_query_id gives bit-identical per-query tallies.  All queries are validated first;
- * on MCQ_EINVAL nothing is launched and out is untouched. */
+ * on MCQ_EINVAL nothing is launched and out is untouched.
+ * MCQ_MODE_PHILOX: batches of small queries (at most 8192 iterations each -- the reference asks for 1000,
+ * gym_env/env.py:22) cost ONE kernel launch: the kernel reads the records from and stores the finished rows to pinned
+ * host memory, no copy, prep or zeroing launches around it; larger queries are priced on the host and sliced over the
+ * whole GPU.  MCQ_MODE_REPLAY_MT19937: numpy's MT19937 stream of every query is walked on the GPU, one wave per query. */
 MCQ_API int mcq_eval_batch(mcq_ctx *ctx, const mcq_query *q, size_t n, uint64_t seed, uint64_t first_query_id, int mode,
                    mcq_result *out);
 
@@ -173,11 +177,12 @@ MCQ_API int mcq_exact_batch(mcq_ctx *ctx, const mcq_query *q, size_t n, int law,
 /* Select the dealing law used by MCQ_MODE_PHILOX on this context (MCQ_LAW_*). */
 MCQ_API int mcq_set_dealing_law(mcq_ctx *ctx, int law);
 
-/* Every evaluation-kernel launch is bracketed by a pair of HIP events on the stream it is launched on (a ring
- * of the 64 most recent launches).  mcq_kernel_times writes the durations in milliseconds of the latest
- * min(max_n, 64, launches so far) launches, oldest first, and returns how many; the launches must have
- * completed (synchronise the stream first).  mcq_last_kernel_ms: the most recent host-entry call's total
- * (all chunks), else the latest launch. */
+/* Every evaluation-kernel launch carries a pair of HIP events that take the kernel's own begin and end timestamps
+ * on the stream it is launched on (a ring of the 64 most recent launches; in parity mode the pair spans the stream
+ * walk and the evaluation kernel; launches recorded into a stream capture are not timed).  mcq_kernel_times writes
+ * the durations in milliseconds of the latest min(max_n, 64, launches so far) launches, oldest first, and returns how
+ * many; it waits for the newest of them to have finished.  mcq_last_kernel_ms: the most recent host-entry call's
+ * total (all chunks), else the latest launch. */
 MCQ_API int mcq_kernel_times(mcq_ctx *ctx, float *ms, int max_n);
 MCQ_API float mcq_last_kernel_ms(mcq_ctx *ctx);
 

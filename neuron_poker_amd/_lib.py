@@ -386,7 +386,7 @@ class MultiEngine:
         self._m = self._lib.mcq_multi_create(devs.ctypes.data, len(devs), 0)
         if not self._m:
             msg = (self._lib.mcq_last_error() or b"").decode("utf-8", "replace")
-            raise McqError("mcq_multi_create(%s) failed: %s" % (list(devs), msg))
+            raise McqError("mcq_multi_create(%s) failed: %s" % ([int(d) for d in devs], msg))
         self.devices = [int(d) for d in devs]
 
     def close(self):
