@@ -345,7 +345,7 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
                 const uint32_t cnt = (uint32_t)min((uint64_t)chunk, (uint64_t)qc.runs - it0);
                 for (uint32_t j = 0; j < cnt; j++)
                     mcq_iteration(qc, dr, base - 128, g_tab->tf, tab.tops, tab.sd, acc);
-                acc.passes = cnt * qc.n_opp; /* MCQ-CTR v3: one attempt per opponent, never re-drawn */
+                acc.passes = cnt * qc.n_opp; /* MCQ-CTR v4: one attempt per opponent, never re-drawn */
             }
         } else {
             const uint64_t stride = (qc.runs + 63u) & ~63ull;

@@ -85,8 +85,8 @@ static uint32_t np_randint(mt_t *s, uint32_t n) {
 }
 
 /* ------------------------------------------------------- counter-based front end (product's CTR mode) */
-/* Spec (DESIGN.md "MCQ-CTR v3"): iterations are grouped in streams of 16; stream s of query id q under
- * seed k starts xoshiro128++ from Philox4x32-10(counter = {q_lo, q_hi, s, 'MCQ1'}, key = {k_lo, k_hi}).
+/* Spec (DESIGN.md "MCQ-CTR v4"): iterations are grouped in streams of 16; stream s of query id q under
+ * seed k starts jsf32 (state a, b, c, d) from Philox4x32-10(counter = {q_lo, q_hi, s, 'MCQ1'}, key = {k_lo, k_hi}).
  * Opponent pair on a deck of length L, ONE word u, d = L-1: a = mulhi32(u, d), c = mulhi32(u * d mod 2^32, d);
  * (r1, r2) = (a, c) if a != c else (d, a) -- a bijection onto the pairs the reference accepts
  * (r1 in [0,L), r2 in [0,L-1), r1 != r2), so they are equally likely exactly as after its re-draw loop
@@ -108,42 +108,40 @@ static void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-typedef struct { uint32_t s[4]; } xo_t;
+/* Bob Jenkins' small noncryptographic PRNG ("jsf32", two-rotate version 27/17) */
+typedef struct { uint32_t s[4]; } js_t;
 
 static inline uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
 
-static uint32_t xo_next(xo_t *x) {
-    uint32_t *s = x->s;
-    uint32_t result = rotl32(s[0] + s[3], 7) + s[0];
-    uint32_t t = s[1] << 9;
-    s[2] ^= s[0];
-    s[3] ^= s[1];
-    s[1] ^= s[2];
-    s[0] ^= s[3];
-    s[2] ^= t;
-    s[3] = rotl32(s[3], 11);
-    return result;
+static uint32_t js_next(js_t *x) {
+    uint32_t *s = x->s; /* a, b, c, d */
+    uint32_t e = s[0] - rotl32(s[1], 27);
+    s[0] = s[1] ^ rotl32(s[2], 17);
+    s[1] = s[2] + s[3];
+    s[2] = s[3] + e;
+    s[3] = e + s[0];
+    return s[3];
 }
 
-static void xo_seed(xo_t *x, uint64_t seed, uint64_t qid, uint32_t stream) {
+static void js_seed(js_t *x, uint64_t seed, uint64_t qid, uint32_t stream) {
     uint32_t ctr[4] = {(uint32_t)qid, (uint32_t)(qid >> 32), stream, 0x4D435131u};
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
     philox4x32_10(ctr, key, x->s);
-    if ((x->s[0] | x->s[1] | x->s[2] | x->s[3]) == 0) x->s[0] = 1;
+    if ((x->s[0] | x->s[1] | x->s[2] | x->s[3]) == 0) x->s[0] = 0xf1ea5eedu; /* the all-zero state is a fixed point */
 }
 
-static uint32_t xo_draw(xo_t *x, uint32_t n) { return (uint32_t)(((uint64_t)xo_next(x) * n) >> 32); }
+static uint32_t js_draw(js_t *x, uint32_t n) { return (uint32_t)(((uint64_t)js_next(x) * n) >> 32); }
 
 /* one RNG handle for the dealing code */
 typedef struct {
-    int kind; /* 0 = MT19937 + numpy randint, 1 = xoshiro + mulhi */
+    int kind; /* 0 = MT19937 + numpy randint, 1 = jsf32 + mulhi */
     mt_t *mt;
-    xo_t *xo;
+    js_t *xo;
 } rng_t;
 
-static uint32_t draw(rng_t *r, uint32_t n) { return r->kind == 0 ? np_randint(r->mt, n) : xo_draw(r->xo, n); }
-/* kind: 0 = MT19937 + numpy randint (the reference), 1 = MCQ-CTR v3 with the reference's dealing law,
- * 2 = MCQ-CTR v3 with the UNIFORM law (what montecarlo_cython.pyx:188 and Montecarlo.cpp:296-312 intend) */
+static uint32_t draw(rng_t *r, uint32_t n) { return r->kind == 0 ? np_randint(r->mt, n) : js_draw(r->xo, n); }
+/* kind: 0 = MT19937 + numpy randint (the reference), 1 = MCQ-CTR v4 with the reference's dealing law,
+ * 2 = MCQ-CTR v4 with the UNIFORM law (what montecarlo_cython.pyx:188 and Montecarlo.cpp:296-312 intend) */
 
 /* ------------------------------------------------------------------------------------------ evaluator */
 enum { T_HIGH, T_PAIR, T_TWOPAIR, T_TRIPS, T_STRAIGHT, T_FLUSH, T_FULL, T_QUADS, T_SF };
@@ -343,16 +341,16 @@ static uint32_t deal_iteration(rng_t *rng, const uint8_t hero[2], const uint8_t 
     hole[0][0] = hero[0]; hole[0][1] = hero[1];
     deck_remove(&d, hero[0]); /* l.154-161 */
     deck_remove(&d, hero[1]);
-    for (int p = 1; p < n_players && rng->kind == 2; p++) { /* MCQ-CTR v3, UNIFORM law */
-        uint32_t dd = (uint32_t)d.n - 1, u = xo_next(rng->xo);
+    for (int p = 1; p < n_players && rng->kind == 2; p++) { /* MCQ-CTR v4, UNIFORM law */
+        uint32_t dd = (uint32_t)d.n - 1, u = js_next(rng->xo);
         uint32_t r1 = (uint32_t)(((uint64_t)u * (dd + 1)) >> 32);                   /* in [0, L) */
         uint32_t r2 = (uint32_t)(((uint64_t)(uint32_t)(u * (dd + 1)) * dd) >> 32);  /* in [0, L-1): every ordered pair */
         passes++;
         hole[p][0] = deck_pop(&d, (int)r1);
         hole[p][1] = deck_pop(&d, (int)r2);
     }
-    for (int p = 1; p < n_players && rng->kind == 1; p++) { /* MCQ-CTR v3 */
-        uint32_t dd = (uint32_t)d.n - 1, u = xo_next(rng->xo);
+    for (int p = 1; p < n_players && rng->kind == 1; p++) { /* MCQ-CTR v4 */
+        uint32_t dd = (uint32_t)d.n - 1, u = js_next(rng->xo);
         uint32_t a = (uint32_t)(((uint64_t)u * dd) >> 32), c = (uint32_t)(((uint64_t)(uint32_t)(u * dd) * dd) >> 32);
         uint32_t r1 = a != c ? a : dd, r2 = a != c ? c : a;
         passes++;
@@ -377,7 +375,7 @@ static uint32_t deal_iteration(rng_t *rng, const uint8_t hero[2], const uint8_t 
         for (int k = nb; k < 5; k++) {
             uint32_t n = (uint32_t)d.n - (rng->kind == 2 ? 0u : 1u); /* uniform law: any remaining card */
             if (((k - nb) & 1) == 0) {
-                uint32_t u = xo_next(rng->xo);
+                uint32_t u = js_next(rng->xo);
                 table[k] = deck_pop(&d, (int)(((uint64_t)u * n) >> 32));
                 w = u * n;
             } else {
@@ -433,10 +431,10 @@ uint64_t mcqo_np_randint(uint32_t seed, uint32_t n, const uint32_t *bounds, uint
 
 void mcqo_philox4x32_10(const uint32_t *ctr, const uint32_t *key, uint32_t *out) { philox4x32_10(ctr, key, out); }
 
-void mcqo_xoshiro_stream(uint64_t seed, uint64_t qid, uint32_t stream, uint32_t n, uint32_t *out) {
-    xo_t x;
-    xo_seed(&x, seed, qid, stream);
-    for (uint32_t i = 0; i < n; i++) out[i] = xo_next(&x);
+void mcqo_ctr_stream(uint64_t seed, uint64_t qid, uint32_t stream, uint32_t n, uint32_t *out) {
+    js_t x;
+    js_seed(&x, seed, qid, stream);
+    for (uint32_t i = 0; i < n; i++) out[i] = js_next(&x);
 }
 
 /* out[0]=nscore, out[1..3]=score (padded 0), out[4]=nranks, out[5..13]=ranks (padded -128), out[14]=type */
@@ -460,7 +458,7 @@ int mcqo_compare(const uint8_t *a, const uint8_t *b) {
 
 int mcqo_best_hand(const uint8_t *hands, int n, int *type, int *tie) { return best_hand(hands, n, type, tie); }
 
-/* mode 0: np.random.seed((uint32)seed) then the reference loop; mode 1: MCQ-CTR v3 with query id qid.
+/* mode 0: np.random.seed((uint32)seed) then the reference loop; mode 1: MCQ-CTR v4 with query id qid.
  * trace (optional): first `keep` iterations' hands [keep][n_players][7]; words (optional, mode 0): MT words
  * per kept iteration; total_words (optional). Returns 0, or -1 on invalid input. */
 int mcqo_run(int mode, const uint8_t *hero, const uint8_t *board, int nb, int n_players, uint32_t runs,
@@ -468,14 +466,14 @@ int mcqo_run(int mode, const uint8_t *hero, const uint8_t *board, int nb, int n_
              uint64_t *total_words) {
     if (!valid_query(hero, board, nb, n_players)) return -1;
     mt_t mt;
-    xo_t xo;
+    js_t xo;
     rng_t rng = {mode, &mt, &xo};
     uint8_t hands[70];
     memset(out, 0, 13 * sizeof(uint64_t));
     mt.words = 0;
     if (mode == 0) mt_seed(&mt, (uint32_t)seed);
     for (uint32_t it = 0; it < runs; it++) {
-        if (mode >= 1 && it % STREAM_ITERS == 0) xo_seed(&xo, seed, qid, it / STREAM_ITERS);
+        if (mode >= 1 && it % STREAM_ITERS == 0) js_seed(&xo, seed, qid, it / STREAM_ITERS);
         uint64_t w0 = mt.words;
         out[1] += deal_iteration(&rng, hero, board, nb, n_players, hands);
         out[0]++;
@@ -495,13 +493,13 @@ int mcqo_run_range(int mode, const uint8_t *hero, const uint8_t *board, int nb, 
                    uint64_t qid, uint32_t it_begin, uint32_t it_end, uint64_t *out) {
     if (mode < 1 || !valid_query(hero, board, nb, n_players)) return -1;
     mt_t mt;
-    xo_t xo;
+    js_t xo;
     rng_t rng = {mode, &mt, &xo};
     uint8_t hands[70];
     uint64_t scratch[13];
     memset(out, 0, 13 * sizeof(uint64_t));
     for (uint32_t it = it_begin - it_begin % STREAM_ITERS; it < it_end; it++) {
-        if (it % STREAM_ITERS == 0) xo_seed(&xo, seed, qid, it / STREAM_ITERS);
+        if (it % STREAM_ITERS == 0) js_seed(&xo, seed, qid, it / STREAM_ITERS);
         uint64_t passes = deal_iteration(&rng, hero, board, nb, n_players, hands);
         uint64_t *dst = it >= it_begin ? out : scratch;
         dst[1] += passes;
@@ -579,7 +577,7 @@ static int in_range(const uint32_t *bits, uint8_t a, uint8_t b) {
  * there any more: the reference's try/except), a random opponent is tested on the unpopped list and then popped in turn
  * (l.165-181).
  *
- * mode 1 (production, "MCQ-CTR v3x"): the same LAW without index arithmetic.  The reference accepts every ordered
+ * mode 1 (production, "MCQ-CTR v4x"): the same LAW without index arithmetic.  The reference accepts every ordered
  * index pair (r1, r2), r1 in [0,L), r2 in [0,L-1), r1 != r2, whose classes are allowed, equally often; as cards that
  * is every ordered pair (A, B) of distinct cards of the current deck with B not the deck's highest card and
  * class(A, B) allowed.  Per draw (range hand h, or the opponents) there is a fixed candidate list
@@ -604,7 +602,7 @@ int mcqo_run_ex2(int mode, int n_known, const uint8_t *known_cards, const uint32
         if (known_cards[2 * h] != 0xFF) { EX_SEE(known_cards[2 * h]); EX_SEE(known_cards[2 * h + 1]); }
 #undef EX_SEE
     mt_t mt;
-    xo_t xo;
+    js_t xo;
     rng_t rng = {mode, &mt, &xo};
     memset(out, 0, 13 * sizeof(uint64_t));
     mt.words = 0;
@@ -641,7 +639,7 @@ int mcqo_run_ex2(int mode, int n_known, const uint8_t *known_cards, const uint32
         }
     }
     for (uint32_t it = 0; it < runs; it++) {
-        if (mode == 1 && it % STREAM_ITERS == 0) xo_seed(&xo, seed, qid, it / STREAM_ITERS);
+        if (mode == 1 && it % STREAM_ITERS == 0) js_seed(&xo, seed, qid, it / STREAM_ITERS);
         deck_t d = original;
         uint8_t table[5], hole[10][2], hands[70];
         int w = 0; /* table draws of this iteration (CTR: two per word) */
@@ -674,8 +672,8 @@ int mcqo_run_ex2(int mode, int n_known, const uint8_t *known_cards, const uint32
                     A = deck_pop(&d, (int)r1);
                     B = deck_pop(&d, (int)r2);
                 }
-            } else if (!is_known && opp_all) { /* MCQ-CTR v3, one word, never re-drawn */
-                uint32_t dd = (uint32_t)d.n - 1, u = xo_next(&xo);
+            } else if (!is_known && opp_all) { /* MCQ-CTR v4, one word, never re-drawn */
+                uint32_t dd = (uint32_t)d.n - 1, u = js_next(&xo);
                 uint32_t a = (uint32_t)(((uint64_t)u * dd) >> 32), c = (uint32_t)(((uint64_t)(uint32_t)(u * dd) * dd) >> 32);
                 out[1]++;
                 A = deck_pop(&d, (int)(a != c ? a : dd));
@@ -685,7 +683,7 @@ int mcqo_run_ex2(int mode, int n_known, const uint8_t *known_cards, const uint32
                 for (uint32_t trial = 0;; trial++) {
                     if (trial >= EX_MAX_TRIALS) return -2;
                     out[1]++;
-                    const uint32_t k = (uint32_t)(((uint64_t)xo_next(&xo) * pcount[li]) >> 32);
+                    const uint32_t k = (uint32_t)(((uint64_t)js_next(&xo) * pcount[li]) >> 32);
                     A = (uint8_t)(plist[li][k] & 0xFF);
                     B = (uint8_t)(plist[li][k] >> 8);
                     int ia = -1, ib = -1;
@@ -703,7 +701,7 @@ int mcqo_run_ex2(int mode, int n_known, const uint8_t *known_cards, const uint32
         for (int k = nb; k < 5; k++, w++) { /* l.186-188 */
             uint32_t n = (uint32_t)d.n - 1, idx;
             if (mode == 0) idx = np_randint(&mt, n);
-            else if ((w & 1) == 0) { uint32_t u = xo_next(&xo); idx = (uint32_t)(((uint64_t)u * n) >> 32); word = u * n; }
+            else if ((w & 1) == 0) { uint32_t u = js_next(&xo); idx = (uint32_t)(((uint64_t)u * n) >> 32); word = u * n; }
             else idx = (uint32_t)(((uint64_t)word * n) >> 32);
             table[k] = deck_pop(&d, (int)idx);
         }

@@ -53,8 +53,8 @@ def lib():
         L.mcqo_np_randint.restype = C.c_uint64
         L.mcqo_philox4x32_10.argtypes = [u32p, u32p, u32p]
         L.mcqo_philox4x32_10.restype = None
-        L.mcqo_xoshiro_stream.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, u32p]
-        L.mcqo_xoshiro_stream.restype = None
+        L.mcqo_ctr_stream.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, u32p]
+        L.mcqo_ctr_stream.restype = None
         L.mcqo_calc_score.argtypes = [u8p, C.c_int, i32p]
         L.mcqo_calc_score.restype = None
         L.mcqo_compare.argtypes = [u8p, u8p]
@@ -110,9 +110,9 @@ def philox4x32_10(ctr, key):
     return out
 
 
-def xoshiro_stream(seed, qid, stream, n):
+def ctr_stream(seed, qid, stream, n):
     out = np.zeros(n, np.uint32)
-    lib().mcqo_xoshiro_stream(seed, qid, stream, n, _p(out, C.c_uint32))
+    lib().mcqo_ctr_stream(seed, qid, stream, n, _p(out, C.c_uint32))
     return out
 
 

@@ -88,7 +88,7 @@ static int run_ctr_t(const mcq_query *q, uint64_t seed, uint64_t qid, mcq_result
         for (uint32_t j = 0; j < MCQ_STREAM_ITERS; j++) {
             if ((uint64_t)s * MCQ_STREAM_ITERS + j >= q->runs) break;
             mcq_iteration(qc, dr, base, t.tf, t.tops, t.sd, acc);
-            acc.passes += qc.n_opp; /* MCQ-CTR v3: one attempt per opponent, never re-drawn */
+            acc.passes += qc.n_opp; /* MCQ-CTR v4: one attempt per opponent, never re-drawn */
         }
         fold(acc, out);
     }

@@ -58,17 +58,21 @@ def test_philox_known_answers():
                                                                            '0x24126ea1']
 
 
-def test_xoshiro128pp_reference_sequence():
-    # independent restatement of Blackman & Vigna's xoshiro128++ in Python ints
+def test_jsf32_reference_sequence():
+    # independent restatement of Bob Jenkins' small PRNG (jsf32, rotations 27 / 17) in Python ints, seeded with the
+    # Philox block of (seed, query id, stream) as MCQ-CTR v4 does
     def rotl(x, k):
         return ((x << k) | (x >> (32 - k))) & 0xffffffff
-    s = [int(x) for x in O.philox4x32_10([5, 0, 3, 0x4D435131], [77, 1])]
+    a, b, c, d = [int(x) for x in O.philox4x32_10([5, 0, 3, 0x4D435131], [77, 1])]
     exp = []
     for _ in range(64):
-        exp.append((rotl((s[0] + s[3]) & 0xffffffff, 7) + s[0]) & 0xffffffff)
-        t = (s[1] << 9) & 0xffffffff
-        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 11)
-    assert list(O.xoshiro_stream(77 + (1 << 32), 5, 3, 64)) == exp
+        e = (a - rotl(b, 27)) & 0xffffffff
+        a = b ^ rotl(c, 17)
+        b = (c + d) & 0xffffffff
+        c = (d + e) & 0xffffffff
+        d = (e + a) & 0xffffffff
+        exp.append(d)
+    assert list(O.ctr_stream(77 + (1 << 32), 5, 3, 64)) == exp
 
 
 # ------------------------------------------------------------------ evaluator
@@ -232,7 +236,7 @@ def test_reference_range_tests_statistically():
 
 
 def test_production_law_of_extended_queries_equals_the_reference_law():
-    """The production sampler of extended queries (MCQ-CTR v3x: rejection from a fixed candidate list, no index
+    """The production sampler of extended queries (MCQ-CTR v4x: rejection from a fixed candidate list, no index
     arithmetic) must deal the reference's LAW: on cases small enough to see differences of a few 1e-3, its equity
     agrees with the literal MT19937 walk of the reference's loops within Monte-Carlo noise (both 400k iterations,
     sigma of the difference 1.1e-3; bound 4.5e-3)."""
