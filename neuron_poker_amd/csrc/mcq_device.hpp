@@ -60,8 +60,17 @@ MCQ_HD uint32_t mcq_mulhi(uint32_t a, uint32_t b) {
 }
 // mulhi32(a, b) + 128: draw indices travel as r | 0x80 (r < 64), the form the byte-SWAR hole scan wants, so the
 // bias comes for free with the multiply (one v_mad_u64_u32)
-MCQ_HD uint32_t mcq_mulhi_p128(uint32_t a, uint32_t b) {
-    return (uint32_t)(((uint64_t)a * b + (128ull << 32)) >> 32);
+MCQ_HD uint32_t mcq_mulhi_p128(uint32_t a, uint32_t b, uint64_t bias /* 128 << 32, see mcq_p128_bias */) {
+    return (uint32_t)(((uint64_t)a * b + bias) >> 32);
+}
+// The bias as a value the optimiser cannot see through (device: pinned in a VGPR pair): left to itself the
+// compiler re-creates the constant with a v_mov_b64 in front of every multiply (fifteen per 6-max iteration).
+MCQ_HD uint64_t mcq_p128_bias() {
+    uint64_t x = 128ull << 32;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(x));
+#endif
+    return x;
 }
 MCQ_HD bool mcq_any(bool pred) { /* true if the predicate holds in any active lane of the wave */
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -275,11 +284,17 @@ struct McqCtrDrawsT {
     static constexpr uint32_t kTableShort = UNIFORM ? 0u : 1u; /* table draw range = deck length - kTableShort */
     McqJsf32 rng;
     uint32_t w;
+    uint64_t bias; /* mcq_p128_bias(), set once per stream (start) */
+    MCQ_HDM void start(uint64_t seed, uint64_t qid, uint32_t stream) {
+        w = 0;
+        bias = mcq_p128_bias();
+        rng.seed(seed, qid, stream);
+    }
     MCQ_HDM void pair(uint32_t L, uint32_t &r1, uint32_t &r2) {
         const uint32_t dd = L - 1u, m1 = UNIFORM ? L : dd;
         const uint32_t u = rng.next();
-        const uint32_t a = mcq_opaque(mcq_mulhi_p128(u, m1)); /* opaque: else a == c becomes a 64-bit compare + moves */
-        const uint32_t c = mcq_mulhi_p128(u * m1, dd);
+        const uint32_t a = mcq_opaque(mcq_mulhi_p128(u, m1, bias)); /* opaque: else a == c becomes a 64-bit compare + moves */
+        const uint32_t c = mcq_mulhi_p128(u * m1, dd, bias);
         r1 = (!UNIFORM && a == c) ? dd + 128u : a;
         r2 = c;
     }
@@ -288,9 +303,9 @@ struct McqCtrDrawsT {
         if ((K & 1) == 0) {
             const uint32_t u = rng.next();
             w = u * n;
-            return mcq_mulhi_p128(u, n);
+            return mcq_mulhi_p128(u, n, bias);
         }
-        return mcq_mulhi_p128(w, n);
+        return mcq_mulhi_p128(w, n, bias);
     }
 };
 typedef McqCtrDrawsT<false> McqCtrDraws;
@@ -920,6 +935,10 @@ struct McqExtCtrDraws {
     static constexpr bool kReplay = false;
     McqJsf32 rng;
     uint32_t w;
+    MCQ_HDM void start(uint64_t seed, uint64_t qid, uint32_t stream) {
+        w = 0;
+        rng.seed(seed, qid, stream);
+    }
     MCQ_HDM uint32_t pick(uint32_t n) { return mcq_mulhi(rng.next(), n); } /* a candidate of a list of n */
     MCQ_HDM void pair(uint32_t &, uint32_t &) {}
     MCQ_HDM void index_pair(uint32_t L, uint32_t &r1, uint32_t &r2) { /* MCQ-CTR v4 as the plain path: McqCtrDrawsT::pair */

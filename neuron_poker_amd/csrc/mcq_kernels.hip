@@ -338,8 +338,7 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
             const uint64_t it0 = (uint64_t)stream * MCQ_STREAM_ITERS + sub * chunk;
             if (it0 < qc.runs) {
                 McqCtrDrawsT<MODE == MCQ_INTERNAL_MODE_UNIFORM> dr;
-                dr.w = 0;
-                dr.rng.seed(seed, first_qid + qi, stream);
+                dr.start(seed, first_qid + qi, stream);
                 /* words per iteration: one per opponent, one per two table cards */
                 for (uint32_t k = sub * chunk * (qc.n_opp + ((qc.n_deal + 1u) >> 1)); k != 0; k--) dr.rng.next();
                 const uint32_t cnt = (uint32_t)min((uint64_t)chunk, (uint64_t)qc.runs - it0);
@@ -455,8 +454,7 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_direct_kernel(const uint4 
                     const uint64_t it0 = (uint64_t)stream * MCQ_STREAM_ITERS + sub * chunk;
                     if (it0 < qc.runs) {
                         McqCtrDrawsT<MODE == MCQ_INTERNAL_MODE_UNIFORM> dr;
-                        dr.w = 0;
-                        dr.rng.seed(seed, first_qid + qi, stream);
+                        dr.start(seed, first_qid + qi, stream);
                         for (uint32_t k = sub * chunk * (qc.n_opp + ((qc.n_deal + 1u) >> 1)); k != 0; k--) dr.rng.next();
                         const uint32_t cnt = (uint32_t)min((uint64_t)chunk, (uint64_t)qc.runs - it0);
                         for (uint32_t j = 0; j < cnt; j++) mcq_iteration(qc, dr, base - 128, g_tab->tf, tab.tops, tab.sd, acc);
@@ -680,8 +678,7 @@ __global__ __launch_bounds__(kExtBlock) void mcq_eval_ext_kernel(const mcq_query
             const uint64_t it0 = (uint64_t)stream * MCQ_STREAM_ITERS;
             if (it0 < qc.runs) {
                 McqExtCtrDraws dr;
-                dr.w = 0;
-                dr.rng.seed(seed, first_qid + qi, stream);
+                dr.start(seed, first_qid + qi, stream);
                 const uint32_t cnt = (uint32_t)min((uint64_t)MCQ_STREAM_ITERS, (uint64_t)qc.runs - it0);
                 for (uint32_t j = 0; j < cnt && !failed; j++)
                     failed = !mcq_iteration_ext(qc, wc, dr, cards, tab.sel8, my_lists, my_ids, kExtBlock, g_tab->tf, tab.tops,

@@ -38,7 +38,7 @@
 #define MCQ_L(name) name                      /* ... and its value in the current lane */
 #define MCQ_AT(name, idx) mcq_mt_shfl(name, idx) /* ... and in lane idx (written in an EARLIER region) */
 #define MCQ_AT_UNIFORM(name, idx) ((uint32_t)__builtin_amdgcn_readlane((int)(name), (int)(idx))) /* idx wave-uniform */
-#define MCQ_FOR_LANES(l) for (uint32_t l = mcq_mt_lane(), once_ = 1; once_; once_ = 0)
+#define MCQ_FOR_LANES(l) for (uint32_t l __attribute__((unused)) = mcq_mt_lane(), once_ = 1; once_; once_ = 0)
 #define MCQ_BALLOT(name) __ballot(name)
 /* number of set bits of the wave mask m below this lane */
 #define MCQ_COUNT_BELOW(m, l) __builtin_amdgcn_mbcnt_hi((uint32_t)((m) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(m), 0u))

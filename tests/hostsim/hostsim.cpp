@@ -82,8 +82,7 @@ static int run_ctr_t(const mcq_query *q, uint64_t seed, uint64_t qid, mcq_result
     uint32_t n_streams = (q->runs + MCQ_STREAM_ITERS - 1) / MCQ_STREAM_ITERS;
     for (uint32_t s = 0; s < n_streams; s++) {
         Draws dr;
-        dr.w = 0;
-        dr.rng.seed(seed, qid, s);
+        dr.start(seed, qid, s);
         McqLaneAcc acc = {0, 0, 0};
         for (uint32_t j = 0; j < MCQ_STREAM_ITERS; j++) {
             if ((uint64_t)s * MCQ_STREAM_ITERS + j >= q->runs) break;
@@ -212,8 +211,7 @@ extern "C" int hs_run_ext(int replay, const mcq_query *q, const mcq_query_ext *e
     uint32_t n_streams = (q->runs + MCQ_STREAM_ITERS - 1) / MCQ_STREAM_ITERS;
     for (uint32_t s = 0; s < n_streams; s++) {
         McqExtCtrDraws dr;
-        dr.w = 0;
-        dr.rng.seed(seed, qid, s);
+        dr.start(seed, qid, s);
         McqLaneAcc acc = {0, 0, 0};
         for (uint32_t j = 0; j < MCQ_STREAM_ITERS; j++) {
             if ((uint64_t)s * MCQ_STREAM_ITERS + j >= q->runs) break;
