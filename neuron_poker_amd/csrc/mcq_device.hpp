@@ -650,7 +650,8 @@ MCQ_HD void mcq_hole_count(uint32_t rb, uint32_t h, uint32_t &k) {
     k += (rb ^ h) & 1u;
     return;
 #endif
-    k = mcq_popc((rb - h) & 0x80808080u) + k; /* v_sub, v_and, v_bcnt (with its add) */
+    k = mcq_opaque(mcq_popc((rb - h) & 0x80808080u) + k); /* v_sub, v_and, v_bcnt with its add (opaque: else the compiler
+                                                            counts into zero and sums afterwards: one more add3) */
 }
 
 // table draw number K (0..4).  Two levels, because the table is dealt after ALL opponents (l.215-217): the K earlier
