@@ -63,6 +63,22 @@ MCQ_HD uint32_t mcq_mulhi(uint32_t a, uint32_t b) {
 MCQ_HD uint32_t mcq_mulhi_p128(uint32_t a, uint32_t b, uint64_t bias /* 128 << 32, see mcq_p128_bias */) {
     return (uint32_t)(((uint64_t)a * b + bias) >> 32);
 }
+// Both halves of the same product: the high word (biased as above) is returned, the low word -- the fraction that
+// feeds the next draw -- goes to `lo`.  The product is made opaque as ONE 64-bit value: otherwise the compiler
+// computes the low word a second time (v_mul_lo_u32 beside the v_mad_u64_u32; 32-bit multiplies issue at a quarter
+// of the plain VALU rate).
+MCQ_HD uint32_t mcq_mulhilo_p128(uint32_t a, uint32_t b, uint64_t bias, uint32_t &lo) {
+    uint64_t p = (uint64_t)a * b + bias;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(p));
+#endif
+    lo = (uint32_t)p;
+    uint32_t hi = (uint32_t)(p >> 32);
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(hi)); /* a 32-bit value from here on: else comparing two of them becomes a 64-bit compare + moves */
+#endif
+    return hi;
+}
 // The bias as a value the optimiser cannot see through (device: pinned in a VGPR pair): left to itself the
 // compiler re-creates the constant with a v_mov_b64 in front of every multiply (fifteen per 6-max iteration).
 MCQ_HD uint64_t mcq_p128_bias() {
@@ -207,8 +223,9 @@ MCQ_HD void mcq_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3
                               uint32_t out[4]) {
 #pragma unroll
     for (int r = 0; r < 10; r++) {
-        uint32_t h0 = mcq_mulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        uint32_t h1 = mcq_mulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        uint32_t l0, l1; /* both halves of a product from ONE v_mad_u64_u32 (not v_mul_hi_u32 + v_mul_lo_u32) */
+        const uint32_t h0 = mcq_mulhilo_p128(0xD2511F53u, c0, 0ull, l0);
+        const uint32_t h1 = mcq_mulhilo_p128(0xCD9E8D57u, c2, 0ull, l1);
         uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
         c0 = n0; c1 = l1; c2 = n2; c3 = l0;
         k0 += 0x9E3779B9u;
@@ -293,8 +310,9 @@ struct McqCtrDrawsT {
     MCQ_HDM void pair(uint32_t L, uint32_t &r1, uint32_t &r2) {
         const uint32_t dd = L - 1u, m1 = UNIFORM ? L : dd;
         const uint32_t u = rng.next();
-        const uint32_t a = mcq_opaque(mcq_mulhi_p128(u, m1, bias)); /* opaque: else a == c becomes a 64-bit compare + moves */
-        const uint32_t c = mcq_mulhi_p128(u * m1, dd, bias);
+        uint32_t frac; /* u * m1 mod 2^32 */
+        const uint32_t a = mcq_mulhilo_p128(u, m1, bias, frac); /* (opaque: else a == c becomes a 64-bit compare + moves) */
+        const uint32_t c = mcq_mulhi_p128(frac, dd, bias);
         r1 = (!UNIFORM && a == c) ? dd + 128u : a;
         r2 = c;
     }
@@ -302,8 +320,7 @@ struct McqCtrDrawsT {
     MCQ_HDM uint32_t table(uint32_t n) {
         if ((K & 1) == 0) {
             const uint32_t u = rng.next();
-            w = u * n;
-            return mcq_mulhi_p128(u, n, bias);
+            return mcq_mulhilo_p128(u, n, bias, w); /* w = u * n mod 2^32 */
         }
         return mcq_mulhi_p128(w, n, bias);
     }
@@ -945,16 +962,16 @@ struct McqExtCtrDraws {
     MCQ_HDM void index_pair(uint32_t L, uint32_t &r1, uint32_t &r2) { /* MCQ-CTR v4 as the plain path: McqCtrDrawsT::pair */
         const uint32_t dd = L - 1u;
         const uint32_t u = rng.next();
-        const uint32_t a = mcq_mulhi(u, dd);
-        const uint32_t c = mcq_mulhi(u * dd, dd);
+        uint32_t frac;
+        const uint32_t a = mcq_mulhilo_p128(u, dd, 0ull, frac);
+        const uint32_t c = mcq_mulhi(frac, dd);
         r1 = a == c ? dd : a;
         r2 = c;
     }
     MCQ_HDM uint32_t table(uint32_t k, uint32_t n) {
         if ((k & 1u) == 0) {
             const uint32_t u = rng.next();
-            w = u * n;
-            return mcq_mulhi(u, n);
+            return mcq_mulhilo_p128(u, n, 0ull, w);
         }
         return mcq_mulhi(w, n);
     }
