@@ -240,7 +240,7 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    eng = npa.Engine(local_rank)
+    eng = npa.Engine(local_rank, kernel_times=True)
     B, N, runs = args.states, args.players, args.iters
     hole, board = make_states(B, rank)
     q = npa.pack_queries(hole, board, N, runs)

@@ -177,12 +177,14 @@ MCQ_API int mcq_exact_batch(mcq_ctx *ctx, const mcq_query *q, size_t n, int law,
 /* Select the dealing law used by MCQ_MODE_PHILOX on this context (MCQ_LAW_*). */
 MCQ_API int mcq_set_dealing_law(mcq_ctx *ctx, int law);
 
-/* Every evaluation-kernel launch carries a pair of HIP events that take the kernel's own begin and end timestamps
+/* Kernel timing (off by default: a timestamped launch costs a small query about 6 us of its call time).  When on,
+ * every evaluation-kernel launch carries a pair of HIP events that take the kernel's own begin and end timestamps
  * on the stream it is launched on (a ring of the 64 most recent launches; in parity mode the pair spans the stream
  * walk and the evaluation kernel; launches recorded into a stream capture are not timed).  mcq_kernel_times writes
  * the durations in milliseconds of the latest min(max_n, 64, launches so far) launches, oldest first, and returns how
  * many; it waits for the newest of them to have finished.  mcq_last_kernel_ms: the most recent host-entry call's
- * total (all chunks), else the latest launch. */
+ * total (all chunks), else the latest launch; 0 while timing is off.  The contexts of an mcq_multi always time. */
+MCQ_API int mcq_set_kernel_timing(mcq_ctx *ctx, int on);
 MCQ_API int mcq_kernel_times(mcq_ctx *ctx, float *ms, int max_n);
 MCQ_API float mcq_last_kernel_ms(mcq_ctx *ctx);
 

@@ -101,6 +101,8 @@ def load_library():
         L.mcq_exact_batch.restype = C.c_int
         L.mcq_set_dealing_law.argtypes = [vp, C.c_int]
         L.mcq_set_dealing_law.restype = C.c_int
+        L.mcq_set_kernel_timing.argtypes = [vp, C.c_int]
+        L.mcq_set_kernel_timing.restype = C.c_int
         L.mcq_kernel_times.argtypes = [vp, vp, C.c_int]
         L.mcq_kernel_times.restype = C.c_int
         L.mcq_last_kernel_ms.argtypes = [vp]
@@ -240,13 +242,22 @@ def pack_query_ext(n, ghost=None, known2=None, hero_range=None, opp_range=None, 
 class Engine:
     """One mcq_ctx: an equity engine bound to one GPU.  Not re-entrant (one call in flight per engine)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, kernel_times=False):
         self._lib = load_library()
         self._ctx = self._lib.mcq_create(int(device), 0)
         if not self._ctx:
             msg = (self._lib.mcq_last_error() or b"").decode("utf-8", "replace")
             raise McqError("mcq_create(device=%d) failed: %s" % (device, msg))
         self.device = int(device)
+        if kernel_times:
+            self.set_kernel_timing(True)
+
+    def set_kernel_timing(self, on):
+        """Timestamp every evaluation-kernel launch (kernel_times / last_kernel_ms); off by default: it costs a small
+        query about 6 us of its call time."""
+        rc = self._lib.mcq_set_kernel_timing(self._ctx, 1 if on else 0)
+        if rc:
+            _raise(rc)
 
     def close(self):
         if getattr(self, "_ctx", None):

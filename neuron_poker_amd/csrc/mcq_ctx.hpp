@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/mcq.h"
+#include "mcq_internal.hpp"
 #include "mcq_layout.hpp"
 
 struct McqTables;
@@ -132,6 +133,8 @@ struct mcq_ctx {
     PinBuf h_q, h_res, h_draws, h_off, h_misc, h_flag;
     DevBuf d_done;                /* block counter of the one-launch path */
     uint32_t direct_ticket = 0;   /* value the kernel raises the flag in h_flag to */
+    McqDirectKarg direct_karg; /* one-launch path: the work of a small launch, passed by value */
+    bool timing = false; /* mcq_set_kernel_timing: launches carry timestamp events */
     bool direct_poll = true;      /* pick the rows up at the flag instead of synchronising the stream (MCQ_DIRECT_POLL) */
     McqDirectLayout direct_layout;      /* the one-launch path's layout of the current call */
     std::vector<uint64_t> direct_cost;

@@ -129,7 +129,7 @@ int mcq_run_slice(mcq_ctx *c, int mode, const mcq_query *d_q, uint32_t n, mcq_re
                   const uint64_t *d_prefix_ready) {
     if (mode == MCQ_MODE_PHILOX && c->law == MCQ_LAW_UNIFORM) mode = MCQ_INTERNAL_MODE_UNIFORM;
     const bool capturing = stream_capturing(s);
-    if (capturing) timed = false; /* events recorded inside a capture cannot be read back */
+    if (capturing || !c->timing) timed = false; /* events recorded inside a capture cannot be read back */
     mcq_ctx::Scratch *sc = nullptr;
     const uint64_t *d_prefix = d_prefix_ready;
     if (!d_prefix) {
@@ -284,7 +284,7 @@ int replay_batch(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed, uint64
         if (rc) return rc;
         HIP_TRY(hipStreamSynchronize(c->stream)); /* staging buffers are reused by the next chunk */
         float ms = 0.f;
-        if (mcq_kernel_times(c, &ms, 1) == 1) replay_ms += ms;
+        if (c->timing && mcq_kernel_times(c, &ms, 1) == 1) replay_ms += ms;
         a = b;
     }
     HIP_TRY(hipMemcpyAsync(c->h_res.p, c->d_res.p, n * sizeof(mcq_result), hipMemcpyDeviceToHost, c->stream));
@@ -333,6 +333,7 @@ mcq_ctx *mcq_ctx_clone(const mcq_ctx *c) {
         d->load_waves = c->load_waves;
         d->direct_max_tasks = c->direct_max_tasks;
         d->direct_poll = c->direct_poll;
+        d->timing = c->timing;
         d->replay_device_bytes = c->replay_device_bytes;
     }
     return d;
@@ -413,7 +414,7 @@ mcq_ctx *mcq_create(int device, int flags) {
     }
     if (const char *e = getenv("MCQ_DIRECT_MAX_TASKS")) { /* tuning knob, see eval_host_philox */
         const int v = atoi(e);
-        c->direct_max_tasks = (uint32_t)(v < 0 ? 0 : v);
+        c->direct_max_tasks = (uint32_t)(v < 0 ? 0 : v > (int)MCQ_DIRECT_TASKS_LIMIT ? (int)MCQ_DIRECT_TASKS_LIMIT : v);
     }
     if (const char *e = getenv("MCQ_DIRECT_POLL")) c->direct_poll = atoi(e) != 0;
     if (const char *e = getenv("MCQ_LOAD_WAVES")) { /* tuning knob, see pick_geometry */
@@ -460,6 +461,12 @@ int mcq_kernel_times(mcq_ctx *c, float *ms, int max_n) {
     return n;
 }
 
+int mcq_set_kernel_timing(mcq_ctx *c, int on) {
+    if (!c) return mcq_fail(MCQ_EINVAL, "mcq_set_kernel_timing: null context");
+    c->timing = on != 0;
+    return MCQ_OK;
+}
+
 int mcq_set_dealing_law(mcq_ctx *c, int law) {
     if (!c || (law != MCQ_LAW_REFERENCE && law != MCQ_LAW_UNIFORM)) return mcq_fail(MCQ_EINVAL, "mcq_set_dealing_law: bad argument");
     c->law = law;
@@ -470,6 +477,7 @@ float mcq_last_kernel_ms(mcq_ctx *c) {
     float ms = 0.f;
     if (!c) return 0.f;
     if (c->last_ms > 0.f) return c->last_ms;
+    if (!c->timing) return 0.f;
     return mcq_kernel_times(c, &ms, 1) == 1 ? ms : 0.f;
 }
 
@@ -542,6 +550,13 @@ static int eval_host_philox(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t s
          * query's wave count and the wave's cut number), then one query index per wave */
         mcq_query *work_rec = reinterpret_cast<mcq_query *>(static_cast<char *>(c->h_q.p) + a_off);
         uint32_t *work_qi = reinterpret_cast<uint32_t *>(work_rec + a_words);
+        /* a launch of few waves carries its work in the kernel arguments instead (no read across PCIe by the kernel) */
+        const bool by_karg = a_words <= MCQ_DIRECT_KARG_SLOTS && rounds <= 8u;
+        McqDirectKarg &karg = c->direct_karg;
+        if (by_karg) {
+            work_rec = reinterpret_cast<mcq_query *>(karg.rec);
+            work_qi = karg.qi;
+        }
         memcpy(work_qi, lay.slot_qi.data(), a_words * sizeof(uint32_t));
         for (size_t k = 0; k < a_words; k++) {
             const uint32_t i = lay.slot_qi[k];
@@ -560,6 +575,7 @@ static int eval_host_philox(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t s
         if (++c->direct_ticket == 0u) c->direct_ticket = 1u; /* 0 is the flag's resting value */
         const uint32_t ticket = c->direct_ticket;
         const int slot = (int)(c->n_timed % mcq_ctx::kRing);
+        const bool timed = c->timing;
         c->last_ms = 0.f;
         static const bool trace = getenv("MCQ_TRACE") != nullptr; /* phase times of this path on stderr (tuning) */
         const auto t0 = std::chrono::steady_clock::now();
@@ -567,9 +583,10 @@ static int eval_host_philox(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t s
         HIP_TRY(mcq_launch_eval_direct((int)mode, dev_rec,
                                        reinterpret_cast<const uint32_t *>(dev_rec + a_words * sizeof(mcq_query)), rounds,
                                        lay.merge ? 1u : 0u, (mcq_result *)c->h_res.dev, seed, first_query_id, c->d_luts, grid,
-                                       (uint32_t *)c->d_done.p, (uint32_t *)c->h_flag.dev, ticket, c->stream, c->ev0[slot],
-                                       c->ev1[slot]));
-        c->n_timed++;
+                                       (uint32_t *)c->d_done.p, (uint32_t *)c->h_flag.dev, ticket, c->stream,
+                                       timed ? c->ev0[slot] : nullptr, timed ? c->ev1[slot] : nullptr,
+                                       by_karg ? &karg : nullptr));
+        if (timed) c->n_timed++;
         const auto t1 = std::chrono::steady_clock::now();
         /* The last block raises a flag in pinned memory once every row is out: picking the rows up there saves the
          * end-of-kernel handshake of a stream synchronisation (measured: 14 us of a 40 us call).  A kernel that has
@@ -591,7 +608,7 @@ static int eval_host_philox(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t s
                 return std::chrono::duration<double, std::micro>(b - a).count();
             };
             float kms = 0.f;
-            (void)mcq_kernel_times(c, &kms, 1);
+            if (timed) (void)mcq_kernel_times(c, &kms, 1);
             fprintf(stderr, "mcq direct n=%zu waves=%llu grid=%u rounds=%u: launch %.1f us, wait %.1f us (%s), copy out %.1f us, "
                     "kernel %.1f us\n", n, (unsigned long long)lay.waves, grid, rounds, us(t0, t1), us(t1, t2),
                     seen ? "flag" : "stream sync", us(t2, std::chrono::steady_clock::now()), 1e3 * kms);
@@ -615,7 +632,7 @@ static int eval_host_philox(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t s
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemsetAsync(c->d_res.p, 0, r_bytes, c->stream)); /* not waited for: the next call finds its rows zero */
     c->res_clean = r_bytes;
-    if (!total_tasks || mcq_kernel_times(c, &c->last_ms, 1) != 1) c->last_ms = 0.f;
+    if (!total_tasks || !c->timing || mcq_kernel_times(c, &c->last_ms, 1) != 1) c->last_ms = 0.f;
     memcpy(out, c->h_res.p, r_bytes);
     for (size_t i = 0; i < n; i++) out[i].runs = mcq_part(tasks_of(q[i]), q[i].runs, part, n_parts).runs;
     return MCQ_OK;
@@ -748,11 +765,12 @@ int mcq_eval_batch_ext(mcq_ctx *c, const mcq_query *q, const mcq_query_ext *ext,
     HIP_TRY(mcq_launch_eval_ext(mode, (const mcq_query *)c->d_q.p, (const mcq_query_ext *)c->d_ext.p, (uint32_t)n,
                                 (const uint64_t *)c->scratch[0].prefix.p, (mcq_result *)c->d_res.p, seed, first_query_id, c->d_luts,
                                 (const uint8_t *)c->d_draws.p, (const uint64_t *)c->d_off.p, (const uint16_t *)c->d_lists.p,
-                                (const uint32_t *)c->d_cnts.p, lists_stride, grid, block, c->stream, c->ev0[slot], c->ev1[slot]));
-    c->n_timed++;
+                                (const uint32_t *)c->d_cnts.p, lists_stride, grid, block, c->stream,
+                                c->timing ? c->ev0[slot] : nullptr, c->timing ? c->ev1[slot] : nullptr));
+    if (c->timing) c->n_timed++;
     HIP_TRY(hipMemcpyAsync(c->h_res.p, c->d_res.p, n * sizeof(mcq_result), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (mcq_kernel_times(c, &c->last_ms, 1) != 1) c->last_ms = 0.f;
+    if (!c->timing || mcq_kernel_times(c, &c->last_ms, 1) != 1) c->last_ms = 0.f;
     const mcq_result *hr = (const mcq_result *)c->h_res.p;
     for (size_t i = 0; i < n; i++)
         if (hr[i].runs != q[i].runs)

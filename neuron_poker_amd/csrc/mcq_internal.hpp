@@ -40,7 +40,13 @@ hipError_t mcq_launch_mt_parse(const mcq_query *d_q, uint32_t n, uint32_t seed32
 /* small queries, one launch and nothing else: work_rec / work_qi (the work laid out wave by wave, see the kernel), res
  * and done_flag may be pinned host memory (device-visible); d_done: a zeroed device word */
 #define MCQ_DIRECT_IDLE 0xFFFFFFFFu
+#define MCQ_DIRECT_KARG_SLOTS 128u /* one-launch path: the work of a launch this small travels in the kernel arguments */
+struct McqDirectKarg {
+    uint32_t rec[MCQ_DIRECT_KARG_SLOTS][4]; /* per wave slot: the query record (16 B) */
+    uint32_t qi[MCQ_DIRECT_KARG_SLOTS];     /* per wave slot: the query index or MCQ_DIRECT_IDLE */
+};
+#define MCQ_DIRECT_TASKS_LIMIT 32u /* most tasks of a query on the one-launch path: its row sums add two counters per word */
 hipError_t mcq_launch_eval_direct(int mode, const void *work_rec, const uint32_t *work_qi, uint32_t rounds, uint32_t merge,
                                   mcq_result *res, uint64_t seed, uint64_t first_qid, const McqTables *d_luts, uint32_t grid,
                                   uint32_t *d_done, uint32_t *done_flag, uint32_t ticket, hipStream_t s, hipEvent_t t0,
-                                  hipEvent_t t1);
+                                  hipEvent_t t1, const McqDirectKarg *karg /* or null: read work_rec / work_qi */);

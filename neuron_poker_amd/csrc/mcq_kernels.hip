@@ -24,6 +24,26 @@ namespace {
 constexpr int kMaxBlock = 1024; /* 16 waves = 4 per SIMD; one block per CU: tables 97 KB + 16 base decks 16 KB of the 160 KB LDS */
 constexpr int kExtBlock = 1024; /* extended queries: 40 KB of dealt card ids beside the tables */
 
+// A launch with or without the pair of timestamp events (mcq_set_kernel_timing): the timestamped form costs a
+// one-launch query about 6 us of its call time on this pool (tools/launch_floor.hip), so it is only used on request.
+#define MCQ_LAUNCH_TIMED(kern, grid, block, ...)                                                  \
+    do {                                                                                          \
+        if (t0 || t1) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, s, t0, t1, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, s, __VA_ARGS__);                \
+    } while (0)
+
+// Sum over the 64 lanes of a whole wave (EXEC full), wave-uniform result: four DPP adds bring every 16-lane row to
+// its row sum (quad_perm [1,0,3,2], [2,3,0,1], row_ror:4, row_ror:8 -- plain VALU rate), four v_readlane add the rows.
+// The shuffle form below goes through the LDS crossbar once per step (ds_bpermute): ~1 us for a row of twelve sums.
+__device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16) +
+           (uint32_t)__builtin_amdgcn_readlane((int)v, 32) + (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+}
+
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -217,19 +237,29 @@ struct WaveTally { /* per-lane running sums of the current (wave, query) pair */
         passes += a.passes;
         dirty = true;
     }
-    /* lanes -> wave: lane k < 12 returns word k + 1 of the result row (passes, win, tie, by_type[9]) */
+    /* lanes -> wave: lane k < 12 returns word k + 1 of the result row (passes, win, tie, by_type[9]).  For the
+     * one-launch path: the whole wave is active and a lane has added at most MCQ_DIRECT_TASKS_LIMIT tasks of 16
+     * iterations, so a counter's wave sum is below 2^16 and two counters share a reduction. */
     __device__ __forceinline__ unsigned long long row_words(uint32_t lane) {
+        static_assert(64u * 16u * MCQ_DIRECT_TASKS_LIMIT < 65536u, "two counters per 32-bit reduction");
+        uint32_t sums[MCQ_N_CODES + 1]; /* the codes (5 unused), then the ties */
+#pragma unroll
+        for (uint32_t c = 0; c < MCQ_N_CODES; c += 2) {
+            const uint32_t hi = c + 1 < MCQ_N_CODES ? code[c + 1] : 0u;
+            const uint32_t v = wave_sum_dpp(code[c] | (hi << 16));
+            sums[c] = v & 0xFFFFu;
+            sums[c + 1] = v >> 16;
+        }
+        const uint32_t ties = wave_sum_dpp(tie);
+        const uint32_t pass = wave_sum_dpp(passes);
         uint32_t wins = 0;
         unsigned long long mine = 0;
 #pragma unroll
         for (uint32_t c = 0; c < MCQ_N_CODES; c++) {
             if (c == 5) continue;
-            const uint32_t v = wave_sum(code[c]);
-            wins += v;
-            if (lane == 3u + mcq_code_to_type(c)) mine = v;
+            wins += sums[c];
+            if (lane == 3u + mcq_code_to_type(c)) mine = sums[c];
         }
-        const uint32_t ties = wave_sum(tie);
-        const uint32_t pass = wave_sum(passes);
         if (lane == 0) mine = pass;
         if (lane == 1) mine = wins - ties;
         if (lane == 2) mine = ties;
@@ -383,13 +413,25 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
 // reset by the last block) counts finished blocks; the last one raises done_flag (pinned host memory) to `ticket`
 // after a system-scope fence, which lets the host pick the rows up without waiting for the end-of-grid handshake.
 #define MCQ_DIRECT_STAGE_ROUNDS 8u
+#ifdef MCQ_DIRECT_STAMPS /* diagnostic build (tools/direct_stamps.py): 100 MHz timestamps of block 0's waves */
+__device__ unsigned long long mcq_direct_stamps[16][16];
+#define MCQ_STAMP(k)                                                                                           \
+    do {                                                                                                       \
+        if (blockIdx.x == 0 && (threadIdx.x & 63u) == 0) mcq_direct_stamps[threadIdx.x >> 6][k] = wall_clock64(); \
+    } while (0)
+extern "C" __attribute__((visibility("default"))) int mcq_debug_read_stamps(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mcq_direct_stamps), sizeof(mcq_direct_stamps));
+}
+#else
+#define MCQ_STAMP(k)
+#endif
 template <int MODE>
 __global__ __launch_bounds__(kMaxBlock) void mcq_eval_direct_kernel(const uint4 *__restrict__ work_rec,
                                                                     const uint32_t *__restrict__ work_qi, uint32_t rounds,
                                                                     uint32_t merge, mcq_result *__restrict__ res, uint64_t seed,
                                                                     uint64_t first_qid, const McqTables *__restrict__ g_tab,
                                                                     uint32_t *__restrict__ done, volatile uint32_t *done_flag,
-                                                                    uint32_t ticket) {
+                                                                    uint32_t ticket, uint32_t use_karg, McqDirectKarg karg) {
     constexpr uint32_t kWaves = kMaxBlock / 64, kStage = MCQ_DIRECT_STAGE_ROUNDS * kWaves;
     __shared__ __attribute__((aligned(16))) LdsTablesEval tab;
     __shared__ McqCard base_tab[kMaxBlock];
@@ -400,14 +442,21 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_direct_kernel(const uint4 
     const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
     McqCard *base = base_tab + (threadIdx.x & ~63u);
     /* the first rounds' work: the loads leave before the table image is fetched, their latency hides behind it */
+    MCQ_STAMP(0);
     uint4 pre_rec = {0u, 0u, 0u, 0u};
     uint32_t pre_qi = MCQ_DIRECT_IDLE;
     if (threadIdx.x < kStage && threadIdx.x / kWaves < rounds) {
         const size_t at = ((size_t)(threadIdx.x / kWaves) * gridDim.x + blockIdx.x) * kWaves + threadIdx.x % kWaves;
-        pre_qi = work_qi[at];
-        pre_rec = work_rec[at];
+        if (use_karg) { /* a small launch: its work came with the kernel arguments (no read across PCIe) */
+            pre_qi = karg.qi[at];
+            pre_rec = make_uint4(karg.rec[at][0], karg.rec[at][1], karg.rec[at][2], karg.rec[at][3]);
+        } else {
+            pre_qi = work_qi[at];
+            pre_rec = work_rec[at];
+        }
     }
     load_tables(tab, g_tab);
+    MCQ_STAMP(1);
     for (uint32_t g0 = 0; g0 < rounds; g0 += MCQ_DIRECT_STAGE_ROUNDS) {
         if (g0) __syncthreads(); /* the previous rounds' work has been read by every wave */
         if (threadIdx.x < kStage) {
@@ -424,6 +473,7 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_direct_kernel(const uint4 
             s_rec[threadIdx.x] = pre_rec;
         }
         __syncthreads();
+        MCQ_STAMP(2);
         const uint32_t g1 = g0 + MCQ_DIRECT_STAGE_ROUNDS < rounds ? g0 + MCQ_DIRECT_STAGE_ROUNDS : rounds;
         for (uint32_t round = g0; round < g1; round++) {
             const uint32_t at = (round - g0) * kWaves + wib;
@@ -445,6 +495,7 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_direct_kernel(const uint4 
                 base[lane] = mcq_base_entry(qc, lane, tab.sel8);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+                MCQ_STAMP(3);
                 WaveTally tally;
                 tally.clear();
                 const uint32_t tasks = mcq_task_count(q);
@@ -455,12 +506,16 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_direct_kernel(const uint4 
                     if (it0 < qc.runs) {
                         McqCtrDrawsT<MODE == MCQ_INTERNAL_MODE_UNIFORM> dr;
                         dr.start(seed, first_qid + qi, stream);
+                        MCQ_STAMP(4);
                         for (uint32_t k = sub * chunk * (qc.n_opp + ((qc.n_deal + 1u) >> 1)); k != 0; k--) dr.rng.next();
+                        MCQ_STAMP(5);
                         const uint32_t cnt = (uint32_t)min((uint64_t)chunk, (uint64_t)qc.runs - it0);
                         for (uint32_t j = 0; j < cnt; j++) mcq_iteration(qc, dr, base - 128, g_tab->tf, tab.tops, tab.sd, acc);
                         acc.passes = cnt * qc.n_opp;
+                        MCQ_STAMP(6);
                     }
                     tally.add(acc);
+                    MCQ_STAMP(7);
                 }
                 mine = tally.row_words(lane);
             }
@@ -474,6 +529,7 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_direct_kernel(const uint4 
                 continue;
             }
             if (lane < 12u) partial[round & 1u][wib][lane] = mine;
+            MCQ_STAMP(8);
             __syncthreads(); /* every wave of the block, every round; two buffers: a wave may run one round ahead */
             if (work && sub == 0u) {
                 unsigned long long v = runs;
@@ -483,20 +539,25 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_direct_kernel(const uint4 
                 }
                 reinterpret_cast<unsigned long long *>(res + qi)[w] = v;
             }
+            MCQ_STAMP(9);
         }
     }
     /* completion: rows first (ONE system-scope release per block, behind the barrier that orders the other waves'
      * stores before it -- a fence in every wave would write the L2 back 16 times over), then the count; the block
      * that completes the count tells the host */
     __syncthreads();
+    MCQ_STAMP(10);
     if (threadIdx.x == 0) {
-        __threadfence_system();
-        const uint32_t prev = atomicAdd(done, 1u);
-        if (prev + 1u == gridDim.x) {
-            *done = 0; /* ready for the next launch on this stream */
-            __threadfence_system();
-            *done_flag = ticket;
+        __threadfence_system(); /* this block's rows have reached the host's memory */
+        MCQ_STAMP(11);
+        bool last = true;
+        if (gridDim.x > 1u) { /* each block counts itself in behind its own release; the one that completes the
+                               * count has therefore seen every block's rows leave */
+            last = atomicAdd(done, 1u) + 1u == gridDim.x;
+            if (last) *done = 0; /* ready for the next launch on this stream */
         }
+        if (last) *done_flag = ticket;
+        MCQ_STAMP(12);
     }
 }
 
@@ -822,10 +883,10 @@ hipError_t mcq_launch_eval(int mode, const mcq_query *d_q, uint32_t n, const uin
 #define MCQ_LAUNCH_EVAL(M)                                                                                          \
     do {                                                                                                            \
         if (split)                                                                                                  \
-            hipExtLaunchKernelGGL((mcq_eval_kernel<M, true>), dim3(grid), dim3(block), 0, s, t0, t1, 0, d_q, n,     \
+            MCQ_LAUNCH_TIMED((mcq_eval_kernel<M, true>), grid, block, d_q, n,     \
                                   d_prefix, d_res, seed, first_qid, d_luts, d_draws, d_draw_off, split, part, n_parts, work_wpb); \
         else                                                                                                        \
-            hipExtLaunchKernelGGL((mcq_eval_kernel<M, false>), dim3(grid), dim3(block), 0, s, t0, t1, 0, d_q, n,    \
+            MCQ_LAUNCH_TIMED((mcq_eval_kernel<M, false>), grid, block, d_q, n,    \
                                   d_prefix, d_res, seed, first_qid, d_luts, d_draws, d_draw_off, 0u, part, n_parts, work_wpb); \
     } while (0)
     if (mode == MCQ_MODE_PHILOX) MCQ_LAUNCH_EVAL(MCQ_MODE_PHILOX);
@@ -838,15 +899,20 @@ hipError_t mcq_launch_eval(int mode, const mcq_query *d_q, uint32_t n, const uin
 hipError_t mcq_launch_eval_direct(int mode, const void *work_rec, const uint32_t *work_qi, uint32_t rounds, uint32_t merge,
                                   mcq_result *res, uint64_t seed, uint64_t first_qid, const McqTables *d_luts, uint32_t grid,
                                   uint32_t *d_done, uint32_t *done_flag, uint32_t ticket, hipStream_t s, hipEvent_t t0,
-                                  hipEvent_t t1) {
+                                  hipEvent_t t1, const McqDirectKarg *karg) {
     if (grid == 0 || rounds == 0) return hipErrorInvalidValue;
+    if (karg && (uint64_t)grid * rounds * (kMaxBlock / 64) > MCQ_DIRECT_KARG_SLOTS) return hipErrorInvalidValue;
+    if (karg && rounds > MCQ_DIRECT_STAGE_ROUNDS) return hipErrorInvalidValue; /* the kernel reads them in its first stage only */
     const uint4 *rec = static_cast<const uint4 *>(work_rec);
+    static const McqDirectKarg none = {};
+    const uint32_t use = karg ? 1u : 0u;
+    const McqDirectKarg &ka = karg ? *karg : none;
     if (mode == MCQ_INTERNAL_MODE_UNIFORM)
-        hipExtLaunchKernelGGL((mcq_eval_direct_kernel<MCQ_INTERNAL_MODE_UNIFORM>), dim3(grid), dim3(kMaxBlock), 0, s, t0, t1, 0, rec,
-                              work_qi, rounds, merge, res, seed, first_qid, d_luts, d_done, done_flag, ticket);
+        MCQ_LAUNCH_TIMED((mcq_eval_direct_kernel<MCQ_INTERNAL_MODE_UNIFORM>), grid, kMaxBlock, rec,
+                              work_qi, rounds, merge, res, seed, first_qid, d_luts, d_done, done_flag, ticket, use, ka);
     else
-        hipExtLaunchKernelGGL((mcq_eval_direct_kernel<MCQ_MODE_PHILOX>), dim3(grid), dim3(kMaxBlock), 0, s, t0, t1, 0, rec, work_qi,
-                              rounds, merge, res, seed, first_qid, d_luts, d_done, done_flag, ticket);
+        MCQ_LAUNCH_TIMED((mcq_eval_direct_kernel<MCQ_MODE_PHILOX>), grid, kMaxBlock, rec, work_qi,
+                              rounds, merge, res, seed, first_qid, d_luts, d_done, done_flag, ticket, use, ka);
     return hipGetLastError();
 }
 
@@ -888,10 +954,10 @@ hipError_t mcq_launch_eval_ext(int mode, const mcq_query *d_q, const mcq_query_e
                                const uint16_t *d_lists, const uint32_t *d_cnts, uint32_t lists_stride, uint32_t grid,
                                uint32_t block, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
     if (mode == MCQ_MODE_PHILOX)
-        hipExtLaunchKernelGGL(mcq_eval_ext_kernel<MCQ_MODE_PHILOX>, dim3(grid), dim3(block), 0, s, t0, t1, 0, d_q, d_ext, n,
+        MCQ_LAUNCH_TIMED(mcq_eval_ext_kernel<MCQ_MODE_PHILOX>, grid, block, d_q, d_ext, n,
                               d_prefix, d_res, seed, first_qid, d_luts, d_draws, d_draw_off, d_lists, d_cnts, lists_stride);
     else
-        hipExtLaunchKernelGGL(mcq_eval_ext_kernel<MCQ_MODE_REPLAY_MT19937>, dim3(grid), dim3(block), 0, s, t0, t1, 0, d_q, d_ext,
+        MCQ_LAUNCH_TIMED(mcq_eval_ext_kernel<MCQ_MODE_REPLAY_MT19937>, grid, block, d_q, d_ext,
                               n, d_prefix, d_res, seed, first_qid, d_luts, d_draws, d_draw_off, d_lists, d_cnts, lists_stride);
     return hipGetLastError();
 }

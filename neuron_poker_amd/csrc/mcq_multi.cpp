@@ -403,6 +403,7 @@ mcq_multi *mcq_multi_create(const int *devices, int n_shards, int flags) {
             Shard &sh = m->shards[(size_t)s];
             sh.ctx = mcq_create(sh.device, 0);
             if (!sh.ctx) { mcq_multi_destroy(m); return nullptr; }
+            sh.ctx->timing = true; /* mcq_multi_times reports the shards' kernel times; these are bulk launches */
             McqDeviceScope dev(sh.device);
             hipError_t e2 = hipEventCreateWithFlags(&sh.launched, hipEventDisableTiming);
             if (e2 == hipSuccess && s == m->primary_shard[0]) {

@@ -23,7 +23,7 @@ G = os.path.join(os.path.dirname(__file__), "golden")
 
 @pytest.fixture(scope="module")
 def eng():
-    e = npa.Engine(0)
+    e = npa.Engine(0, kernel_times=True)
     yield e
     e.close()
 
@@ -574,7 +574,7 @@ def test_one_launch_path_for_small_queries_equals_the_general_path(monkeypatch):
     monkeypatch.setenv("MCQ_DIRECT_MAX_TASKS", "0")
     general = npa.Engine(0)
     monkeypatch.setenv("MCQ_DIRECT_MAX_TASKS", "8")
-    direct = npa.Engine(0)
+    direct = npa.Engine(0, kernel_times=True)
     try:
         for n in (1, 2, 3, 100, 257, 1000, 5000):      # 16, 16, 16, 16, 8, 4, 1 waves per query
             q = batch(n)
@@ -584,6 +584,10 @@ def test_one_launch_path_for_small_queries_equals_the_general_path(monkeypatch):
             if n <= 257:
                 assert np.array_equal(want, O.run_batch(O.MODE_CTR, q.view(np.uint8).reshape(-1, 16), 77, first_qid=9, threads=8))
             assert direct.last_kernel_ms > 0
+        direct.set_kernel_timing(False)          # the default: plain launches, nothing to report
+        q = batch(3)
+        assert np.array_equal(u64(direct.eval_batch(q, seed=77, first_query_id=9)), u64(general.eval_batch(q, seed=77, first_query_id=9)))
+        assert direct.last_kernel_ms == 0 and general.last_kernel_ms == 0
         q = batch(300)
         for e in (general, direct):
             e.set_dealing_law("uniform")

@@ -36,7 +36,7 @@ def main():
     import neuron_poker_amd as npa
     from neuron_poker_amd import table_driver as td
 
-    eng = npa.Engine(int(os.environ.get("LOCAL_RANK", "0")))
+    eng = npa.Engine(int(os.environ.get("LOCAL_RANK", "0")), kernel_times=True)
     rng = np.random.default_rng(args.seed)
     pairs = [(.5, -.5), (.8, -.8), (.7, -.7), (.2, -.3)]  # main.py:142-145
 

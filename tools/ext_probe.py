@@ -21,7 +21,7 @@ def top(frac):
 
 
 def main():
-    eng = npa.Engine(0)
+    eng = npa.Engine(0, kernel_times=True)
     g = np.random.default_rng(7)
     B, N, runs = 2048, 6, 20000
     cards = np.array([g.permutation(52)[:8] for _ in range(B)], np.uint8)

@@ -1,7 +1,7 @@
 import sys; sys.path.insert(0, '/root/repo')
 import numpy as np, time
 import neuron_poker_amd as npa
-eng = npa.Engine(0)
+eng = npa.Engine(0, kernel_times=True)
 for runs in (1, 64, 1024, 16384, 100000, 1000000):
     q = npa.pack_queries([[50, 46]], [[255]*5], 2, runs)
     for _ in range(5): eng.eval_batch(q, seed=1)

@@ -47,7 +47,10 @@ def main():
         def host(i):
             eng.eval_batch(q, seed=i)
             return eng.last_kernel_ms
-        dt, k = timeit(host, 200)
+        eng.set_kernel_timing(True)      # kernel time from timestamped launches, call time from plain ones (the default)
+        _, k = timeit(host, 200)
+        eng.set_kernel_timing(False)
+        dt, _ = timeit(host, 200)
         print("%-26s host entry: call %7.1f us  kernel %7.1f us  %.3g evals/s   [%s]" % (name, dt * 1e6, k * 1e3, evals / dt, tag))
     from neuron_poker_amd import montecarlo_hip as mh
     mh.seed(1)
@@ -75,8 +78,12 @@ def main():
             def devf(i):
                 eng.eval_batch_device(d_q.data_ptr(), n, i, out.data_ptr(), stream=s.cuda_stream)
                 torch.cuda.synchronize()
-                return float(eng.kernel_times(1)[0])
-            dt, k = timeit(devf, 200)
+                kt = eng.kernel_times(1)
+                return float(kt[0]) if len(kt) else 0.0
+            eng.set_kernel_timing(True)
+            _, k = timeit(devf, 200)
+            eng.set_kernel_timing(False)
+            dt, _ = timeit(devf, 200)
             print("%-26s device entry: call+sync %7.1f us  kernel %7.1f us" % ("%d x 1000 runs (mix)" % n, dt * 1e6, k * 1e3))
     except ImportError:
         pass

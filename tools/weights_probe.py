@@ -9,7 +9,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import neuron_poker_amd as npa  # noqa: E402
 
-eng = npa.Engine(0)
+eng = npa.Engine(0, kernel_times=True)
 g = np.random.default_rng(3)
 
 
