@@ -441,13 +441,28 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_direct_kernel(const uint4 
 
     const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
     McqCard *base = base_tab + (threadIdx.x & ~63u);
-    /* the first rounds' work: the loads leave before the table image is fetched, their latency hides behind it */
+    typedef McqCtrDrawsT<MODE == MCQ_INTERNAL_MODE_UNIFORM> Draws;
+    /* The start of a one-launch query is a chain of latencies, so they overlap: the first rounds' work is asked for,
+     * the table image is sent on its way global -> LDS without passing through registers (global_load_lds_dwordx4:
+     * every wave instruction moves 1 KB), and while it travels every wave prepares the generator of its first task
+     * (Philox, and for a query cut over several waves the walk to this wave's place in the lane streams).  One
+     * barrier then publishes the image and the staged work. */
     MCQ_STAMP(0);
+    /* a small launch (its work came with the kernel arguments): this wave's round-0 record by scalar loads from its
+     * own copy -- the staged one needs the barrier.  (Not for work in pinned host memory: a small read per wave
+     * across PCIe costs more than it hides.) */
+    uint32_t qi0 = MCQ_DIRECT_IDLE;
+    uint4 raw0 = {0u, 0u, 0u, 0u};
+    if (use_karg) {
+        const size_t at0 = (size_t)blockIdx.x * kWaves + __builtin_amdgcn_readfirstlane(wib);
+        qi0 = karg.qi[at0];
+        raw0 = make_uint4(karg.rec[at0][0], karg.rec[at0][1], karg.rec[at0][2], karg.rec[at0][3]);
+    }
     uint4 pre_rec = {0u, 0u, 0u, 0u};
     uint32_t pre_qi = MCQ_DIRECT_IDLE;
     if (threadIdx.x < kStage && threadIdx.x / kWaves < rounds) {
         const size_t at = ((size_t)(threadIdx.x / kWaves) * gridDim.x + blockIdx.x) * kWaves + threadIdx.x % kWaves;
-        if (use_karg) { /* a small launch: its work came with the kernel arguments (no read across PCIe) */
+        if (use_karg) {
             pre_qi = karg.qi[at];
             pre_rec = make_uint4(karg.rec[at][0], karg.rec[at][1], karg.rec[at][2], karg.rec[at][3]);
         } else {
@@ -455,10 +470,48 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_direct_kernel(const uint4 
             pre_rec = work_rec[at];
         }
     }
-    load_tables(tab, g_tab);
+    {
+        typedef const __attribute__((address_space(1))) void *GlobalPtr;
+        typedef __attribute__((address_space(3))) void *LdsPtr;
+        constexpr uint32_t kChunks = (MCQ_TF_BYTE_OFFSET + 1024u) / 1024u; /* tops, sd | kc, sel8: 1 KB per wave instruction */
+        static_assert(sizeof(LdsTablesEval) == kChunks * 1024u, "table image in LDS: whole 1 KB pieces");
+        const char *src = reinterpret_cast<const char *>(g_tab);
+        char *dst = reinterpret_cast<char *>(&tab);
+        const char *sel = reinterpret_cast<const char *>(g_tab->sel8); /* the last piece: not behind sd in the global image */
+        /* the same number of pieces for every wave (the last one, sel8, is sent by all of them: same bytes, same
+         * place), so that the count of loads in flight is a constant the compiler can wait against */
+        constexpr uint32_t kPer = (kChunks + kWaves - 1u) / kWaves;
+        static_assert((kPer - 1u) * kWaves == kChunks - 1u, "pieces per wave");
+        const uint32_t wu = __builtin_amdgcn_readfirstlane(wib);
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; k++) {
+            const uint32_t c = k + 1u < kPer ? wu + k * kWaves : kChunks - 1u;
+            __builtin_amdgcn_global_load_lds((GlobalPtr)((k + 1u < kPer ? src + c * 1024u : sel) + lane * 16u),
+                                             (LdsPtr)(dst + c * 1024u), 16, 0, 0);
+        }
+    }
+    /* round 0, task 0 of this wave: the lanes that have iterations to run there */
+    Draws dr0;
+    {
+        const uint32_t qi = __builtin_amdgcn_readfirstlane(qi0);
+        if (qi != MCQ_DIRECT_IDLE) {
+            const uint32_t w2 = __builtin_amdgcn_readfirstlane(raw0.z);
+            const uint32_t split = (w2 >> 8) & 0xFFu, sub = (w2 >> 16) & 0xFFu;
+            const uint32_t chunk = MCQ_STREAM_ITERS >> split;
+            const McqQueryWords q = {(uint32_t)__builtin_amdgcn_readfirstlane(raw0.x), (uint32_t)__builtin_amdgcn_readfirstlane(raw0.y),
+                                     w2 & 0xFFu, (uint32_t)__builtin_amdgcn_readfirstlane(raw0.w)};
+            McqQueryCtx qc;
+            mcq_query_ctx(q, qc);
+            if ((uint64_t)lane * MCQ_STREAM_ITERS + sub * chunk < qc.runs) {
+                dr0.start(seed, first_qid + qi, lane);
+                for (uint32_t k = sub * chunk * (qc.n_opp + ((qc.n_deal + 1u) >> 1)); k != 0; k--) dr0.rng.next();
+            }
+        }
+    }
     MCQ_STAMP(1);
     for (uint32_t g0 = 0; g0 < rounds; g0 += MCQ_DIRECT_STAGE_ROUNDS) {
         if (g0) __syncthreads(); /* the previous rounds' work has been read by every wave */
+        else __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): this wave's pieces of the table image have landed */
         if (threadIdx.x < kStage) {
             if (g0) {
                 const uint32_t r = g0 + threadIdx.x / kWaves;
@@ -504,10 +557,13 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_direct_kernel(const uint4 
                     const uint32_t stream = task * MCQ_WAVE + lane;
                     const uint64_t it0 = (uint64_t)stream * MCQ_STREAM_ITERS + sub * chunk;
                     if (it0 < qc.runs) {
-                        McqCtrDrawsT<MODE == MCQ_INTERNAL_MODE_UNIFORM> dr;
-                        dr.start(seed, first_qid + qi, stream);
-                        MCQ_STAMP(4);
-                        for (uint32_t k = sub * chunk * (qc.n_opp + ((qc.n_deal + 1u) >> 1)); k != 0; k--) dr.rng.next();
+                        Draws dr;
+                        if (use_karg && round == 0u && task == 0u) {
+                            dr = dr0; /* prepared while the table image was on its way */
+                        } else {
+                            dr.start(seed, first_qid + qi, stream);
+                            for (uint32_t k = sub * chunk * (qc.n_opp + ((qc.n_deal + 1u) >> 1)); k != 0; k--) dr.rng.next();
+                        }
                         MCQ_STAMP(5);
                         const uint32_t cnt = (uint32_t)min((uint64_t)chunk, (uint64_t)qc.runs - it0);
                         for (uint32_t j = 0; j < cnt; j++) mcq_iteration(qc, dr, base - 128, g_tab->tf, tab.tops, tab.sd, acc);

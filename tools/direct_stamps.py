@@ -13,9 +13,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import neuron_poker_amd as npa  # noqa: E402
 from neuron_poker_amd import _lib  # noqa: E402
 
-STAGES = ["entry", "tables in LDS", "work staged", "query ctx + base deck", "stream seeded (Philox)", "skip-ahead done",
-          "iterations done", "wave sums (tally.add)", "partials in LDS", "rows stored", "block barrier", "system fence",
-          "flag written"]
+STAGES = ["entry (table image leaves)", "round-0 generator ready", "tables + work in LDS", "base deck", "(unused)",
+          "generator taken", "iterations done", "wave sums (tally.add)", "partials in LDS", "rows stored", "block barrier",
+          "system fence", "flag written"]
 
 
 def main():
