@@ -544,7 +544,7 @@ static int eval_host_philox(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t s
         McqDirectLayout &lay = c->direct_layout;
         mcq_direct_layout(qcost.data(), n, (uint32_t)c->n_cu, c->split_max, lay);
         const uint32_t grid = lay.grid, rounds = lay.rounds;
-        const size_t a_words = lay.slot_qi.size();
+        const size_t a_words = lay.slots;
         if (a_words > a_cap) return mcq_fail(MCQ_EDEVICE, who, "internal: wave layout larger than its bound");
         /* behind the caller's records and the prefix: one record copy per wave (its reserved bytes carry log2 of the
          * query's wave count and the wave's cut number), then one query index per wave */
@@ -557,14 +557,22 @@ static int eval_host_philox(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t s
             work_rec = reinterpret_cast<mcq_query *>(karg.rec);
             work_qi = karg.qi;
         }
-        memcpy(work_qi, lay.slot_qi.data(), a_words * sizeof(uint32_t));
-        for (size_t k = 0; k < a_words; k++) {
-            const uint32_t i = lay.slot_qi[k];
-            if (i == MCQ_LAYOUT_IDLE) continue;
-            mcq_query r = q[i];
-            r.reserved[0] = lay.lg[i];
-            r.reserved[1] = lay.slot_sub[k];
-            work_rec[k] = r;
+        memset(work_qi, 0xFF, a_words * sizeof(uint32_t)); /* MCQ_DIRECT_IDLE */
+        {   /* as two 64-bit words per record (reserved[0], reserved[1] = bytes 1, 2 of the second): a byte patched into
+             * a struct that is then copied whole stalls on the store it has just made */
+            static_assert(offsetof(mcq_query, reserved) == 9 && sizeof(mcq_query) == 16, "record words");
+            uint64_t *rec64 = reinterpret_cast<uint64_t *>(work_rec);
+            for (size_t i = 0; i < n; i++) {
+                uint64_t w[2];
+                memcpy(w, &q[i], 16);
+                const uint32_t l = lay.lg[i], at = lay.slot0[i];
+                w[1] |= (uint64_t)l << 8;
+                for (uint32_t sub = 0; sub < (1u << l); sub++) {
+                    rec64[2 * (size_t)(at + sub)] = w[0];
+                    rec64[2 * (size_t)(at + sub) + 1] = w[1] | ((uint64_t)sub << 16);
+                    work_qi[at + sub] = (uint32_t)i;
+                }
+            }
         }
         if (!c->h_flag.p) {
             HIP_TRY(c->h_flag.reserve(64));

@@ -19,9 +19,9 @@ struct McqDirectLayout {
     uint32_t grid = 0, rounds = 0;
     bool merge = false;            /* some query has more than one wave */
     uint64_t waves = 0;
+    size_t slots = 0;              /* rounds * grid * 16 */
     std::vector<uint8_t> lg;       /* per query: log2 of its wave count */
-    std::vector<uint32_t> slot_qi; /* per slot: query index or MCQ_LAYOUT_IDLE */
-    std::vector<uint8_t> slot_sub; /* per slot: the wave's cut number within its query */
+    std::vector<uint32_t> slot0;   /* per query: its first slot (its waves take slot0 .. slot0 + 2^lg - 1) */
     std::vector<uint32_t> sorted, fill; /* scratch */
 };
 
@@ -36,7 +36,8 @@ static inline void mcq_direct_layout(const uint64_t *cost, size_t n, uint32_t n_
     size_t count[5] = {0, 0, 0, 0, 0};
     for (size_t i = 0; i < n; i++) {
         uint32_t l = 0;
-        while (l < max_lg && (2ull << l) * total <= cost[i] * want_waves) l++; /* 2^l <= the query's share of the waves */
+        const uint64_t mine = cost[i] * want_waves; /* 2^l <= the query's share of the waves */
+        while (l < max_lg && (2ull << l) * total <= mine) l++;
         if (cost[i] == 0) l = 0;
         L.lg[i] = (uint8_t)l;
         count[l]++;
@@ -44,29 +45,36 @@ static inline void mcq_direct_layout(const uint64_t *cost, size_t n, uint32_t n_
     }
     L.merge = count[0] != n;
     L.grid = (uint32_t)(n < (size_t)n_cu ? n : (size_t)n_cu);
-    if (L.grid == 0) { L.rounds = 0; L.slot_qi.clear(); L.slot_sub.clear(); return; }
+    L.slot0.resize(n);
+    if (L.grid == 0) { L.rounds = 0; L.slots = 0; return; }
     L.sorted.resize(n);
     {
         size_t at[5], pos = 0;
         for (int l = 4; l >= 0; l--) { at[l] = pos; pos += count[l]; }
         for (size_t i = 0; i < n; i++) L.sorted[at[L.lg[i]]++] = (uint32_t)i; /* counting sort, wide queries first */
     }
+    /* dealt to the blocks in turn; a block's position counts waves, slot = (position / 16 * grid + block) * 16 + position % 16 */
     L.fill.assign(L.grid, 0u);
-    for (size_t k = 0; k < n; k++) L.fill[k % L.grid] += 1u << L.lg[L.sorted[k]];
-    uint32_t most = 0;
-    for (uint32_t b = 0; b < L.grid; b++) most = L.fill[b] > most ? L.fill[b] : most;
-    L.rounds = (most + MCQ_LAYOUT_WAVES - 1u) / MCQ_LAYOUT_WAVES;
-    const size_t slots = (size_t)L.rounds * L.grid * MCQ_LAYOUT_WAVES;
-    L.slot_qi.assign(slots, MCQ_LAYOUT_IDLE);
-    L.slot_sub.assign(slots, 0);
-    L.fill.assign(L.grid, 0u);
+    uint32_t most = 0, b = 0;
     for (size_t k = 0; k < n; k++) {
-        const uint32_t i = L.sorted[k], l = L.lg[i], b = (uint32_t)(k % L.grid), at = L.fill[b];
-        L.fill[b] = at + (1u << l);
-        const size_t dst = ((size_t)(at / MCQ_LAYOUT_WAVES) * L.grid + b) * MCQ_LAYOUT_WAVES + at % MCQ_LAYOUT_WAVES;
-        for (uint32_t sub = 0; sub < (1u << l); sub++) {
-            L.slot_qi[dst + sub] = i;
-            L.slot_sub[dst + sub] = (uint8_t)sub;
-        }
+        const uint32_t i = L.sorted[k], at = L.fill[b], w = 1u << L.lg[i];
+        L.slot0[i] = ((at / MCQ_LAYOUT_WAVES) * L.grid + b) * MCQ_LAYOUT_WAVES + at % MCQ_LAYOUT_WAVES;
+        L.fill[b] = at + w;
+        most = at + w > most ? at + w : most;
+        if (++b == L.grid) b = 0;
     }
+    L.rounds = (most + MCQ_LAYOUT_WAVES - 1u) / MCQ_LAYOUT_WAVES;
+    L.slots = (size_t)L.rounds * L.grid * MCQ_LAYOUT_WAVES;
+}
+
+/* The slot tables of a layout: slot_qi[s] = query index or MCQ_LAYOUT_IDLE, slot_sub[s] = the wave's cut number within
+ * its query (both L.slots long).  The library writes its work records straight from slot0 / lg; this form is what the
+ * kernel sees and what tests/hostsim checks. */
+static inline void mcq_direct_layout_slots(const McqDirectLayout &L, uint32_t *slot_qi, uint8_t *slot_sub) {
+    for (size_t s = 0; s < L.slots; s++) { slot_qi[s] = MCQ_LAYOUT_IDLE; slot_sub[s] = 0; }
+    for (size_t i = 0; i < L.lg.size(); i++)
+        for (uint32_t sub = 0; sub < (1u << L.lg[i]); sub++) {
+            slot_qi[L.slot0[i] + sub] = (uint32_t)i;
+            slot_sub[L.slot0[i] + sub] = (uint8_t)sub;
+        }
 }

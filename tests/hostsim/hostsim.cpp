@@ -306,9 +306,8 @@ extern "C" uint32_t hs_direct_layout(const uint64_t *cost, size_t n, uint32_t n_
     McqDirectLayout L;
     mcq_direct_layout(cost, n, n_cu, max_lg, L);
     *grid = L.grid;
-    if (L.slot_qi.size() > slot_cap) return 0xFFFFFFFFu;
+    if (L.slots > slot_cap) return 0xFFFFFFFFu;
     memcpy(lg, L.lg.data(), n);
-    memcpy(slot_qi, L.slot_qi.data(), L.slot_qi.size() * sizeof(uint32_t));
-    memcpy(slot_sub, L.slot_sub.data(), L.slot_sub.size());
+    mcq_direct_layout_slots(L, slot_qi, slot_sub);
     return L.rounds;
 }

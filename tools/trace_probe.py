@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"),
 import numpy as np
 import neuron_poker_amd as npa
 from small_probe import mix
-eng = npa.Engine(0, kernel_times=True)
+eng = npa.Engine(0)
 for n in (1, 1024):
     q, ev = mix(n)
     for i in range(8):
