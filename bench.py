@@ -339,13 +339,25 @@ def main():
 
         def side_measurements():  # a failure here must never cost the headline line
             # BASELINE configs[1]: single query AhKh heads-up 100k iterations (latency-bound: 98 wave tasks)
+            def call_time(q, reps):
+                # call time from plain launches (the library's default) -- a timestamped launch adds ~6 us to a call
+                # (tools/launch_floor.hip), which matters for the small configurations -- then one timestamped call
+                # for the kernel time
+                eng.set_kernel_timing(False)
+                try:
+                    for _ in range(3):
+                        eng.eval_batch(q, seed=1)
+                    t = time.perf_counter()
+                    for i in range(reps):
+                        eng.eval_batch(q, seed=i)
+                    dt = (time.perf_counter() - t) / reps
+                finally:
+                    eng.set_kernel_timing(True)
+                eng.eval_batch(q, seed=1)
+                return dt
+
             q1 = npa.pack_queries([[npa.card_id("AH"), npa.card_id("KH")]], [[255] * 5], 2, 100000)
-            for _ in range(3):
-                eng.eval_batch(q1, seed=1)
-            t1 = time.perf_counter()
-            for i in range(20):
-                eng.eval_batch(q1, seed=i)
-            dt = (time.perf_counter() - t1) / 20
+            dt = call_time(q1, 20)
             extras["configs[1]_single_query_100k"] = {"call_ms_host_buffers": 1e3 * dt, "kernel_ms": eng.last_kernel_ms,
                                                      "hand_evals_per_s": 2e5 / dt}
             # BASELINE configs[2]: 4096 preflop states x 3 players x 50k iterations, host buffers (PCIe-inclusive)
@@ -432,25 +444,24 @@ def main():
                 hq.append(cards[:2])
                 bq.append(list(cards[2:]) + [255] * (5 - nb[i]))
             q5 = npa.pack_queries(hq, bq, npl, 1000)
-            for _ in range(3):
-                eng.eval_batch(q5, seed=1)
-            t1 = time.perf_counter()
-            for i in range(50):
-                eng.eval_batch(q5, seed=i)
-            dt = (time.perf_counter() - t1) / 50
+            dt = call_time(q5, 50)
             extras["configs[4]_equity_side_only_1024x1000"] = {"call_ms_host_buffers": 1e3 * dt, "kernel_ms": eng.last_kernel_ms,
                                                                "hand_evals_per_s": float((npl * 1000).sum()) / dt,
                                                                "lock_steps_per_s": 1.0 / dt}
             # BASELINE configs[4], the whole loop: 512 six-seat tables (seats as main.py:142-145 + two random seats) driven
             # by the native lock-step driver (mcq_tables_run): table rules on the host, ONE equity batch per lock-step
             seats = [("equity", .5, -.5), ("equity", .8, -.8), ("equity", .7, -.7), ("equity", .2, -.3), ("random",), ("random",)]
-            tb = npa.Tables(eng, 512, seats, runs=1000, initial_stacks=100, small_blind=1, big_blind=2, seed=5)
-            tb.run(50)
-            s0 = tb.stats()
-            t1 = time.perf_counter()
-            tb.run(2000)
-            dt = time.perf_counter() - t1
-            s1 = tb.stats()
+            eng.set_kernel_timing(False)   # the driver's contexts copy the engine's setting: plain launches
+            try:
+                tb = npa.Tables(eng, 512, seats, runs=1000, initial_stacks=100, small_blind=1, big_blind=2, seed=5)
+                tb.run(50)
+                s0 = tb.stats()
+                t1 = time.perf_counter()
+                tb.run(2000)
+                dt = time.perf_counter() - t1
+                s1 = tb.stats()
+            finally:
+                eng.set_kernel_timing(True)
             extras["configs[4]_native_driver_512_tables"] = {"lock_steps": 2000, "ms_per_lock_step": 1e3 * dt / 2000,
                                                              "env_steps_per_s": (s1["env_steps"] - s0["env_steps"]) / dt,
                                                              "equity_queries_per_s": (s1["queries"] - s0["queries"]) / dt}
