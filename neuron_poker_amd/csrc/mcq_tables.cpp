@@ -481,9 +481,9 @@ struct mcq_tables {
     Pool *pool = nullptr;
     /* further streams + buffers (and thread pools) of the multi-stream schedule: group g of the tables is stepped by
      * helper thread g while the other groups' batches are on the GPU (mcq_tables_run); [0] unused */
-    static constexpr size_t kGroups = 4;
-    Pool *pool_g[kGroups] = {nullptr, nullptr, nullptr, nullptr};
-    mcq_ctx *ctx_g[kGroups] = {nullptr, nullptr, nullptr, nullptr};
+    static constexpr size_t kGroups = 8;
+    Pool *pool_g[kGroups] = {};
+    mcq_ctx *ctx_g[kGroups] = {};
     ~mcq_tables() {
         delete pool;
         for (size_t g = 1; g < kGroups; g++) {
@@ -655,8 +655,9 @@ static int tables_run_impl(mcq_tables *t, uint32_t lock_steps, uint64_t *stats) 
     /* Groups of tables on streams of their own (three; two below 192 tables; $MCQ_TABLES_GROUPS = 1..4).  While one group's
      * batch is on the GPU the other groups' tables are stepped on the host (each by its own thread, and its own thread
      * pool when the table count is large); per-query ids, hence all results, are as in one batch per step. */
-    size_t groups = n >= 192 ? 3 : 2; /* measured (tools/groups_probe.sh): 512 tables 82 / 67 / 57 / 57 us per lock-step with
-                                         1 / 2 / 3 / 4 groups, 4096 tables 278 / 178 / 138 / 150 us */
+    size_t groups = n >= 192 ? 3 : 2; /* measured (tools/groups_probe.sh, profiles/r03y_table_driver_groups.txt): 512 tables
+                                         71 / 54 / 47 / 45 / 45 / 57 us per lock-step with 1 / 2 / 3 / 4 / 6 / 8 groups,
+                                         4096 tables 233 / 151 / 111 / 131 / 157 / 192 us */
     if (const char *e = getenv("MCQ_TABLES_GROUPS")) groups = (size_t)atoi(e);
     if (groups > kMaxGroups) groups = kMaxGroups;
     if (n >= 64 && lock_steps >= 4 && t->cfg.reserved[1] == 0 && groups >= 2) {
@@ -668,7 +669,7 @@ static int tables_run_impl(mcq_tables *t, uint32_t lock_steps, uint64_t *stats) 
         }
         if (ready) {
             std::string err[kMaxGroups];
-            int rc[kMaxGroups] = {0, 0, 0, 0};
+            int rc[kMaxGroups] = {};
             std::vector<std::thread> helpers;
             auto join_all = [&] { for (auto &h : helpers) if (h.joinable()) h.join(); };
             try {
