@@ -652,7 +652,7 @@ static int tables_run_impl(mcq_tables *t, uint32_t lock_steps, uint64_t *stats) 
     const size_t n = t->tables.size();
     const uint32_t runs = t->cfg.runs;
     if (lock_steps && mcq_tables_begin(t, t->q.data()) == 0) return MCQ_EINVAL;
-    /* Groups of tables on streams of their own (three; two below 192 tables; $MCQ_TABLES_GROUPS = 1..4).  While one group's
+    /* Groups of tables on streams of their own (three; two below 192 tables; $MCQ_TABLES_GROUPS = 1..8).  While one group's
      * batch is on the GPU the other groups' tables are stepped on the host (each by its own thread, and its own thread
      * pool when the table count is large); per-query ids, hence all results, are as in one batch per step. */
     size_t groups = n >= 192 ? 3 : 2; /* measured (tools/groups_probe.sh, profiles/r03y_table_driver_groups.txt): 512 tables
