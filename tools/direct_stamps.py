@@ -10,6 +10,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import neuron_poker_amd as npa  # noqa: E402
 from neuron_poker_amd import _lib  # noqa: E402
 
@@ -26,6 +27,9 @@ def main():
              ("1 x 1000 runs, heads-up preflop", npa.pack_queries([[50, 46]], [[255] * 5], 2, 1000)),
              ("1 x 1000 runs, 6 players preflop", npa.pack_queries([[50, 46]], [[255] * 5], 6, 1000)),
              ("1 x 1000 runs, 4 players flop", npa.pack_queries([[50, 46]], [[0, 13, 30, 255, 255]], 4, 1000))]
+    from small_probe import mix
+    cases.append(("1024 x 1000 runs (mix), block 0", mix(1024)[0]))
+    cases.append(("256 x 1000 runs (mix), block 0", mix(256)[0]))
     for name, q in cases:
         rows, kms = [], []
         for i in range(300):
