@@ -561,15 +561,15 @@ static int eval_host_philox(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t s
         {   /* as two 64-bit words per record (reserved[0], reserved[1] = bytes 1, 2 of the second): a byte patched into
              * a struct that is then copied whole stalls on the store it has just made */
             static_assert(offsetof(mcq_query, reserved) == 9 && sizeof(mcq_query) == 16, "record words");
-            uint64_t *rec64 = reinterpret_cast<uint64_t *>(work_rec);
+            unsigned char *rec_bytes = reinterpret_cast<unsigned char *>(work_rec);
             for (size_t i = 0; i < n; i++) {
                 uint64_t w[2];
                 memcpy(w, &q[i], 16);
                 const uint32_t l = lay.lg[i], at = lay.slot0[i];
                 w[1] |= (uint64_t)l << 8;
                 for (uint32_t sub = 0; sub < (1u << l); sub++) {
-                    rec64[2 * (size_t)(at + sub)] = w[0];
-                    rec64[2 * (size_t)(at + sub) + 1] = w[1] | ((uint64_t)sub << 16);
+                    const uint64_t o[2] = {w[0], w[1] | ((uint64_t)sub << 16)};
+                    memcpy(rec_bytes + 16u * (size_t)(at + sub), o, 16); /* (one 16-byte store) */
                     work_qi[at + sub] = (uint32_t)i;
                 }
             }
