@@ -448,6 +448,31 @@ def main():
             extras["configs[4]_equity_side_only_1024x1000"] = {"call_ms_host_buffers": 1e3 * dt, "kernel_ms": eng.last_kernel_ms,
                                                                "hand_evals_per_s": float((npl * 1000).sum()) / dt,
                                                                "lock_steps_per_s": 1.0 / dt}
+            # the two remaining kernels of the library, so that they have a number and a row in the kernel trace
+            # (tools/profile.sh runs this command under rocprofv3): exact enumeration of AhKh heads-up
+            # preflop under the reference's law -- C(50,5) completions x 990 candidate hands -- and of a three-player
+            # flop; the showdown evaluator on 65 536 six-seat tables (7 cards per seat from one deck per table)
+            qx = npa.pack_queries([[npa.card_id("AH"), npa.card_id("KH")]], [[255] * 5], 2, 1)
+            eng.exact(qx)
+            t1 = time.perf_counter()
+            rx = eng.exact(qx)
+            dt = time.perf_counter() - t1
+            extras["exact_heads_up_preflop"] = {"call_ms": 1e3 * dt, "showdowns_per_s_nominal": 2118760 * 990 / dt,  # C(50,5) x 990, the order of magnitude
+                                                "equity": float((int(rx["win"][0]) + int(rx["tie"][0])) / int(rx["runs"][0]))}
+            qf = npa.pack_queries([[npa.card_id("AH"), npa.card_id("KH")]], [[0, 13, 30, 255, 255]], 3, 1)
+            eng.exact(qf)
+            t1 = time.perf_counter()
+            eng.exact(qf)
+            extras["exact_three_players_flop"] = {"call_ms": 1e3 * (time.perf_counter() - t1)}
+            gs = np.random.default_rng(65536)
+            decks = np.argsort(gs.random((65536, 52)), axis=1).astype(np.uint8)
+            hands = np.concatenate([decks[:, 5:17].reshape(65536, 6, 2),
+                                    np.repeat(decks[:, None, :5], 6, axis=1)], axis=2)
+            eng.showdown(hands)
+            t1 = time.perf_counter()
+            eng.showdown(hands)
+            dt = time.perf_counter() - t1
+            extras["showdown_65536_tables_6_seats"] = {"call_ms_host_buffers": 1e3 * dt, "hand_evals_per_s": 65536 * 6 / dt}
             # BASELINE configs[4], the whole loop: 512 six-seat tables (seats as main.py:142-145 + two random seats) driven
             # by the native lock-step driver (mcq_tables_run): table rules on the host, ONE equity batch per lock-step
             seats = [("equity", .5, -.5), ("equity", .8, -.8), ("equity", .7, -.7), ("equity", .2, -.3), ("random",), ("random",)]
