@@ -117,9 +117,10 @@ MCQ_API void mcq_destroy(mcq_ctx *ctx);
  * the matching first_query_id gives bit-identical per-query tallies.  All queries are validated first;
  * on MCQ_EINVAL nothing is launched and out is untouched.
  * MCQ_MODE_PHILOX: batches of small queries (at most 8192 iterations each -- the reference asks for 1000,
- * gym_env/env.py:22) cost ONE kernel launch: the kernel reads the records from and stores the finished rows to pinned
- * host memory, no copy, prep or zeroing launches around it; larger queries are priced on the host and sliced over the
- * whole GPU.  MCQ_MODE_REPLAY_MT19937: numpy's MT19937 stream of every query is walked on the GPU, one wave per query. */
+ * gym_env/env.py:22) cost ONE kernel launch: the kernel takes the records from its arguments (up to eight queries) or
+ * from pinned host memory and stores the finished rows to pinned host memory, no copy, prep or zeroing launches around
+ * it, and the call returns when a flag the kernel raises there is seen (about 19 us for one 1000-run query); larger
+ * queries are priced on the host and sliced over the whole GPU.  MCQ_MODE_REPLAY_MT19937: numpy's MT19937 stream of every query is walked on the GPU, one wave per query. */
 MCQ_API int mcq_eval_batch(mcq_ctx *ctx, const mcq_query *q, size_t n, uint64_t seed, uint64_t first_query_id, int mode,
                    mcq_result *out);
 
