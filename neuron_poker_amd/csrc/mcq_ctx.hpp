@@ -134,6 +134,7 @@ struct mcq_ctx {
     DevBuf d_done;                /* block counter of the one-launch path */
     uint32_t direct_ticket = 0;   /* value the kernel raises the flag in h_flag to */
     McqDirectKarg direct_karg; /* one-launch path: the work of a small launch, passed by value */
+    size_t publish_max_rows = 8192; /* host-buffer calls of at most this many rows get them through mcq_publish_kernel + flag (MCQ_PUBLISH_MAX_ROWS, 0 = never) */
     bool timing = false; /* mcq_set_kernel_timing: launches carry timestamp events */
     bool direct_poll = true;      /* pick the rows up at the flag instead of synchronising the stream (MCQ_DIRECT_POLL) */
     McqDirectLayout direct_layout;      /* the one-launch path's layout of the current call */

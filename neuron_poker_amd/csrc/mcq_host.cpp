@@ -333,6 +333,7 @@ mcq_ctx *mcq_ctx_clone(const mcq_ctx *c) {
         d->load_waves = c->load_waves;
         d->direct_max_tasks = c->direct_max_tasks;
         d->direct_poll = c->direct_poll;
+        d->publish_max_rows = c->publish_max_rows;
         d->timing = c->timing;
         d->replay_device_bytes = c->replay_device_bytes;
     }
@@ -417,6 +418,10 @@ mcq_ctx *mcq_create(int device, int flags) {
         c->direct_max_tasks = (uint32_t)(v < 0 ? 0 : v > (int)MCQ_DIRECT_TASKS_LIMIT ? (int)MCQ_DIRECT_TASKS_LIMIT : v);
     }
     if (const char *e = getenv("MCQ_DIRECT_POLL")) c->direct_poll = atoi(e) != 0;
+    if (const char *e = getenv("MCQ_PUBLISH_MAX_ROWS")) { /* tuning knob, see eval_host_philox */
+        const long v = atol(e);
+        c->publish_max_rows = (size_t)(v < 0 ? 0 : v);
+    }
     if (const char *e = getenv("MCQ_LOAD_WAVES")) { /* tuning knob, see pick_geometry */
         const int v = atoi(e);
         c->load_waves = (uint32_t)(v < 1 ? 1 : (v > 16 ? 16 : v));
@@ -498,6 +503,40 @@ int mcq_eval_batch_device(mcq_ctx *c, const void *d_queries, size_t n, uint64_t 
     ABI_GUARD_END("mcq_eval_batch_device")
 }
 
+/* The completion flag of the kernels that hand their rows over in pinned memory (mcq_eval_direct_kernel,
+ * mcq_publish_kernel): a word the last block sets to the call's ticket, and the device counter that finds that block. */
+static int flag_ready(mcq_ctx *c) {
+    if (!c->h_flag.p) {
+        HIP_TRY(c->h_flag.reserve(64));
+        memset(c->h_flag.p, 0, 64);
+        HIP_TRY(c->d_done.reserve(64));
+        HIP_TRY(hipMemsetAsync(c->d_done.p, 0, 64, c->stream));
+    }
+    return MCQ_OK;
+}
+static uint32_t next_ticket(mcq_ctx *c) {
+    if (++c->direct_ticket == 0u) c->direct_ticket = 1u; /* 0 is the flag's resting value */
+    return c->direct_ticket;
+}
+/* Picking the rows up at the flag saves the end-of-kernel handshake of a stream synchronisation (24 us against 7.5 us
+ * from launch to flag for an empty kernel, tools/launch_floor.hip).  A kernel that has not answered after a few
+ * milliseconds is left to hipStreamSynchronize, which reports what went wrong. */
+static int wait_ticket(mcq_ctx *c, uint32_t ticket, bool *by_flag) {
+    const volatile uint32_t *flag = static_cast<const volatile uint32_t *>(c->h_flag.p);
+    const auto t1 = std::chrono::steady_clock::now();
+    bool seen = false;
+    if (c->direct_poll) {
+        for (uint32_t spin = 0;; spin++) {
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == ticket) { seen = true; break; }
+            if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t1 > std::chrono::milliseconds(5)) break;
+            __builtin_ia32_pause();
+        }
+    }
+    if (!seen) HIP_TRY(hipStreamSynchronize(c->stream));
+    if (by_flag) *by_flag = seen;
+    return MCQ_OK;
+}
+
 /* Production mode from host buffers.  The host has the queries in its hands, so it prices them itself: the cost
  * prefix travels with the queries in ONE copy, the result rows are zero already (every call leaves them so), and
  * the only kernel of the call is the evaluation kernel -- no prep launch on the path of the reference's own call
@@ -510,14 +549,15 @@ static int eval_host_philox(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t s
     int rc = validate(q, n);
     if (rc) return rc;
     const size_t q_bytes = n * sizeof(mcq_query), p_bytes = (n + 3) * sizeof(uint64_t), r_bytes = n * sizeof(mcq_result);
+    const size_t r_pad = (n + (n & 1u)) * sizeof(mcq_result); /* whole 16-byte words (mcq_publish_kernel) */
     /* behind the records: the cost prefix, then (one-launch path) the wave layout: at most n + 2 * 16 * n_cu waves, dealt
      * to the blocks in whole rounds */
     const size_t a_off = (q_bytes + p_bytes + 15u) & ~(size_t)15u, a_cap = n + 96u * (size_t)c->n_cu + 64u; /* waves */
     HIP_TRY(c->h_q.reserve(a_off + a_cap * (sizeof(mcq_query) + sizeof(uint32_t))));
     HIP_TRY(c->d_q.reserve(q_bytes + p_bytes));
-    HIP_TRY(c->h_res.reserve(r_bytes));
-    if (r_bytes > c->d_res.cap) c->res_clean = 0;
-    HIP_TRY(c->d_res.reserve(r_bytes));
+    HIP_TRY(c->h_res.reserve(r_pad));
+    if (r_pad > c->d_res.cap) c->res_clean = 0;
+    HIP_TRY(c->d_res.reserve(r_pad));
     memcpy(c->h_q.p, q, q_bytes);
     uint64_t *prefix = reinterpret_cast<uint64_t *>(static_cast<char *>(c->h_q.p) + q_bytes);
     uint64_t total_tasks = 0, max_tasks = 0, cost = 0, unsplit = 0;
@@ -574,14 +614,9 @@ static int eval_host_philox(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t s
                 }
             }
         }
-        if (!c->h_flag.p) {
-            HIP_TRY(c->h_flag.reserve(64));
-            memset(c->h_flag.p, 0, 64);
-            HIP_TRY(c->d_done.reserve(64));
-            HIP_TRY(hipMemsetAsync(c->d_done.p, 0, 64, c->stream));
-        }
-        if (++c->direct_ticket == 0u) c->direct_ticket = 1u; /* 0 is the flag's resting value */
-        const uint32_t ticket = c->direct_ticket;
+        rc = flag_ready(c);
+        if (rc) return rc;
+        const uint32_t ticket = next_ticket(c);
         const int slot = (int)(c->n_timed % mcq_ctx::kRing);
         const bool timed = c->timing;
         c->last_ms = 0.f;
@@ -596,19 +631,9 @@ static int eval_host_philox(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t s
                                        by_karg ? &karg : nullptr));
         if (timed) c->n_timed++;
         const auto t1 = std::chrono::steady_clock::now();
-        /* The last block raises a flag in pinned memory once every row is out: picking the rows up there saves the
-         * end-of-kernel handshake of a stream synchronisation (measured: 14 us of a 40 us call).  A kernel that has
-         * not answered after a few milliseconds is left to hipStreamSynchronize, which reports what went wrong. */
-        const volatile uint32_t *flag = static_cast<const volatile uint32_t *>(c->h_flag.p);
-        bool seen = false;
-        if (c->direct_poll) {
-            for (uint32_t spin = 0;; spin++) {
-                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == ticket) { seen = true; break; }
-                if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t1 > std::chrono::milliseconds(5)) break;
-                __builtin_ia32_pause();
-            }
-        }
-        if (!seen) HIP_TRY(hipStreamSynchronize(c->stream));
+        bool seen = false; /* the last block raises the flag once every row is out */
+        rc = wait_ticket(c, ticket, &seen);
+        if (rc) return rc;
         const auto t2 = std::chrono::steady_clock::now();
         memcpy(out, c->h_res.p, r_bytes);
         if (trace) {
@@ -627,7 +652,7 @@ static int eval_host_philox(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t s
     prefix[n + 1] = 0;
     prefix[n + 2] = 0;
     HIP_TRY(hipMemcpyAsync(c->d_q.p, c->h_q.p, q_bytes + p_bytes, hipMemcpyHostToDevice, c->stream));
-    if (c->res_clean < r_bytes) HIP_TRY(hipMemsetAsync(c->d_res.p, 0, r_bytes, c->stream));
+    if (c->res_clean < r_pad) HIP_TRY(hipMemsetAsync(c->d_res.p, 0, r_pad, c->stream));
     c->res_clean = 0; /* dirty until this call has put its rows back to zero */
     c->last_ms = 0.f;
     if (total_tasks) {
@@ -636,10 +661,22 @@ static int eval_host_philox(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t s
                            reinterpret_cast<const uint64_t *>(static_cast<const char *>(c->d_q.p) + q_bytes));
         if (rc) return rc;
     }
-    HIP_TRY(hipMemcpyAsync(c->h_res.p, c->d_res.p, r_bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_res.p, 0, r_bytes, c->stream)); /* not waited for: the next call finds its rows zero */
-    c->res_clean = r_bytes;
+    if (n <= c->publish_max_rows) {
+        /* few rows: a small kernel behind the evaluation moves them into pinned memory, zeroes them in HBM for the next
+         * call and raises the flag (no D2H copy, no stream synchronisation, no memset) */
+        rc = flag_ready(c);
+        if (rc) return rc;
+        const uint32_t ticket = next_ticket(c);
+        HIP_TRY(mcq_launch_publish((mcq_result *)c->d_res.p, (mcq_result *)c->h_res.dev, n + (n & 1u), (uint32_t *)c->d_done.p,
+                                   (uint32_t *)c->h_flag.dev, ticket, c->stream));
+        rc = wait_ticket(c, ticket, nullptr);
+        if (rc) return rc;
+    } else {
+        HIP_TRY(hipMemcpyAsync(c->h_res.p, c->d_res.p, r_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_res.p, 0, r_pad, c->stream)); /* not waited for: the next call finds its rows zero */
+    }
+    c->res_clean = r_pad;
     if (!total_tasks || !c->timing || mcq_kernel_times(c, &c->last_ms, 1) != 1) c->last_ms = 0.f;
     memcpy(out, c->h_res.p, r_bytes);
     for (size_t i = 0; i < n; i++) out[i].runs = mcq_part(tasks_of(q[i]), q[i].runs, part, n_parts).runs;

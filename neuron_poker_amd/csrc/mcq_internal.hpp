@@ -31,6 +31,10 @@ hipError_t mcq_launch_eval_ext(int mode, const mcq_query *d_q, const mcq_query_e
                                const McqTables *d_luts, const uint8_t *d_draws, const uint64_t *d_draw_off,
                                const uint16_t *d_lists, const uint32_t *d_cnts, uint32_t lists_stride, uint32_t grid,
                                uint32_t block, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
+/* host-buffer calls with few rows: d_rows[0..n_rows) -> pinned host memory (device address h_rows_dev), d_rows zeroed,
+ * then *done_flag = ticket; n_rows even (buffers hold the odd row's neighbour), d_done a zeroed device word */
+hipError_t mcq_launch_publish(mcq_result *d_rows, mcq_result *h_rows_dev, uint64_t n_rows, uint32_t *d_done,
+                              uint32_t *done_flag, uint32_t ticket, hipStream_t s);
 /* dst[i] += src[i], i < n (tally matrices of two shards on one device, both 16-byte aligned) */
 hipError_t mcq_launch_add_u64(uint64_t *d_dst, const uint64_t *d_src, uint64_t n, hipStream_t s);
 /* parity mode: one wave per query parses np.random.seed(seed32 + i)'s MT19937 stream into d_draws (+ passes into the
