@@ -703,13 +703,19 @@ MCQ_HD void mcq_deal_table(const McqQueryCtx &qc, Draws &dr, const McqCard *base
                            McqBoard &b) {
     uint32_t hb = MCQ_HOLE_SENTINEL;
     const uint32_t n_deal = mcq_opaque_uniform(qc.n_deal); /* scalar compares, no lane masks kept in SGPR pairs */
+    /* A card joins the table one draw late: its LDS read leaves at the end of its block and is waited for behind the
+     * next draw's arithmetic (the blocks are separate basic blocks, the compiler cannot move the wait itself). */
+    McqCard pend = {0u, 0u, 0u, 0u};
 #define MCQ_TABLE(K)                                                                                            \
     if (K < n_deal) {                                                                                           \
-        b.add(base128[mcq_draw_table<K, NREGS>(dr.template table<K>(L - Draws::kTableShort), H, hb)]); /* l.188 */ \
+        const uint32_t at = mcq_draw_table<K, NREGS>(dr.template table<K>(L - Draws::kTableShort), H, hb); /* l.188 */ \
+        if (K > 0) b.add(pend);                                                                                 \
+        pend = base128[at];                                                                                     \
         L -= 1;                                                                                                 \
     }
     MCQ_TABLE(0) MCQ_TABLE(1) MCQ_TABLE(2) MCQ_TABLE(3) MCQ_TABLE(4)
 #undef MCQ_TABLE
+    if (n_deal > 0u) b.add(pend);
 }
 
 // One Monte-Carlo iteration of one lane.  The opponents' hole cards stay in registers (statically indexed:
