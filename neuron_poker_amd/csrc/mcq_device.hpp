@@ -698,11 +698,12 @@ MCQ_HD uint32_t mcq_draw_table(uint32_t rp, const uint32_t (&H)[5], uint32_t &hb
 }
 
 // the missing table cards (montecarlo_python.py:185-189) after opponents whose holes fill NREGS registers
-template <int NREGS, class Draws>
+template <int NREGS, class Draws, int NDEAL = -1>
 MCQ_HD void mcq_deal_table(const McqQueryCtx &qc, Draws &dr, const McqCard *base128, const uint32_t (&H)[5], uint32_t L,
                            McqBoard &b) {
     uint32_t hb = MCQ_HOLE_SENTINEL;
-    const uint32_t n_deal = mcq_opaque_uniform(qc.n_deal); /* scalar compares, no lane masks kept in SGPR pairs */
+    /* scalar compares, no lane masks kept in SGPR pairs; NDEAL >= 0: known at compile time, no branches at all */
+    const uint32_t n_deal = NDEAL >= 0 ? (uint32_t)NDEAL : mcq_opaque_uniform(qc.n_deal);
     /* A card joins the table one draw late: its LDS read leaves at the end of its block and is waited for behind the
      * next draw's arithmetic (the blocks are separate basic blocks, the compiler cannot move the wait itself). */
     McqCard pend = {0u, 0u, 0u, 0u};
@@ -721,14 +722,17 @@ MCQ_HD void mcq_deal_table(const McqQueryCtx &qc, Draws &dr, const McqCard *base
 // One Monte-Carlo iteration of one lane.  The opponents' hole cards stay in registers (statically indexed:
 // everything below is unrolled over the opponent number) until the table is complete: the reference deals
 // ALL opponents before any table card (montecarlo_python.py:215-217).
-template <class Draws>
+// NOPP / NDEAL >= 0: the number of opponents / of table cards to come is known at compile time (it must equal
+// qc.n_opp / qc.n_deal): the iteration is ONE basic block, which lets the compiler send lookups early and wait late
+// across hands and draws -- the wave-uniform branches of the general form are scheduling barriers.
+template <class Draws, int NOPP = -1, int NDEAL = -1>
 // base128 = (base deck table) - 128 entries: draw indices carry a bias of 128 (r | 0x80), folded into the pointer.
 MCQ_HD void mcq_iteration(const McqQueryCtx &qc, Draws &dr, const McqCard *base128, const uint32_t *tf,
                           const uint32_t *tops, const uint32_t *sd, McqLaneAcc &acc) {
     uint32_t H[5] = {MCQ_HOLE_SENTINEL, MCQ_HOLE_SENTINEL, MCQ_HOLE_SENTINEL, MCQ_HOLE_SENTINEL, MCQ_HOLE_SENTINEL};
     uint32_t L = qc.L0;
     McqHole opp[MCQ_MAX_OPP];
-    const uint32_t n_opp_d = mcq_opaque_uniform(qc.n_opp);
+    const uint32_t n_opp_d = NOPP >= 0 ? (uint32_t)NOPP : mcq_opaque_uniform(qc.n_opp);
 #define MCQ_OPP(P)                                                                                             \
     if (P < n_opp_d) {                                                                                         \
         uint32_t r1, r2;                                                                                       \
@@ -741,7 +745,9 @@ MCQ_HD void mcq_iteration(const McqQueryCtx &qc, Draws &dr, const McqCard *base1
     MCQ_OPP(0) MCQ_OPP(1) MCQ_OPP(2) MCQ_OPP(3) MCQ_OPP(4) MCQ_OPP(5) MCQ_OPP(6) MCQ_OPP(7) MCQ_OPP(8)
 #undef MCQ_OPP
     McqBoard b = qc.board;
-    switch (mcq_opaque_uniform((2u * qc.n_opp + 3u) / 4u)) { /* registers holding the opponents' holes: wave-uniform */
+    if (NOPP >= 0) {
+        mcq_deal_table<(NOPP >= 0 ? (2 * NOPP + 3) / 4 : 0), Draws, NDEAL>(qc, dr, base128, H, L, b);
+    } else switch (mcq_opaque_uniform((2u * qc.n_opp + 3u) / 4u)) { /* registers holding the opponents' holes: wave-uniform */
         case 0: mcq_deal_table<0>(qc, dr, base128, H, L, b); break;
         case 1: mcq_deal_table<1>(qc, dr, base128, H, L, b); break;
         case 2: mcq_deal_table<2>(qc, dr, base128, H, L, b); break;
@@ -753,7 +759,7 @@ MCQ_HD void mcq_iteration(const McqQueryCtx &qc, Draws &dr, const McqCard *base1
     fs.from_board(b);
     const uint32_t hk = mcq_eval_key(b, fs, qc.hero, tf, tops, sd);
     uint32_t best = 0;
-    const uint32_t n_opp_e = mcq_opaque_uniform(qc.n_opp); /* a fresh scalar compare per block, see mcq_opaque_uniform */
+    const uint32_t n_opp_e = NOPP >= 0 ? (uint32_t)NOPP : mcq_opaque_uniform(qc.n_opp); /* a fresh scalar compare per block, see mcq_opaque_uniform */
 #define MCQ_EVAL(P)                                                        \
     if (P < n_opp_e) {                                                     \
         const uint32_t k = mcq_eval_key(b, fs, opp[P], tf, tops, sd);     \
