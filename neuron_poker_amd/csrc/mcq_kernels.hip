@@ -258,6 +258,10 @@ __device__ __forceinline__ void mcq_iterations(const McqQueryCtx &qc, Draws &dr,
     case N:                                                                                               \
         if (qc.n_deal == 5u)                                                                              \
             for (uint32_t j = 0; j < cnt; j++) mcq_iteration<Draws, N, 5>(qc, dr, base128, tf, tops, sd, acc); \
+        else if (qc.n_deal == 2u)                                                                         \
+            for (uint32_t j = 0; j < cnt; j++) mcq_iteration<Draws, N, 2>(qc, dr, base128, tf, tops, sd, acc); \
+        else if (qc.n_deal == 1u)                                                                         \
+            for (uint32_t j = 0; j < cnt; j++) mcq_iteration<Draws, N, 1>(qc, dr, base128, tf, tops, sd, acc); \
         else                                                                                              \
             for (uint32_t j = 0; j < cnt; j++) mcq_iteration<Draws, N, -1>(qc, dr, base128, tf, tops, sd, acc); \
         return;
