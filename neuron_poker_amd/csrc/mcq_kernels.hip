@@ -246,34 +246,6 @@ __global__ __launch_bounds__(256) void mcq_publish_kernel(ulonglong2 *__restrict
 }
 
 // ---------------------------------------------------------------------------------------------- eval
-// `cnt` iterations of one lane.  STRAIGHT: by the (wave-uniform) number of opponents, and before the flop also by the
-// number of table cards, the loop body is a specialisation of mcq_iteration without branches -- one basic block, in
-// which the compiler sends lookups early and waits late across hands and draws (6-max before the flop: 6.37 -> 6.00 ms;
-// the general form's wave-uniform branches are scheduling barriers).  Same arithmetic, same results.
-template <bool STRAIGHT, class Draws>
-__device__ __forceinline__ void mcq_iterations(const McqQueryCtx &qc, Draws &dr, const McqCard *base128, const uint32_t *tf,
-                                               const uint32_t *tops, const uint32_t *sd, McqLaneAcc &acc, uint32_t cnt) {
-    if (STRAIGHT) {
-#define MCQ_STRAIGHT(N)                                                                                   \
-    case N:                                                                                               \
-        if (qc.n_deal == 5u)                                                                              \
-            for (uint32_t j = 0; j < cnt; j++) mcq_iteration<Draws, N, 5>(qc, dr, base128, tf, tops, sd, acc); \
-        else if (qc.n_deal == 2u)                                                                         \
-            for (uint32_t j = 0; j < cnt; j++) mcq_iteration<Draws, N, 2>(qc, dr, base128, tf, tops, sd, acc); \
-        else if (qc.n_deal == 1u)                                                                         \
-            for (uint32_t j = 0; j < cnt; j++) mcq_iteration<Draws, N, 1>(qc, dr, base128, tf, tops, sd, acc); \
-        else                                                                                              \
-            for (uint32_t j = 0; j < cnt; j++) mcq_iteration<Draws, N, -1>(qc, dr, base128, tf, tops, sd, acc); \
-        return;
-        switch (qc.n_opp) {
-            MCQ_STRAIGHT(1) MCQ_STRAIGHT(2) MCQ_STRAIGHT(3) MCQ_STRAIGHT(4) MCQ_STRAIGHT(5) MCQ_STRAIGHT(6)
-            default: break; /* more opponents (or none): the general form -- their straight-line forms spill registers */
-        }
-#undef MCQ_STRAIGHT
-    }
-    for (uint32_t j = 0; j < cnt; j++) mcq_iteration(qc, dr, base128, tf, tops, sd, acc);
-}
-
 struct WaveTally { /* per-lane running sums of the current (wave, query) pair */
     uint32_t code[MCQ_N_CODES], tie, passes;
     bool dirty;

@@ -45,10 +45,11 @@ def key_type(keys):
     return (code - (code >= 6)).astype(np.uint32)
 
 
-def run_ctr(query16, seed, qid, uniform=False):
+def run_ctr(query16, seed, qid, uniform=False, general=False):
+    """general=True: every iteration through the general form of mcq_iteration (no straight-line specialisation)."""
     q = np.ascontiguousarray(query16, np.uint8)
     out = np.zeros(13, np.uint64)
-    f = lib().hs_run_ctr_uniform if uniform else lib().hs_run_ctr
+    f = lib().hs_run_ctr_uniform if uniform else lib().hs_run_ctr_general if general else lib().hs_run_ctr
     rc = f(_p(q, C.c_uint8), C.c_uint64(seed), C.c_uint64(qid), _p(out, C.c_uint64))
     if rc:
         raise ValueError(rc)

@@ -69,7 +69,7 @@ void hs_philox(const uint32_t *ctr, const uint32_t *key, uint32_t *out) {
 // production mode, lane/stream decomposition exactly as the kernel: lane <-> stream of 16 iterations
 }  // extern "C"
 
-template <class Draws>
+template <class Draws, bool STRAIGHT = true>
 static int run_ctr_t(const mcq_query *q, uint64_t seed, uint64_t qid, mcq_result *out) {
     if (!mcq_query_valid(mcq_query_words(*q))) return MCQ_EINVAL;
     const McqTables &t = luts();
@@ -84,11 +84,11 @@ static int run_ctr_t(const mcq_query *q, uint64_t seed, uint64_t qid, mcq_result
         Draws dr;
         dr.start(seed, qid, s);
         McqLaneAcc acc = {0, 0, 0};
-        for (uint32_t j = 0; j < MCQ_STREAM_ITERS; j++) {
-            if ((uint64_t)s * MCQ_STREAM_ITERS + j >= q->runs) break;
-            mcq_iteration(qc, dr, base, t.tf, t.tops, t.sd, acc);
-            acc.passes += qc.n_opp; /* MCQ-CTR v4: one attempt per opponent, never re-drawn */
-        }
+        const uint64_t left = (uint64_t)q->runs - (uint64_t)s * MCQ_STREAM_ITERS;
+        const uint32_t cnt = left < MCQ_STREAM_ITERS ? (uint32_t)left : MCQ_STREAM_ITERS;
+        if (STRAIGHT) mcq_iterations<true>(qc, dr, base, t.tf, t.tops, t.sd, acc, cnt); /* as the bulk kernel runs them */
+        else for (uint32_t j = 0; j < cnt; j++) mcq_iteration(qc, dr, base, t.tf, t.tops, t.sd, acc);
+        acc.passes += cnt * qc.n_opp; /* MCQ-CTR v4: one attempt per opponent, never re-drawn */
         fold(acc, out);
     }
     return MCQ_OK;
@@ -101,6 +101,9 @@ int hs_run_ctr(const mcq_query *q, uint64_t seed, uint64_t qid, mcq_result *out)
 }
 int hs_run_ctr_uniform(const mcq_query *q, uint64_t seed, uint64_t qid, mcq_result *out) {
     return run_ctr_t<McqCtrDrawsUniform>(q, seed, qid, out);
+}
+int hs_run_ctr_general(const mcq_query *q, uint64_t seed, uint64_t qid, mcq_result *out) { /* without the straight-line forms */
+    return run_ctr_t<McqCtrDraws, false>(q, seed, qid, out);
 }
 
 // parity mode: host parse of the MT19937 stream + the same lane arithmetic

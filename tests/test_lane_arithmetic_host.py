@@ -109,6 +109,25 @@ def test_ctr_mode_equals_oracle_ctr(hero, board, n, runs):
         assert np.array_equal(got, exp), (seed, qid, got, exp)
 
 
+def test_straight_line_iterations_equal_the_general_form():
+    """mcq_iterations (what the bulk kernel runs): for 1-6 opponents and 5 / 2 / 1 table cards to come the loop body is a
+    branch-free specialisation of mcq_iteration; every one of them (and the general fall-backs: river, 7-9 opponents,
+    hero alone) gives the general form's tallies, and the oracle's."""
+    g = np.random.default_rng(99)
+    for n_players in range(1, 11):
+        for nb in (0, 3, 4, 5):
+            c = g.permutation(52)[:2 + nb]
+            hero = [O.card_str(int(x)) for x in c[:2]]
+            board = [O.card_str(int(x)) for x in c[2:]]
+            q = q16(hero, board, n_players, 333)
+            a = H.run_ctr(q, 11, n_players * 7 + nb)
+            b = H.run_ctr(q, 11, n_players * 7 + nb, general=True)
+            assert np.array_equal(a, b), (n_players, nb)
+            if nb in (0, 4):
+                exp = O.run(O.MODE_CTR, hero, board, n_players, 333, 11, qid=n_players * 7 + nb)["tallies"]
+                assert np.array_equal(a, exp), (n_players, nb)
+
+
 def test_numpy_stream_coupling_matches_reference_sequence():
     """consecutive calls share numpy's global state; after each call np.random is exactly where the
     reference leaves it (tests/golden/sequence.json was recorded from the reference)."""
