@@ -792,8 +792,8 @@ MCQ_HD void mcq_iterations(const McqQueryCtx &qc, Draws &dr, const McqCard *base
             for (uint32_t j = 0; j < cnt; j++) mcq_iteration<Draws, N, -1>(qc, dr, base128, tf, tops, sd, acc); \
         return;
         switch (qc.n_opp) {
-            MCQ_STRAIGHT(1) MCQ_STRAIGHT(2) MCQ_STRAIGHT(3) MCQ_STRAIGHT(4) MCQ_STRAIGHT(5) MCQ_STRAIGHT(6)
-            default: break; /* more opponents (or none): the general form -- their straight-line forms spill registers */
+            MCQ_STRAIGHT(1) MCQ_STRAIGHT(2) MCQ_STRAIGHT(3) MCQ_STRAIGHT(4) MCQ_STRAIGHT(5) MCQ_STRAIGHT(6) MCQ_STRAIGHT(7)
+            default: break; /* eight or nine opponents (or none): the general form -- their straight-line forms spill registers */
         }
 #undef MCQ_STRAIGHT
     }
