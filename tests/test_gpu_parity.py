@@ -609,6 +609,33 @@ def _xq(hero, board, n):
     return npa.pack_queries([[O.card_id(c) for c in hero]], [b + [255] * (5 - len(b))], n, 1)
 
 
+def test_rows_through_the_publish_kernel_equal_rows_through_the_copy(monkeypatch):
+    """Host-buffer calls on the general path (queries of more than 8 tasks) with up to 8192 rows get their rows through
+    mcq_publish_kernel + the completion flag; larger ones (and MCQ_PUBLISH_MAX_ROWS=0) through D2H copy + stream
+    synchronisation.  Same rows, odd and even counts, and the HBM rows are zero again for the next call."""
+    g = np.random.default_rng(8192)
+
+    def batch(n):
+        hole = np.array([g.choice(52, 2, replace=False) for _ in range(n)], np.uint8)
+        return npa.pack_queries(hole, np.full((n, 5), 255, np.uint8), g.integers(2, 8, n), g.choice([9000, 12000, 20000], n))
+
+    monkeypatch.setenv("MCQ_PUBLISH_MAX_ROWS", "0")
+    by_copy = npa.Engine(0)
+    monkeypatch.delenv("MCQ_PUBLISH_MAX_ROWS")
+    by_flag = npa.Engine(0)
+    try:
+        for n in (1, 2, 7, 64, 501):
+            q = batch(n)
+            want = u64(by_copy.eval_batch(q, seed=3, first_query_id=n))
+            assert np.array_equal(u64(by_flag.eval_batch(q, seed=3, first_query_id=n)), want), n
+            assert np.array_equal(u64(by_flag.eval_batch(q, seed=3, first_query_id=n)), want), n   # rows were left zero
+        q = batch(5)
+        assert np.array_equal(u64(by_flag.eval_batch(q, seed=9)), O.run_batch(O.MODE_CTR, q.view(np.uint8).reshape(-1, 16), 9, threads=8))
+    finally:
+        by_copy.close()
+        by_flag.close()
+
+
 def test_exact_enumeration_gpu_equals_host_lane_code_and_oracle(eng):
     from tests import hostsim as H
     from tests.test_lane_arithmetic_host import EXACT_CASES
