@@ -582,7 +582,9 @@ static int eval_host_philox(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t s
         qcost.resize(n);
         for (size_t i = 0; i < n; i++) qcost[i] = (i + 1 < n ? prefix[i + 1] : cost) - prefix[i];
         McqDirectLayout &lay = c->direct_layout;
-        mcq_direct_layout(qcost.data(), n, (uint32_t)c->n_cu, c->split_max, lay);
+        /* at most eight waves per query here: a sixteenth wave steps over fifteen iterations' words to run one
+         * (tools/single_probe.py: one 1000-run query 1 us slower with sixteen, whatever the players and the table) */
+        mcq_direct_layout(qcost.data(), n, (uint32_t)c->n_cu, c->split_max < 3u ? c->split_max : 3u, lay);
         const uint32_t grid = lay.grid, rounds = lay.rounds;
         const size_t a_words = lay.slots;
         if (a_words > a_cap) return mcq_fail(MCQ_EDEVICE, who, "internal: wave layout larger than its bound");

@@ -576,8 +576,8 @@ def test_one_launch_path_for_small_queries_equals_the_general_path(monkeypatch):
     monkeypatch.setenv("MCQ_DIRECT_MAX_TASKS", "8")
     direct = npa.Engine(0, kernel_times=True)
     try:
-        # 16, 16, 16, 16 (8 queries = 128 waves: the last batch whose work travels in the kernel arguments), 16, 16, 8, 4,
-        # 1, 1 waves per query; 45000 queries = 11 rounds per block (the work is staged eight rounds at a time)
+        # 8, 8, 8, 8 (8 queries = 64 of the 128 wave slots: their work travels in the kernel arguments), 8, 8, 8, 4, 1, 1 waves
+        # per query; 45000 queries = 11 rounds per block (the work is staged eight rounds at a time)
         for n in (1, 2, 3, 8, 9, 100, 257, 1000, 5000, 45000):
             q = batch(n)
             want = u64(general.eval_batch(q, seed=77, first_query_id=9))
