@@ -256,6 +256,13 @@ TALLY_GRID = [  # (hero, board, n_players, runs, seed)
     (['7H', '2C'], [], 1, 3000, 9),
     (['JD', 'JS'], ['8C', 'TC', 'JC', '5H', 'QC'], 3, 20000, 4294967295),
     (['AD', 'AS'], ['AC', 'AH', 'KD'], 2, 5000, 2 ** 31),
+    # round 2: the player counts the straight-line kernels specialise on (1-7 opponents) and the general fall-back (8),
+    # at every stage of the table
+    (['QC', 'QD'], [], 7, 8000, 21), (['9H', '8H'], ['7H', '6C', '2D'], 7, 8000, 22),
+    (['KD', 'QD'], [], 8, 8000, 23), (['AC', '2C'], ['KC', '7C', '3S', '9D'], 8, 6000, 24),
+    (['4S', '4D'], ['4C', 'JH', 'JD', '9S', '2H'], 7, 6000, 25), (['TD', '9D'], ['8D', '7D', 'AS', 'KS'], 4, 8000, 26),
+    (['6C', '5C'], ['AH', 'KH', 'QH', 'JH', 'TH'], 6, 6000, 27), (['AS', 'QS'], ['2D', '7C', 'TH'], 5, 8000, 28),
+    (['3C', '3D'], [], 9, 6000, 29),
 ]
 
 TRACE_GRID = [  # (hero, board, n_players, seed) -- first 1000 iterations kept
@@ -411,6 +418,9 @@ def gen_ext():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "ext":
         gen_ext()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "tallies":
+        gen_tallies()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "sequence":
         gen_sequence()
