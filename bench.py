@@ -356,6 +356,10 @@ def main():
                 eng.eval_batch(q, seed=1)
                 return dt
 
+            # the headline workload handed over in HOST buffers (H2D of the records, D2H of the rows: PCIe-inclusive)
+            dt = call_time(q, 5)
+            extras["headline_from_host_buffers"] = {"call_ms_host_buffers": 1e3 * dt, "kernel_ms": eng.last_kernel_ms,
+                                                    "hand_evals_per_s": float(B) * runs * N / dt}
             q1 = npa.pack_queries([[npa.card_id("AH"), npa.card_id("KH")]], [[255] * 5], 2, 100000)
             dt = call_time(q1, 20)
             extras["configs[1]_single_query_100k"] = {"call_ms_host_buffers": 1e3 * dt, "kernel_ms": eng.last_kernel_ms,
