@@ -793,7 +793,13 @@ MCQ_HD void mcq_iterations(const McqQueryCtx &qc, Draws &dr, const McqCard *base
         return;
         switch (qc.n_opp) {
             MCQ_STRAIGHT(1) MCQ_STRAIGHT(2) MCQ_STRAIGHT(3) MCQ_STRAIGHT(4) MCQ_STRAIGHT(5) MCQ_STRAIGHT(6) MCQ_STRAIGHT(7)
-            default: break; /* eight or nine opponents (or none): the general form -- their straight-line forms spill registers */
+            case 8: /* (only the form with the table cards counted at run time: the others spill registers) */
+                for (uint32_t j = 0; j < cnt; j++) mcq_iteration<Draws, 8, -1>(qc, dr, base128, tf, tops, sd, acc);
+                return;
+            case 9:
+                for (uint32_t j = 0; j < cnt; j++) mcq_iteration<Draws, 9, -1>(qc, dr, base128, tf, tops, sd, acc);
+                return;
+            default: break; /* hero alone: the general form */
         }
 #undef MCQ_STRAIGHT
     }
