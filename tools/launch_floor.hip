@@ -56,6 +56,37 @@ __global__ __launch_bounds__(1024) void probe(uint32_t flags, const uint32_t *ho
     if (acc == 0xFFFFFFFFu) *sink = acc; /* keeps the loads */
 }
 
+// The same flag-only kernel with N KB of code that is never executed behind a run-time-false branch: does the size of a
+// kernel's code cost launch latency?
+template <int KB>
+__global__ __launch_bounds__(1024) void probe_fat(uint32_t never, volatile uint32_t *flag, uint32_t ticket, uint32_t *sink) {
+    if (never) { /* ~16 bytes of code per step */
+        uint32_t x = threadIdx.x + never;
+#pragma unroll
+        for (int i = 0; i < KB * 64; i++) x = x * 1664525u + (uint32_t)i * 2654435761u + (x >> 7);
+        *sink = x;
+    }
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        *flag = ticket;
+    }
+}
+
+// The same flag-only kernel with N bytes of by-value arguments (only one word of them read): what does the size of
+// the kernel-argument block cost a launch?
+template <int WORDS>
+struct ArgsN {
+    uint32_t w[WORDS];
+};
+template <int WORDS>
+__global__ __launch_bounds__(1024) void probe_args(ArgsN<WORDS> a, volatile uint32_t *flag, uint32_t ticket, uint32_t *sink) {
+    if (a.w[WORDS - 1] == 0xFFFFFFFFu) *sink = a.w[0];
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        *flag = ticket;
+    }
+}
+
 static double now_us() {
     return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -148,6 +179,44 @@ int main() {
         }
         std::sort(f.begin(), f.end());
         printf("%-52s %10s %10s %10.2f\n", "flag only, launched without timestamp events", "-", "-", f[f.size() / 2]);
+    }
+    /* code size: flag-only kernels with 1, 32, 128 KB of dead code */
+    {
+        auto run = [&](auto kern, const char *name) {
+            std::vector<double> f;
+            for (int r = 0; r < reps; r++) {
+                ++ticket;
+                const double a = now_us();
+                hipLaunchKernelGGL(kern, dim3(1), dim3(1024), 0, s, 0u, (volatile uint32_t *)h_flag, ticket, d_sink);
+                while (*(volatile uint32_t *)h_flag != ticket) {
+                }
+                f.push_back(now_us() - a);
+                (void)hipStreamSynchronize(s);
+            }
+            std::sort(f.begin(), f.end());
+            printf("%-52s %10s %10s %10.2f\n", name, "-", "-", f[f.size() / 2]);
+        };
+        auto run_args = [&](auto kern, auto args, const char *name) {
+            std::vector<double> f;
+            memset(&args, 3, sizeof args);
+            for (int r = 0; r < reps; r++) {
+                ++ticket;
+                const double a = now_us();
+                hipLaunchKernelGGL(kern, dim3(1), dim3(1024), 0, s, args, (volatile uint32_t *)h_flag, ticket, d_sink);
+                while (*(volatile uint32_t *)h_flag != ticket) {
+                }
+                f.push_back(now_us() - a);
+                (void)hipStreamSynchronize(s);
+            }
+            std::sort(f.begin(), f.end());
+            printf("%-52s %10s %10s %10.2f\n", name, "-", "-", f[f.size() / 2]);
+        };
+        run_args(probe_args<4>, ArgsN<4>(), "flag only, 16 B of arguments by value");
+        run_args(probe_args<80>, ArgsN<80>(), "flag only, 320 B of arguments by value");
+        run_args(probe_args<640>, ArgsN<640>(), "flag only, 2560 B of arguments by value");
+        run(probe_fat<1>, "flag only, 1 KB of dead code");
+        run(probe_fat<32>, "flag only, 32 KB of dead code");
+        run(probe_fat<128>, "flag only, 128 KB of dead code");
     }
     return 0;
 }
