@@ -532,7 +532,12 @@ static int wait_ticket(mcq_ctx *c, uint32_t ticket, bool *by_flag) {
             __builtin_ia32_pause();
         }
     }
-    if (!seen) HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!seen) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        /* late, or the flag never came: whatever the reason, the next launch starts from a clean block counter */
+        if (c->direct_poll && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != ticket)
+            HIP_TRY(hipMemsetAsync(c->d_done.p, 0, 64, c->stream));
+    }
     if (by_flag) *by_flag = seen;
     return MCQ_OK;
 }
