@@ -109,7 +109,11 @@ def main():
     eng = npa.Engine(0)
     t0 = time.time()
     rounds = queries = iters = ext_q = ext_i = exact_n = 0
+    t_said = t0
     while time.time() - t0 < a.seconds:
+        if time.time() - t_said > 60:   # a sign of life for long runs (the GPU pool kills a command that stays silent)
+            t_said = time.time()
+            print("... %d rounds, %.0f s" % (rounds, t_said - t0), flush=True)
         q = batch(g)
         raw = q.view(np.uint8).reshape(-1, 16)
         seed, first = int(g.integers(0, 2 ** 63)), int(g.integers(0, 2 ** 40))
