@@ -422,21 +422,23 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
 // ---------------------------------------------------------------------------------------------- eval, small queries
 // The reference's own call pattern is thousands of SMALL queries (1000 runs each, gym_env/env.py:22,261-262).  For
 // those the cost of a call is not the arithmetic but the launches and copies around it, so this kernel needs
-// nothing else: it reads the query records straight from the caller's (pinned, device-visible) memory, every query
-// is owned by ONE block -- 2^split waves take the 2^split cuts of each of its 1024-iteration tasks -- the waves'
-// sums meet in LDS and one wave stores the finished 104-byte row straight into the caller's memory.  No prep
-// kernel, no atomics in HBM, no zeroing, no copy kernels.  Iterations, random numbers and hence tallies are those
-// of mcq_eval_kernel (same streams, same cut arithmetic).
+// nothing else: it takes the query records from its own arguments (a launch of up to 128 waves) or straight from the
+// library's pinned, device-visible staging memory, every query is owned by ONE block -- 2^split <= 8 waves take the
+// 2^split cuts of each of its 1024-iteration tasks -- the waves' sums meet in LDS and one wave stores the finished
+// 104-byte row straight into pinned host memory.  No prep kernel, no atomics in HBM, no zeroing, no copy kernels.
+// Iterations, random numbers and hence tallies are those of mcq_eval_kernel (same streams, same cut arithmetic).
 // The host lays the work out (eval_host_philox in mcq_host.cpp): every query gets a power-of-two number of waves in
 // proportion to its cost, so that all waves carry about the same work, and the waves of a query sit side by side in
 // one block.  Wave `v` of block `b` in round `r` finds its work at index (r * gridDim.x + b) * 16 + v:
 //   work_qi[]   the query's index (its RNG stream key and result row), or MCQ_DIRECT_IDLE
 //   work_rec[]  a copy of the 16-byte query record whose reserved bytes carry log2(waves of the query) and this
 //               wave's cut number
-// -- both read by a few lanes per block, eight rounds at a time, into LDS while the tables come in (every wave
-// fetching its own record over PCIe costs more than the arithmetic).  done[0] (device memory, zero before the launch,
-// reset by the last block) counts finished blocks; the last one raises done_flag (pinned host memory) to `ticket`
-// after a system-scope fence, which lets the host pick the rows up without waiting for the end-of-grid handshake.
+// -- both read by a few lanes per block, eight rounds at a time, into LDS while the table image travels global -> LDS
+// (every wave fetching its own record over PCIe costs more than the arithmetic; from the kernel arguments a wave does
+// read its first record itself, by scalar loads, and sets its generator up before the image has landed).  done[0]
+// (device memory, zero before the launch, reset by the last block) counts finished blocks of a grid of several; the
+// last one raises done_flag (pinned host memory) to `ticket` after a system-scope fence, which lets the host pick the
+// rows up without waiting for the end-of-grid handshake.
 #define MCQ_DIRECT_STAGE_ROUNDS 8u
 #ifdef MCQ_DIRECT_STAMPS /* diagnostic build (tools/direct_stamps.py): 100 MHz timestamps of block 0's waves */
 __device__ unsigned long long mcq_direct_stamps[16][16];
