@@ -2,7 +2,7 @@
 // host's point of view, and what each ingredient of mcq_eval_direct_kernel adds (work records read from pinned host
 // memory or from the kernel arguments, a 97 KB table image staged into LDS, a result row stored to pinned host
 // memory behind a system-scope fence, the completion flag).  Build: hipcc --offload-arch=gfx950 -O3 -o
-// tools/launch_floor tools/launch_floor.hip ; run on the GPU box (tools/launch_floor.sh).
+// tools/launch_floor tools/launch_floor.hip ; run tools/launch_floor on the GPU box (the binary travels with the snapshot).
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <chrono>
