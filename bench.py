@@ -14,10 +14,15 @@ scaling: per-GPU work is fixed).
 
 Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
   roofline      VALU integer issue roofline of the evaluation kernel (this path is integer/branch work, neither
-                HBM- nor MFMA-bound: 120 B of HBM traffic per QUERY, none per iteration); `achieved` =
-                algorithmic int32 lane-ops per launch / mean kernel time from HIP events recorded on the
-                launch stream inside the timed region
+                HBM- nor MFMA-bound: 120 B of HBM traffic per QUERY, none per iteration).  `achieved` = int32
+                lane-ops the kernel ISSUES per launch (SQ_INSTS_VALU x 64 lanes, rocprofv3 PMC pass committed
+                under profiles/ for exactly these kernel sources) / mean kernel time from HIP events recorded
+                on the launch stream inside the timed region; `frac` = achieved / the 2-cycle wave64 issue
+                peak, <= 1 by construction.  SURVEY 8(d)'s a-priori cost model is reported beside it as
+                `model` (it over-counts this kernel's instructions 2.3x, so it is not a fraction of anything)
   cpu_baseline  the oracle (a C port of tools/montecarlo_python.py, bit-exact to it) timed on this host
+  parity_spot_check  rows of the LAST timed launch compared with the oracle (outside the timed region); a
+                mismatch makes the process exit non-zero
 """
 import argparse
 import json
@@ -52,16 +57,42 @@ def kernel_source_hash():
 
 
 def profile_counters():
-    """Counter-based figures of the evaluation kernel from the committed rocprofv3 PMC passes (profiles/current.json,
-    written by tools/profile.sh) -- only if they were measured on exactly these kernel sources."""
+    """Counter-based figures of the kernels from the committed rocprofv3 PMC passes (profiles/current.json, written by
+    tools/profile.sh).  -> (summary or None, fresh): fresh = they were measured on exactly these kernel sources."""
     try:
         with open(os.path.join(ROOT, "profiles", "current.json")) as f:
             s = json.load(f)
     except (OSError, ValueError):
-        return None
-    if s.get("kernel_sources_sha256") != kernel_source_hash():
-        return None
-    return s
+        return None, False
+    return s, s.get("kernel_sources_sha256") == kernel_source_hash()
+
+
+def issue_roofline(kernel, kernel_ms, counters, fresh, model_ops_per_launch=None, model_basis=None):
+    """VALU issue roofline of one kernel: achieved = issued int32 lane-ops per launch (SQ_INSTS_VALU wave instructions
+    x 64 lanes, from the committed PMC pass of the same workload) / kernel time; peak = 2-cycle wave64 issue on every
+    SIMD.  An instruction cannot issue faster than that, so frac <= 1 by construction."""
+    r = {"bound": "valu", "kernel": kernel, "kernel_ms": kernel_ms, "peak": PEAK_VALU_TOPS, "unit": "Tops/s (int32 lane-ops)",
+         "achieved": None, "frac": None,
+         "frac_basis": "issued: SQ_INSTS_VALU x 64 lanes per launch (rocprofv3 --pmc, profiles/current.json) / kernel time "
+                       "/ (256 CU x 4 SIMD x 2.4 GHz x 32 lanes)"}
+    insts = counters.get("valu_wave_instructions_per_launch") if counters else None
+    if insts and kernel_ms and kernel_ms == kernel_ms:
+        r["achieved"] = insts * 64.0 / (kernel_ms * 1e-3) / 1e12
+        r["frac"] = r["achieved"] / PEAK_VALU_TOPS
+        r["counters_fresh"] = bool(fresh)  # False: the PMC pass was taken on EARLIER kernel sources (stale count)
+        r["valu_busy"] = counters.get("valu_busy")
+        r["counters"] = {k: counters.get(k) for k in (
+            "kernel_avg_ms_rocprof", "valu_wave_instructions_per_launch", "valu_instructions_per_wave_iteration",
+            "lane_utilisation", "lds_bank_conflict_over_lds_active", "lds_pipe_busy", "hbm_bytes_per_launch", "hbm_GBps")
+            if counters.get(k) is not None}
+        r["counters"]["source"] = "rocprofv3 --pmc passes, profiles/current.json"
+    if model_ops_per_launch:
+        m = model_ops_per_launch / (kernel_ms * 1e-3) / 1e12 if kernel_ms else None
+        r["model"] = {"basis": model_basis, "lane_ops_per_launch": model_ops_per_launch, "Tops": m,
+                      "over_peak": m / PEAK_VALU_TOPS if m else None,
+                      "note": "a-priori cost model, NOT a fraction of a hardware bound: the kernel needs fewer instructions "
+                              "than the model counts, so this ratio can exceed 1"}
+    return r
 
 
 def alg_ops_per_iteration(n_players, n_board):
@@ -296,14 +327,17 @@ def main():
         dist.destroy_process_group()
         return
 
-    ops_per_launch = float(B) * runs * alg_ops_per_iteration(N, 0)
-    achieved = ops_per_launch / (kernel_ms * 1e-3) / 1e12
-    # counter-based figures: from the committed PMC passes, and only when they were taken on these kernel sources and
-    # this workload (else null: a stale profile is not quoted)
-    pc = profile_counters()
+    # counter-based figures: from the committed PMC passes of exactly this workload (kernel time is measured live)
+    pc, fresh = profile_counters()
     if pc and pc.get("workload") != {"states": B, "iters": runs, "players": N}:
         pc = None
-    traffic = pc.get("hbm_bytes_per_launch") if pc else None
+    roof = issue_roofline("mcq_eval_kernel<0, false>", kernel_ms, pc, fresh,
+                          model_ops_per_launch=float(B) * runs * alg_ops_per_iteration(N, 0),
+                          model_basis="SURVEY 8(d): A(N,b) = 48 D + 30 + 82 N = %d lane-ops per iteration" %
+                                      alg_ops_per_iteration(N, 0))
+    roof["traffic"] = pc.get("hbm_bytes_per_launch") if pc else None
+    roof["hbm"] = {"algorithmic_bytes_per_launch": B * 120, "achieved_GBps": B * 120 / (kernel_ms * 1e-3) / 1e9,
+                   "peak_GBps": HBM_PEAK_GBPS}
     out = {
         "metric": "Monte Carlo hand evals/sec @100k iters, 6-max preflop", "value": value, "unit": "hand-evals/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -315,25 +349,9 @@ def main():
                                 ("RCCL" if args.backend == "nccl" else args.backend, world * B) if grouped else ""),
                    "states_per_gpu": B, "n_players": N, "iterations": runs, "n_board": 0,
                    "hand_evals_per_step": evals_per_step},
-        # `achieved` / `frac` are MODEL-based: SURVEY 8(d)'s canonical lane-op count per iteration over the measured
-        # kernel time (a kernel that needs fewer instructions than the model scores above 1).  The counter-based
-        # figures beside it come from rocprofv3 PMC passes of the same kernel (profiles/current.json).
-        "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_VALU_TOPS, "unit": "Tops/s (int32 lane-ops)",
-                     "frac": achieved / PEAK_VALU_TOPS, "frac_basis": "model: 1242 lane-ops per iteration (SURVEY 8d)",
-                     "traffic": traffic,
-                     "kernel": "mcq_eval_kernel<0, false>", "kernel_ms": kernel_ms,
-                     "alg_ops_per_iteration": alg_ops_per_iteration(N, 0),
-                     "counters": None if not pc else {
-                         "source": "rocprofv3 --pmc, profiles/current.json (same kernel sources)",
-                         "kernel_avg_ms_rocprof": pc.get("kernel_avg_ms_rocprof"),
-                         "valu_busy": pc.get("valu_busy"), "lane_utilisation": pc.get("lane_utilisation"),
-                         "valu_instructions_per_wave_iteration": pc.get("valu_instructions_per_wave_iteration"),
-                         "issued_lane_ops_frac": pc.get("issued_lane_ops_frac_of_peak"),
-                         "lds_bank_conflict_over_lds_active": pc.get("lds_bank_conflict_over_lds_active"),
-                         "hbm_GBps": pc.get("hbm_GBps")},
-                     "hbm": {"algorithmic_bytes_per_launch": B * 120,
-                             "achieved_GBps": B * 120 / (kernel_ms * 1e-3) / 1e9, "peak_GBps": HBM_PEAK_GBPS}},
+        "roofline": roof,
     }
+    side_counters = (profile_counters()[0] or {}).get("side_kernels", {})  # PMC passes of tools/side_kernels.py's workloads
     if world == 1 and not args.no_extras:  # single-GPU side measurements; never delay the other ranks' teardown
         extras = {}
 
@@ -384,6 +402,21 @@ def main():
                 extras["configs[2]_replay"] = {"call_ms_host_buffers": 1e3 * dt, "kernel_ms_parse_plus_eval": eng.last_kernel_ms,
                                                "hand_evals_per_s": 4096 * 3 * 50000 / dt,
                                                "mt19937_words_per_s": 4096 * 50000 * 12.8 / dt}
+                sc = side_counters.get("mcq_mt_parse_kernel")  # the stream walk: the dominant kernel of this mode
+                if sc:
+                    extras["configs[2]_replay"]["roofline"] = issue_roofline("mcq_mt_parse_kernel", sc.get("kernel_avg_ms_rocprof"),
+                                                                             sc, fresh)
+            # BASELINE configs[1] in its bit-exact form: ONE query of 100 000 runs replaying np.random.seed(0) -- latency
+            q1r = npa.pack_queries([[npa.card_id("AH"), npa.card_id("KH")]], [[255] * 5], 2, 100000)
+            r1 = eng.eval_batch(q1r, seed=0, mode=npa.MODE_REPLAY_MT19937).view(np.uint64).reshape(-1, 13)
+            t1 = time.perf_counter()
+            for i in range(5):
+                eng.eval_batch(q1r, seed=i, mode=npa.MODE_REPLAY_MT19937)
+            dt = (time.perf_counter() - t1) / 5
+            extras["configs[1]_single_query_100k_replay"] = {
+                "call_ms_host_buffers": 1e3 * dt, "kernel_ms_parse_plus_eval": eng.last_kernel_ms, "hand_evals_per_s": 2e5 / dt,
+                "wins_seed0": int(r1[0, 2] + r1[0, 3]), "passes_seed0": int(r1[0, 1]),
+                "equals_reference_known_answer": bool(int(r1[0, 2] + r1[0, 3]) == 65807 and int(r1[0, 1]) == 102091)}
             # run_montecarlo's other arguments: opponents restricted to the top quarter of the preflop classes
             # (the range the reference's own test uses, tests/test_montecarlo_python.py:215-222), 2048 states x 6 players x
             # 20k iterations through mcq_eval_batch_ext / mcq_eval_ext_kernel (candidate lists instead of the re-draw loop)
@@ -398,13 +431,19 @@ def main():
                     eng.eval_batch_ext(qx, ex, i)
                 dt = (time.perf_counter() - t1) / 3
                 kms = eng.last_kernel_ms
-                ops = 2048.0 * 20000 * alg_ops_per_iteration(6, 0)
                 extras["ext_opponents_top25pct_2048x6x20k"] = {
                     "call_ms_host_buffers": 1e3 * dt, "kernel_ms": kms, "hand_evals_per_s": 2048 * 6 * 20000 / dt,
-                    "roofline": {"bound": "valu", "kernel": "mcq_eval_ext_kernel<0>", "achieved": ops / (kms * 1e-3) / 1e12,
-                                 "peak": PEAK_VALU_TOPS, "unit": "Tops/s (int32 lane-ops)",
-                                 "frac": ops / (kms * 1e-3) / 1e12 / PEAK_VALU_TOPS,
-                                 "frac_basis": "model: the plain path's 1242 lane-ops per iteration (SURVEY 8d)"}}
+                    "roofline": issue_roofline("mcq_eval_ext_kernel<0>", kms, side_counters.get("mcq_eval_ext_kernel<0>"), fresh,
+                                               model_ops_per_launch=2048.0 * 20000 * alg_ops_per_iteration(6, 0),
+                                               model_basis="the plain path's 1242 lane-ops per iteration (SURVEY 8d)")}
+                # the same range in the bit-exact mode (the reference's re-draw loop walked on numpy's MT19937 stream)
+                qxs, exs = qx[:256], npa.pack_query_ext(256, opp_range=npa.range_bits(order[-int(169 * 0.25):]))
+                eng.eval_batch_ext(qxs, exs, 1, mode=npa.MODE_REPLAY_MT19937)
+                t1 = time.perf_counter()
+                eng.eval_batch_ext(qxs, exs, 2, mode=npa.MODE_REPLAY_MT19937)
+                dt = time.perf_counter() - t1
+                extras["ext_opponents_top25pct_256x6x20k_replay"] = {"call_ms_host_buffers": 1e3 * dt,
+                                                                     "hand_evals_per_s": 256 * 6 * 20000 / dt}
             # BASELINE configs[3] (the 8-GPU config) on this one GPU: 65 536 states, flop / turn tables alternating, 6 players,
             # 20k iterations, host buffers; one rank of 8 would take an eighth of the queries
             g3 = np.random.default_rng(65536)
@@ -452,6 +491,8 @@ def main():
             extras["configs[4]_equity_side_only_1024x1000"] = {"call_ms_host_buffers": 1e3 * dt, "kernel_ms": eng.last_kernel_ms,
                                                                "hand_evals_per_s": float((npl * 1000).sum()) / dt,
                                                                "lock_steps_per_s": 1.0 / dt}
+            extras["configs[4]_equity_side_only_1024x1000"]["roofline"] = issue_roofline(
+                "mcq_eval_direct_kernel<0>", eng.last_kernel_ms, side_counters.get("mcq_eval_direct_kernel<0>"), fresh)
             # the two remaining kernels of the library, so that they have a number and a row in the kernel trace
             # (tools/profile.sh runs this command under rocprofv3): exact enumeration of AhKh heads-up
             # preflop under the reference's law -- C(50,5) completions x 990 candidate hands -- and of a three-player
@@ -501,7 +542,36 @@ def main():
         except Exception as e:  # noqa: BLE001 -- recorded in the line, the headline stands
             extras["error"] = "%s: %s" % (type(e).__name__, e)
         out["other_configs"] = extras
+    spot_ok = True
     if world == 1 and not args.no_cpu_baseline:
+        try:
+            # Parity spot check of the LAST TIMED launch: its rows are still in `tallies`; the oracle (MCQ-CTR mode:
+            # the same specification as the production kernel, montecarlo_python.py:223-250 for what a row means)
+            # recomputes 16 of them, spread over the batch, from the same (seed, query id).  Outside the timed region.
+            from oracle import oracle as O
+            O.lib()
+            rows = np.unique(np.linspace(0, B - 1, 16).astype(np.int64))
+            last_seed = seed + args.warmup + args.steps - 1
+            raw = q.view(np.uint8).reshape(B, 16)
+            equal, first_bad = True, None
+            threads = max(1, min(len(rows), len(os.sched_getaffinity(0))))
+            exp = np.zeros((len(rows), 13), np.uint64)
+            import concurrent.futures as cf
+            with cf.ThreadPoolExecutor(threads) as ex:  # one oracle call per row: the row's own query id keys its streams
+                futs = {ex.submit(O.run_batch, O.MODE_CTR, raw[r:r + 1], last_seed, rank * B + int(r)): k
+                        for k, r in enumerate(rows)}
+                for f, k in futs.items():
+                    exp[k] = f.result()[0]
+            got = t[rows]
+            equal = bool(np.array_equal(got, exp))
+            if not equal:
+                first_bad = int(rows[np.nonzero((got != exp).any(1))[0][0]])
+            out["parity_spot_check"] = {"rows": int(len(rows)), "equal": equal, "row_ids": [int(r) for r in rows],
+                                        "seed": int(last_seed), "against": "oracle/mcq_oracle.c MODE_CTR (bit-exact integers: "
+                                        "runs, passes, win, tie, by_type[9])", "first_mismatch": first_bad}
+            spot_ok = equal
+        except Exception as e:  # noqa: BLE001
+            out["parity_spot_check"] = {"rows": 0, "equal": None, "error": "%s: %s" % (type(e).__name__, e)}
         try:
             out["cpu_baseline"] = cpu_baseline(N, runs)
             out["cpu_baseline_1thread"] = cpu_baseline(N, runs, seconds=5.0, threads=1)
@@ -513,6 +583,8 @@ def main():
     print(json.dumps(out), file=JSON_OUT, flush=True)
     if grouped:
         dist.destroy_process_group()
+    if not spot_ok:
+        raise SystemExit("parity spot check FAILED: the timed launch's rows differ from the oracle's")
 
 
 if __name__ == "__main__":

@@ -243,7 +243,11 @@ MCQ_API int mcq_tables_state(const mcq_tables *t, uint32_t table, double *stacks
  * from ncclCommInitAll, owned by the mcq_multi object; RCCL over xGMI) leaves the complete matrix on every device;
  * out[0..n) is copied from the first.  The tallies are bit-identical to mcq_eval_batch on one context with the same
  * (seed, first_query_id), whatever the partition.  MCQ_MODE_PHILOX.  RCCL is bound (dlopen) when the first
- * mcq_multi is created; a process that never creates one never maps it. */
+ * mcq_multi is created; a process that never creates one never maps it.
+ * STATUS: with more than one DISTINCT device this entry has NOT been exercised on hardware yet (no multi-GPU node was
+ * reachable while it was built): the partitions, the same-device add and a one-rank RCCL communicator are tested on
+ * one GPU, where all shards share the device; ncclCommInitAll over several devices, the grouped all-reduce and the
+ * per-device stream waits run for the first time on a multi-GPU node. */
 #define MCQ_PARTITION_AUTO 0
 #define MCQ_PARTITION_QUERIES 1
 #define MCQ_PARTITION_ITERATIONS 2

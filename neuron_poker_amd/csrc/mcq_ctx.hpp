@@ -129,7 +129,7 @@ struct mcq_ctx {
     } scratch[kScratch];
     uint64_t scratch_clock = 0;
     size_t res_clean = 0; /* leading bytes of d_res known to be zero (host entries leave their rows zeroed again) */
-    DevBuf d_q, d_res, d_draws, d_off, d_hands, d_win, d_wt, d_keys, d_ext, d_mt, d_lists, d_cnts;
+    DevBuf d_q, d_res, d_draws, d_off, d_ext, d_mt, d_lists, d_cnts;
     PinBuf h_q, h_res, h_draws, h_off, h_misc, h_flag;
     DevBuf d_done;                /* block counter of the one-launch path */
     uint32_t direct_ticket = 0;   /* value the kernel raises the flag in h_flag to */

@@ -357,7 +357,7 @@ void mcq_destroy(mcq_ctx *c) {
     if (!c) return;
     McqDeviceScope dev_(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf *db[] = {&c->d_q, &c->d_res, &c->d_draws, &c->d_off, &c->d_hands, &c->d_win, &c->d_wt, &c->d_keys, &c->d_ext,
+    DevBuf *db[] = {&c->d_q, &c->d_res, &c->d_draws, &c->d_off, &c->d_ext,
                     &c->d_mt, &c->d_lists, &c->d_cnts};
     for (auto &sc : c->scratch) {
         sc.prefix.release();
@@ -519,13 +519,16 @@ static uint32_t next_ticket(mcq_ctx *c) {
     return c->direct_ticket;
 }
 /* Picking the rows up at the flag saves the end-of-kernel handshake of a stream synchronisation (24 us against 7.5 us
- * from launch to flag for an empty kernel, tools/launch_floor.hip).  A kernel that has not answered after a few
- * milliseconds is left to hipStreamSynchronize, which reports what went wrong. */
-static int wait_ticket(mcq_ctx *c, uint32_t ticket, bool *by_flag) {
+ * from launch to flag for an empty kernel, tools/launch_floor.hip).  Polling burns a core, so it is kept for SHORT
+ * work: a call whose kernels are expected to run for est_us microseconds (scheduling cost x the measured time per cost
+ * unit) first sleeps through most of that and only then polls; a kernel that has not answered a few milliseconds
+ * after it was expected is left to hipStreamSynchronize, which reports what went wrong. */
+static int wait_ticket(mcq_ctx *c, uint32_t ticket, bool *by_flag, double est_us = 0.0) {
     const volatile uint32_t *flag = static_cast<const volatile uint32_t *>(c->h_flag.p);
-    const auto t1 = std::chrono::steady_clock::now();
     bool seen = false;
     if (c->direct_poll) {
+        if (est_us > 300.0) std::this_thread::sleep_for(std::chrono::microseconds((long long)(0.85 * est_us) - 60));
+        const auto t1 = std::chrono::steady_clock::now();
         for (uint32_t spin = 0;; spin++) {
             if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == ticket) { seen = true; break; }
             if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t1 > std::chrono::milliseconds(5)) break;
@@ -541,6 +544,8 @@ static int wait_ticket(mcq_ctx *c, uint32_t ticket, bool *by_flag) {
     if (by_flag) *by_flag = seen;
     return MCQ_OK;
 }
+/* expected kernel time of work of scheduling cost `cost` (mcq_task_weight units, about 0.0066 ns each on a whole MI355X) */
+static double cost_to_us(const mcq_ctx *c, uint64_t cost) { return (double)cost * 6.6e-6 * 256.0 / (double)(c->n_cu > 0 ? c->n_cu : 256); }
 
 /* Production mode from host buffers.  The host has the queries in its hands, so it prices them itself: the cost
  * prefix travels with the queries in ONE copy, the result rows are zero already (every call leaves them so), and
@@ -676,7 +681,7 @@ static int eval_host_philox(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t s
         const uint32_t ticket = next_ticket(c);
         HIP_TRY(mcq_launch_publish((mcq_result *)c->d_res.p, (mcq_result *)c->h_res.dev, n + (n & 1u), (uint32_t *)c->d_done.p,
                                    (uint32_t *)c->h_flag.dev, ticket, c->stream));
-        rc = wait_ticket(c, ticket, nullptr);
+        rc = wait_ticket(c, ticket, nullptr, cost_to_us(c, cost));
         if (rc) return rc;
     } else {
         HIP_TRY(hipMemcpyAsync(c->h_res.p, c->d_res.p, r_bytes, hipMemcpyDeviceToHost, c->stream));
@@ -863,35 +868,40 @@ int mcq_showdown(mcq_ctx *c, const uint8_t *hands, size_t n_tables, int n_player
     if (!hands || !winner || !winner_type) return mcq_fail(MCQ_EINVAL, "mcq_showdown: null buffer");
     if (n_players < 1 || n_players > 10) return mcq_fail(MCQ_EINVAL, "mcq_showdown: n_players must be in [1,10]");
     if (n_tables > 0x7fffffffu / 70u) return mcq_fail(MCQ_EINVAL, "mcq_showdown: n_tables too large");
-    const size_t nh = n_tables * (size_t)n_players;
-    for (size_t h = 0; h < nh; h++) {
-        uint64_t seen = 0;
-        for (int k = 0; k < 7; k++) {
-            uint8_t cd = hands[h * 7 + k];
-            if (cd >= 52 || (seen >> cd) & 1)
-                return mcq_fail(MCQ_EINVAL, "mcq_showdown: a hand needs 7 distinct card ids < 52");
-            seen |= 1ull << cd;
-        }
-    }
+    /* The host only moves bytes: the hands go through pinned memory in pieces, each piece's kernel launched as soon as
+     * the piece is there (the kernel reads it in place across PCIe with 16-byte loads while the host copies the next
+     * piece), validation happens on the device, winners / types / keys come back in pinned memory and the last kernel
+     * raises the completion flag -- no blocking copies, no stream synchronisation. */
+    const size_t per_table = 7u * (size_t)n_players, nh = n_tables * (size_t)n_players;
+    const size_t pad_tables = (n_tables + 255u) & ~(size_t)255u;
+    const size_t in_bytes = pad_tables * per_table, key_bytes = keys ? pad_tables * n_players * sizeof(uint32_t) : 0;
     McqDeviceScope dev_(c->device);
     HIP_TRY(dev_.err);
-    HIP_TRY(c->d_hands.reserve(nh * 7));
-    HIP_TRY(c->d_win.reserve(n_tables));
-    HIP_TRY(c->d_wt.reserve(n_tables));
-    HIP_TRY(c->d_keys.reserve(nh * sizeof(uint32_t)));
-    HIP_TRY(c->h_misc.reserve(nh * 7 + 2 * n_tables + nh * sizeof(uint32_t)));
-    uint8_t *hp = (uint8_t *)c->h_misc.p;
-    memcpy(hp, hands, nh * 7);
-    HIP_TRY(hipMemcpyAsync(c->d_hands.p, hp, nh * 7, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(mcq_launch_showdown((const uint8_t *)c->d_hands.p, (uint32_t)n_tables, (uint32_t)n_players, c->d_luts,
-                                (uint8_t *)c->d_win.p, (uint8_t *)c->d_wt.p, (uint32_t *)c->d_keys.p, c->stream));
-    uint8_t *hw = hp + nh * 7, *ht = hw + n_tables;
-    HIP_TRY(hipMemcpyAsync(hw, c->d_win.p, n_tables, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(ht, c->d_wt.p, n_tables, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    memcpy(winner, hw, n_tables);
-    memcpy(winner_type, ht, n_tables);
-    if (keys) HIP_TRY(hipMemcpy(keys, c->d_keys.p, nh * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(c->h_misc.reserve(in_bytes + 2 * pad_tables + key_bytes + 64));
+    int rc = flag_ready(c);
+    if (rc) return rc;
+    uint8_t *hp = (uint8_t *)c->h_misc.p, *dp = (uint8_t *)c->h_misc.dev;
+    const size_t off_w = in_bytes, off_t = off_w + pad_tables, off_k = off_t + pad_tables; /* all multiples of 16 */
+    volatile uint32_t *bad = static_cast<volatile uint32_t *>(c->h_flag.p) + 1;
+    *bad = 0;
+    size_t piece = (256u << 10) / per_table & ~(size_t)255u; /* tables per piece: about 256 KB, whole tiles */
+    if (piece < 256u) piece = 256u;
+    const uint32_t ticket = next_ticket(c);
+    for (size_t a = 0; a < n_tables; a += piece) {
+        const size_t b = a + piece < n_tables ? a + piece : n_tables;
+        memcpy(hp + a * per_table, hands + a * per_table, (b - a) * per_table);
+        HIP_TRY(mcq_launch_showdown(dp + a * per_table, (uint32_t)(b - a), (uint32_t)n_players, c->d_luts, dp + off_w + a,
+                                    dp + off_t + a, keys ? reinterpret_cast<uint32_t *>(dp + off_k) + a * n_players : nullptr,
+                                    static_cast<uint32_t *>(c->h_flag.dev) + 1, (uint32_t *)c->d_done.p,
+                                    (uint32_t *)c->h_flag.dev, b == n_tables ? ticket : 0u, (uint32_t)c->n_cu, c->stream));
+    }
+    rc = wait_ticket(c, ticket, nullptr);
+    if (rc) return rc;
+    if (__atomic_load_n(bad, __ATOMIC_ACQUIRE) != 0u)
+        return mcq_fail(MCQ_EINVAL, "mcq_showdown: a hand needs 7 distinct card ids < 52");
+    memcpy(winner, hp + off_w, n_tables);
+    memcpy(winner_type, hp + off_t, n_tables);
+    if (keys) memcpy(keys, hp + off_k, nh * sizeof(uint32_t));
     return MCQ_OK;
     ABI_GUARD_END("mcq_showdown")
 }

@@ -18,8 +18,12 @@ hipError_t mcq_launch_eval(int mode, const mcq_query *d_q, uint32_t n, const uin
 /* exact enumeration of ONE query (host pointer q; n_players <= 3): adds into the zeroed row d_row */
 hipError_t mcq_launch_exact(const mcq_query *q, int law, mcq_result *d_row, const McqTables *d_luts, uint32_t n_cu,
                             hipStream_t s);
-hipError_t mcq_launch_showdown(const uint8_t *d_hands, uint32_t n_tables, uint32_t n_players, const McqTables *d_luts,
-                               uint8_t *d_winner, uint8_t *d_wtype, uint32_t *d_keys, hipStream_t s);
+/* hands / winner / wtype / keys: device-visible memory (pinned host memory or HBM), 16-byte aligned and padded to whole
+ * tiles of 256 tables; *bad is set when a hand is not seven distinct ids < 52; ticket != 0: the last block raises
+ * *done_flag behind a system-scope release (d_done: a zeroed device word) */
+hipError_t mcq_launch_showdown(const uint8_t *hands, uint32_t n_tables, uint32_t n_players, const McqTables *d_luts,
+                               uint8_t *winner, uint8_t *wtype, uint32_t *keys, uint32_t *bad, uint32_t *d_done,
+                               uint32_t *done_flag, uint32_t ticket, uint32_t n_cu, hipStream_t s);
 hipError_t mcq_launch_prep_ext(const mcq_query *d_q, const mcq_query_ext *d_ext, uint32_t n, mcq_result *d_res,
                                uint64_t *d_prefix, hipStream_t s);
 /* production mode of the extended queries: lays out the candidate lists (lists_stride per query, MCQ_EXT_LIST_STRIDE

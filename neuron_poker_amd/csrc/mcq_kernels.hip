@@ -411,7 +411,8 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
                     mcq_iteration(qc, dr, base - 128, g_tab->tf, tab.tops, tab.sd, acc);
                 }
             }
-            acc.passes = 0; /* counted by the host while parsing the MT19937 stream */
+            acc.passes = 0; /* `passes` comes from the stream walk: mcq_mt_parse_kernel writes it into the row (the host walk
+                             * of mcq_eval_batch_numpy_stream patches it in afterwards) */
         }
         tally.add(acc);
         task++;
@@ -850,30 +851,84 @@ __global__ __launch_bounds__(kExtBlock) void mcq_eval_ext_kernel(const mcq_query
 }
 
 // ---------------------------------------------------------------------------------------------- showdown
-__global__ __launch_bounds__(256) void mcq_showdown_kernel(const uint8_t *__restrict__ hands, uint32_t n_tables,
-                                                           uint32_t n_players, const McqTables *__restrict__ g_tab,
-                                                           uint8_t *__restrict__ winner, uint8_t *__restrict__ wtype,
-                                                           uint32_t *__restrict__ keys) {
-    __shared__ __attribute__((aligned(16))) LdsTablesEval tab;
-    load_tables(tab, g_tab);
-    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_tables; t += gridDim.x * blockDim.x) {
-        uint32_t best = 0, w = 0;
-        for (uint32_t p = 0; p < n_players; p++) {
-            const uint8_t *h = hands + ((size_t)t * n_players + p) * 7;
-            McqBoard b;
-            b.clear();
+// hand_evaluator.get_winner (tools/hand_evaluator.py:9-24) for many tables: the same ranking key as the Monte-Carlo path.
+// HBM/PCIe-bound byte work (7 bytes in per hand, 2 bytes out per table), so the layout is what matters: a block takes a
+// TILE of 256 tables, whose hands are one contiguous run of 256 * n_players * 7 bytes -- staged into LDS with 16-byte
+// loads straight from the caller-visible buffer (pinned host memory or HBM), evaluated one table per thread with the
+// lookup tables read through the vector L1 / L2 (2 M lookups: not worth 97 KB of LDS per block), results leave as
+// 16-byte stores.  A hand that does not hold seven distinct ids < 52 marks `bad` (the host reports MCQ_EINVAL) --
+// validation on the device, as mcq_prep_kernel does for queries.  With ticket != 0 the last block to finish raises the
+// host's completion flag behind a system-scope release, as mcq_publish_kernel does.
+constexpr int kShowBlock = 256;
+__global__ __launch_bounds__(kShowBlock) void mcq_showdown_kernel(const uint8_t *__restrict__ hands, uint32_t n_tables,
+                                                                  uint32_t n_players, const McqTables *__restrict__ g_tab,
+                                                                  uint8_t *__restrict__ winner, uint8_t *__restrict__ wtype,
+                                                                  uint32_t *__restrict__ keys, uint32_t *__restrict__ bad,
+                                                                  uint32_t *__restrict__ done, volatile uint32_t *done_flag,
+                                                                  uint32_t ticket) {
+    __shared__ __attribute__((aligned(16))) uint8_t tile[kShowBlock * 7 * 10];
+    __shared__ __attribute__((aligned(16))) uint32_t tile_keys[kShowBlock * 10];
+    __shared__ __attribute__((aligned(16))) uint8_t tile_win[kShowBlock], tile_type[kShowBlock];
+    const uint32_t per_table = 7u * n_players, n_tiles = (n_tables + kShowBlock - 1u) / kShowBlock;
+    for (uint32_t t0 = blockIdx.x; t0 < n_tiles; t0 += gridDim.x) {
+        const uint32_t first = t0 * kShowBlock, cnt = min((uint32_t)kShowBlock, n_tables - first);
+        const uint32_t bytes = cnt * per_table, vecs = (bytes + 15u) / 16u; /* the buffers are padded to 16 bytes */
+        const uint4 *src = reinterpret_cast<const uint4 *>(hands + (size_t)first * per_table); /* 256 * 7 * P: a multiple of 16 */
+        __syncthreads(); /* the previous tile has been read */
+        for (uint32_t i = threadIdx.x; i < vecs; i += kShowBlock) reinterpret_cast<uint4 *>(tile)[i] = src[i];
+        __syncthreads();
+        if (threadIdx.x < cnt) {
+            const uint8_t *h = tile + threadIdx.x * per_table;
+            uint32_t best = 0, w = 0;
+            bool ok = true;
+            for (uint32_t p = 0; p < n_players; p++, h += 7) {
+                uint64_t seen = 0;
+                uint32_t c[7];
 #pragma unroll
-            for (int k = 2; k < 7; k++) b.add(mcq_card(h[k] < 52 ? h[k] : 0));
-            McqHole hole;
-            hole.set(mcq_card(h[0] < 52 ? h[0] : 0), mcq_card(h[1] < 52 ? h[1] : 0));
-            McqFlushSel fs;
-            fs.from_board(b);
-            const uint32_t key = mcq_eval_key(b, fs, hole, g_tab->tf, tab.tops, tab.sd);
-            if (keys) keys[(size_t)t * n_players + p] = key;
-            if (key > best) { best = key; w = p; } /* strict: the first of equal hands stays (hand_evaluator.py:23) */
+                for (int k = 0; k < 7; k++) {
+                    c[k] = h[k];
+                    ok = ok && c[k] < 52u && !((seen >> (c[k] & 63u)) & 1ull);
+                    seen |= 1ull << (c[k] & 63u);
+                    c[k] = c[k] < 52u ? c[k] : 0u;
+                }
+                McqBoard b;
+                b.clear();
+#pragma unroll
+                for (int k = 2; k < 7; k++) b.add(mcq_card(c[k]));
+                McqHole hole;
+                hole.set(mcq_card(c[0]), mcq_card(c[1]));
+                McqFlushSel fs;
+                fs.from_board(b);
+                const uint32_t key = mcq_eval_key(b, fs, hole, g_tab->tf, g_tab->tops, g_tab->sd);
+                tile_keys[threadIdx.x * n_players + p] = key;
+                if (key > best) { best = key; w = p; } /* strict: the first of equal hands stays (hand_evaluator.py:23) */
+            }
+            tile_win[threadIdx.x] = (uint8_t)w;
+            tile_type[threadIdx.x] = (uint8_t)mcq_key_type(best);
+            if (!ok) *reinterpret_cast<volatile uint32_t *>(bad) = 1u; /* (a plain store: every writer writes the same word) */
         }
-        winner[t] = (uint8_t)w;
-        wtype[t] = (uint8_t)mcq_key_type(best);
+        __syncthreads();
+        /* results: whole 16-byte words (the output buffers are padded to the tile) */
+        if (threadIdx.x < kShowBlock / 16) {
+            reinterpret_cast<uint4 *>(winner + first)[threadIdx.x] = reinterpret_cast<const uint4 *>(tile_win)[threadIdx.x];
+            reinterpret_cast<uint4 *>(wtype + first)[threadIdx.x] = reinterpret_cast<const uint4 *>(tile_type)[threadIdx.x];
+        }
+        if (keys) {
+            const uint32_t kv = (cnt * n_players + 3u) / 4u;
+            uint4 *dst = reinterpret_cast<uint4 *>(keys + (size_t)first * n_players); /* 256 * P keys: a multiple of four */
+            for (uint32_t i = threadIdx.x; i < kv; i += kShowBlock) dst[i] = reinterpret_cast<const uint4 *>(tile_keys)[i];
+        }
+    }
+    if (ticket == 0u) return; /* not the last launch of the call */
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system(); /* this block's results (and `bad`) have reached the host's memory */
+        bool last = true;
+        if (gridDim.x > 1u) {
+            last = atomicAdd(done, 1u) + 1u == gridDim.x;
+            if (last) *done = 0;
+        }
+        if (last) *done_flag = ticket;
     }
 }
 
@@ -1057,13 +1112,14 @@ hipError_t mcq_launch_eval_ext(int mode, const mcq_query *d_q, const mcq_query_e
     return hipGetLastError();
 }
 
-hipError_t mcq_launch_showdown(const uint8_t *d_hands, uint32_t n_tables, uint32_t n_players, const McqTables *d_luts,
-                               uint8_t *d_winner, uint8_t *d_wtype, uint32_t *d_keys, hipStream_t s) {
-    uint32_t grid = (n_tables + 255) / 256;
-    if (grid > 4096) grid = 4096;
-    if (grid == 0) grid = 1;
-    hipLaunchKernelGGL(mcq_showdown_kernel, dim3(grid), dim3(256), 0, s, d_hands, n_tables, n_players, d_luts,
-                       d_winner, d_wtype, d_keys);
+hipError_t mcq_launch_showdown(const uint8_t *hands, uint32_t n_tables, uint32_t n_players, const McqTables *d_luts,
+                               uint8_t *winner, uint8_t *wtype, uint32_t *keys, uint32_t *bad, uint32_t *d_done,
+                               uint32_t *done_flag, uint32_t ticket, uint32_t n_cu, hipStream_t s) {
+    if (n_tables == 0 || n_players < 1 || n_players > 10) return hipErrorInvalidValue;
+    uint32_t grid = (n_tables + kShowBlock - 1) / kShowBlock;
+    if (grid > 5u * n_cu) grid = 5u * n_cu; /* 30 KB of LDS per block: five blocks per CU */
+    hipLaunchKernelGGL(mcq_showdown_kernel, dim3(grid), dim3(kShowBlock), 0, s, hands, n_tables, n_players, d_luts, winner,
+                       wtype, keys, bad, d_done, done_flag, ticket);
     return hipGetLastError();
 }
 

@@ -63,9 +63,13 @@ bool rccl_bind(Rccl &r, void *h, const char *path) {
 
 /* Bind RCCL once per process.  Order: $MCQ_RCCL_LIBRARY; an RCCL the process has already mapped; the copy that
  * sits beside the HIP runtime in use (the one built against it); the loader's search path. */
-const Rccl *rccl_get() {
+const Rccl *rccl_get(std::string *error /* out: why not, copied while the lock is held */) {
     std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (g_rccl.handle) return &g_rccl;
+    struct OnExit {
+        std::string *e;
+        ~OnExit() { if (e && !g_rccl.handle) *e = g_rccl.error; }
+    } on_exit_{error};
     std::vector<std::string> cand;
     if (const char *e = getenv("MCQ_RCCL_LIBRARY")) cand.push_back(e);
     for (const char *name : {"librccl.so.1", "librccl.so"}) {
@@ -379,13 +383,18 @@ mcq_multi *mcq_multi_create(const int *devices, int n_shards, int flags) {
                      e != hipSuccess ? hipGetErrorString(e) : nullptr);
             return nullptr;
         }
-        mcq_multi *m = new mcq_multi();
+        /* whatever fails from here on -- an error return or an exception (std::system_error from a worker thread,
+         * bad_alloc) -- the guard takes the half-built object apart: contexts, streams, events, communicators, workers */
+        struct Guard {
+            mcq_multi *m;
+            ~Guard() { if (m) mcq_multi_destroy(m); }
+        } guard{new mcq_multi()};
+        mcq_multi *m = guard.m;
         m->shards = std::vector<Shard>((size_t)n_shards);
         for (int s = 0; s < n_shards; s++) {
             const int d = devices ? devices[s] : s;
             if (d < 0 || d >= n_dev) {
                 mcq_fail(MCQ_EINVAL, "mcq_multi_create: device ordinal out of range (devices = NULL means shard s on device s)");
-                mcq_multi_destroy(m);
                 return nullptr;
             }
             Shard &sh = m->shards[(size_t)s];
@@ -402,7 +411,7 @@ mcq_multi *mcq_multi_create(const int *devices, int n_shards, int flags) {
         for (int s = 0; s < n_shards; s++) {
             Shard &sh = m->shards[(size_t)s];
             sh.ctx = mcq_create(sh.device, 0);
-            if (!sh.ctx) { mcq_multi_destroy(m); return nullptr; }
+            if (!sh.ctx) return nullptr;
             sh.ctx->timing = true; /* mcq_multi_times reports the shards' kernel times; these are bulk launches */
             McqDeviceScope dev(sh.device);
             hipError_t e2 = hipEventCreateWithFlags(&sh.launched, hipEventDisableTiming);
@@ -412,14 +421,13 @@ mcq_multi *mcq_multi_create(const int *devices, int n_shards, int flags) {
             }
             if (e2 != hipSuccess) {
                 mcq_fail(MCQ_EDEVICE, "mcq_multi_create: hipEventCreate", hipGetErrorString(e2));
-                mcq_multi_destroy(m);
                 return nullptr;
             }
         }
-        m->rccl = rccl_get();
+        std::string rccl_error;
+        m->rccl = rccl_get(&rccl_error);
         if (!m->rccl) {
-            mcq_fail(MCQ_EDEVICE, "mcq_multi_create", g_rccl.error.c_str());
-            mcq_multi_destroy(m);
+            mcq_fail(MCQ_EDEVICE, "mcq_multi_create", rccl_error.c_str());
             return nullptr;
         }
         (void)m->rccl->GetVersion(&m->rccl_version);
@@ -427,10 +435,10 @@ mcq_multi *mcq_multi_create(const int *devices, int n_shards, int flags) {
         ncclResult_t r = m->rccl->CommInitAll(m->comms.data(), (int)m->devices.size(), m->devices.data());
         if (r != ncclSuccess) {
             mcq_fail(MCQ_EDEVICE, "ncclCommInitAll", m->rccl->GetErrorString(r));
-            mcq_multi_destroy(m);
             return nullptr;
         }
         for (int s = 1; s < n_shards; s++) m->shards[(size_t)s].worker.start(s);
+        guard.m = nullptr;
         return m;
     } catch (const std::exception &ex) {
         mcq_fail(MCQ_ENOMEM, "mcq_multi_create", ex.what());
