@@ -307,6 +307,7 @@ struct McqCtrDrawsT {
         bias = mcq_p128_bias();
         rng.seed(seed, qid, stream);
     }
+    template <int P>
     MCQ_HDM void pair(uint32_t L, uint32_t &r1, uint32_t &r2) {
         const uint32_t dd = L - 1u, m1 = UNIFORM ? L : dd;
         const uint32_t u = rng.next();
@@ -328,14 +329,15 @@ struct McqCtrDrawsT {
 typedef McqCtrDrawsT<false> McqCtrDraws;
 typedef McqCtrDrawsT<true> McqCtrDrawsUniform;
 
-// Draw policy of the parity mode: the host has already turned the MT19937 stream into the accepted draw
-// values (one byte each, draw-major: draws[d * stride + iteration]); rejected pairs only count in `passes`,
-// which the host supplies.
-struct McqReplayDraws {
+// Draw policy of the parity mode: the stream walk (mcq_mt.hpp on the device, mcq_replay.hpp on the host) has already
+// turned the MT19937 stream into the accepted draw values (one byte each, r | 0x80, draw-major:
+// draws[d * stride + iteration]); rejected pairs only count in `passes`, which the walk supplies.
+struct McqReplayDraws { /* one iteration, byte by byte */
     static constexpr uint32_t kTableShort = 1u;
     const uint8_t *p; /* &draws[iteration] */
     uint64_t stride;
-    MCQ_HDM void pair(uint32_t, uint32_t &r1, uint32_t &r2) { /* the host stores every draw as r | 0x80 */
+    template <int P>
+    MCQ_HDM void pair(uint32_t, uint32_t &r1, uint32_t &r2) {
         r1 = p[0];
         r2 = p[stride];
         p += 2 * stride;
@@ -346,6 +348,42 @@ struct McqReplayDraws {
         p += stride;
         return v;
     }
+};
+// The same for FOUR consecutive iterations of a lane: one 32-bit load per draw row brings the four iterations' bytes
+// (a wave reads 256 contiguous bytes per row instead of 64: a quarter of the vector-memory instructions and no
+// 64-bit address arithmetic per byte); iteration `k` of the four takes byte k of every word.
+MCQ_HD uint32_t mcq_ld32_bytes(const uint8_t *p) { /* device: p is 4-aligned (rows start at multiples of 64) */
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *reinterpret_cast<const uint32_t *>(p);
+#else
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+#endif
+}
+struct McqReplayDraws4 {
+    static constexpr uint32_t kTableShort = 1u;
+    uint32_t ow[2 * MCQ_MAX_OPP], tw[5];
+    uint32_t sh; /* 8 * k */
+    MCQ_HDM void load(const uint8_t *first /* &draws[4-aligned iteration] */, uint64_t stride, uint32_t n_opp, uint32_t n_deal) {
+#pragma unroll
+        for (int P = 0; P < MCQ_MAX_OPP; P++)
+            if ((uint32_t)P < n_opp) {
+                ow[2 * P] = mcq_ld32_bytes(first + (uint64_t)(2 * P) * stride);
+                ow[2 * P + 1] = mcq_ld32_bytes(first + (uint64_t)(2 * P + 1) * stride);
+            }
+        const uint8_t *t = first + (uint64_t)(2u * n_opp) * stride;
+#pragma unroll
+        for (int K = 0; K < 5; K++)
+            if ((uint32_t)K < n_deal) tw[K] = mcq_ld32_bytes(t + (uint64_t)K * stride);
+    }
+    template <int P>
+    MCQ_HDM void pair(uint32_t, uint32_t &r1, uint32_t &r2) {
+        r1 = mcq_bfe(ow[2 * P], sh, 8);
+        r2 = mcq_bfe(ow[2 * P + 1], sh, 8);
+    }
+    template <int K>
+    MCQ_HDM uint32_t table(uint32_t) { return mcq_bfe(tw[K], sh, 8); }
 };
 
 // ------------------------------------------------------------------------------------------ base deck
@@ -736,7 +774,7 @@ MCQ_HD void mcq_iteration(const McqQueryCtx &qc, Draws &dr, const McqCard *base1
 #define MCQ_OPP(P)                                                                                             \
     if (P < n_opp_d) {                                                                                         \
         uint32_t r1, r2;                                                                                       \
-        dr.pair(L, r1, r2); /* r1 in [0,L-1], r2 in [0,L-2], r1 != r2 (l.167-176), both | 0x80 */              \
+        dr.template pair<P>(L, r1, r2); /* r1 in [0,L-1], r2 in [0,L-2], r1 != r2 (l.167-176), both | 0x80 */  \
         const McqCard c1 = base128[mcq_draw_opp<2 * P>(r1, H)];     /* deck.pop(r1) (l.178) */                 \
         const McqCard c2 = base128[mcq_draw_opp<2 * P + 1>(r2, H)]; /* deck.pop(r2), shrunk list (l.179) */    \
         opp[P].set(c1, c2);                                                                                    \

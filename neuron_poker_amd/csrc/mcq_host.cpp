@@ -140,6 +140,7 @@ int mcq_run_slice(mcq_ctx *c, int mode, const mcq_query *d_q, uint32_t n, mcq_re
     }
     uint32_t grid, block, split, work_wpb;
     pick_geometry(c, mode, total_tasks, &grid, &block, &split, max_tasks, &work_wpb);
+    if (mode == MCQ_MODE_REPLAY_MT19937 && split > 2) split = 2; /* the parity kernel's lanes take four iterations at a time */
     /* queries in HBM (the host has not seen them): up to 1024 of them may be a small batch -- the prep kernel
      * decides the cut and the evaluation kernel reads it; more queries are at least as many tasks: never cut */
     if (total_tasks == 0 && n <= 1024u) split = MCQ_SPLIT_FROM_PREP;

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(kMtBlock) void mcq_mt_parse_kernel(const mcq_query 
             MCQ_WAVE_SYNC(); /* the previous query's reads of this wave's LDS are done */
             mcq_mt_seed(w, seed32 + qi);
             MCQ_WAVE_SYNC();
-            McqMtState st = {MCQ_MT_N, 0u, 0u, 0u, 0u, 0ull};
+            McqMtState st = {MCQ_MT_N, 0u, 0u, 0u, 0ull};
             mcq_mt_parse_query(w, st, 50u - q.n_board(), n_opp, n_deal, runs, draws + draw_off[qi],
                                ((uint64_t)runs + 63u) & ~63ull);
             /* every lane stores the same word: a store under `lane == 0` here would be a divergent branch in front of
@@ -402,13 +402,21 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
                 acc.passes = cnt * qc.n_opp; /* MCQ-CTR v4: one attempt per opponent, never re-drawn */
             }
         } else {
+            /* a lane takes FOUR consecutive iterations at a time (one 32-bit load per draw row, McqReplayDraws4); a task
+             * is four such groups per lane, a sub-task (split <= 2: the host never cuts this mode finer) whole groups */
             const uint64_t stride = (qc.runs + 63u) & ~63ull;
             const uint8_t *dbase = draws + draw_off[qi];
-            for (uint32_t j = (task & sub_mask) * chunk, je = j + chunk; j < je; j++) {
-                const uint64_t it = (uint64_t)(task >> split) * MCQ_TASK_ITERS + j * MCQ_WAVE + lane;
-                if (it < qc.runs) {
-                    McqReplayDraws dr = {dbase + it, stride};
-                    mcq_iteration(qc, dr, base - 128, g_tab->tf, tab.tops, tab.sd, acc);
+            const uint32_t groups = chunk >> 2;
+            for (uint32_t g = (task & sub_mask) * groups, ge = g + groups; g < ge; g++) {
+                const uint64_t it4 = (uint64_t)(task >> split) * MCQ_TASK_ITERS + (g * MCQ_WAVE + lane) * 4u;
+                if (it4 < qc.runs) {
+                    McqReplayDraws4 dr;
+                    dr.load(dbase + it4, stride, qc.n_opp, qc.n_deal);
+                    const uint32_t cnt4 = (uint32_t)min((uint64_t)4u, (uint64_t)qc.runs - it4);
+                    for (uint32_t k = 0; k < cnt4; k++) {
+                        dr.sh = 8u * k;
+                        mcq_iteration(qc, dr, base - 128, g_tab->tf, tab.tops, tab.sd, acc);
+                    }
                 }
             }
             acc.passes = 0; /* `passes` comes from the stream walk: mcq_mt_parse_kernel writes it into the row (the host walk
@@ -1018,6 +1026,7 @@ hipError_t mcq_launch_eval(int mode, const mcq_query *d_q, uint32_t n, const uin
                            const uint64_t *d_draw_off, uint32_t grid, uint32_t block, uint32_t split, uint32_t part,
                            uint32_t n_parts, hipStream_t s, hipEvent_t t0, hipEvent_t t1, uint32_t work_wpb) {
     if ((split > 4 && split != MCQ_SPLIT_FROM_PREP) || n_parts == 0 || part >= n_parts) return hipErrorInvalidValue;
+    if (mode == MCQ_MODE_REPLAY_MT19937 && split > 2) return hipErrorInvalidValue; /* its lanes take four iterations at a time */
 #define MCQ_LAUNCH_EVAL(M)                                                                                          \
     do {                                                                                                            \
         if (split)                                                                                                  \

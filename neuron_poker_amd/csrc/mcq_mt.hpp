@@ -13,11 +13,13 @@
 // position (neighbouring bounds differ by one).  So a wave parses 64 words at a time by fixed-point iteration:
 //   guess every lane's position p  ->  accept bit of every word under its guessed bound  ->  positions again as
 //   p0 + (accepted words before the lane)  ->  repeat until nothing moves.
-// Every round makes at least one more lane final (lane 0 always is), so the result is the sequential parse; four or
-// five rounds are typical.  A pair that has to be drawn again (r1 == r2, one in fifty) ends the batch at its second
-// word: the position rewinds by two, the words behind go back into the stream.  Accepted draws go, as r | 0x80 bytes, to a per-wave ring in LDS laid out like the
-// draw-major global buffer and are flushed 64 iterations at a time with full-row stores; the evaluation kernel
-// (mcq_eval_kernel<MCQ_MODE_REPLAY_MT19937>) consumes that buffer exactly as it consumed the host's.
+// Every round makes at least one more lane final (lane 0 always is), so the result is the sequential parse; three
+// rounds are typical (the first guess takes every word at the query's middle depth).  A pair that has to be drawn
+// again (r1 == r2, one in fifty) ends the batch at its second word: the position rewinds by two, the words behind go
+// back into the stream.  Accepted draws go, as r | 0x80 bytes, to a per-wave ring in LDS laid out like the draw-major
+// global buffer -- where an accepted r2 finds its r1 one row below -- and are flushed 64 iterations at a time with
+// full-row stores; the evaluation kernel (mcq_eval_kernel<MCQ_MODE_REPLAY_MT19937>) consumes that buffer, four
+// iterations per 32-bit load (McqReplayDraws4).
 //
 // One source for two builds: hipcc compiles the MCQ_FOR_LANES regions for ONE lane (the thread), cross-lane steps
 // are wave intrinsics; tests/hostsim compiles the same text with every per-lane variable as a 64-entry array and
@@ -32,6 +34,9 @@
 #define MCQ_MT_M 397u
 #define MCQ_MT_RING 128u   /* iterations the ring holds: < 64 pending + at most 64 from one batch of words */
 #define MCQ_MT_MAX_DRAWS 23u /* 2 * 9 opponents + 5 table cards */
+#define MCQ_MT_POSITIONS 128u /* positions a batch can form: d0 <= 22, + 64 words, rounded up */
+#define MCQ_MT_REGEN(w) mcq_mt_regenerate(w)
+#define MCQ_MT_FLUSH(w, st, D, n, draws, stride) mcq_mt_flush(w, st, D, n, draws, stride)
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define MCQ_PL(T, name) T name                /* a per-lane variable */
@@ -40,6 +45,10 @@
 #define MCQ_AT_UNIFORM(name, idx) ((uint32_t)__builtin_amdgcn_readlane((int)(name), (int)(idx))) /* idx wave-uniform */
 #define MCQ_FOR_LANES(l) for (uint32_t l __attribute__((unused)) = mcq_mt_lane(), once_ = 1; once_; once_ = 0)
 #define MCQ_BALLOT(name) __ballot(name)
+#define MCQ_BALLOT_K(name, k) __ballot(name[k])
+#define MCQ_KEEP2(a, b) ({ asm volatile("" : "+v"(a), "+v"(b)); })
+#define MCQ_BALLOT_OF(l, expr) __ballot(expr) /* ballot of an expression of the lane's values */
+#define MCQ_LANE_OF(m, l) mcq_mt_lane_of(m)    /* is this lane's bit set in the wave mask m? */
 /* number of set bits of the wave mask m below this lane */
 #define MCQ_COUNT_BELOW(m, l) __builtin_amdgcn_mbcnt_hi((uint32_t)((m) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(m), 0u))
 #define MCQ_WAVE_SYNC()                                                  \
@@ -47,6 +56,21 @@
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");           \
         __builtin_amdgcn_wave_barrier();                                 \
     } while (0)
+/* positions travel as the LDS byte address of their etab entry (device) / as the index itself (host): the base rides
+ * in the accumulate operand of v_mbcnt, so a round needs no address arithmetic */
+typedef __attribute__((address_space(3))) const uint8_t *McqLdsU8;
+typedef __attribute__((address_space(3))) const uint32_t *McqLdsU32;
+#define MCQ_POS_BASE(w) ((uint32_t)(uintptr_t)(McqLdsU8)((w).etab))
+#define MCQ_ETAB_AT(w, pa) (*(McqLdsU8)(uintptr_t)(pa))
+#define MCQ_QTAB_AT(w, pa) (*(McqLdsU8)(uintptr_t)((pa) + MCQ_MT_POSITIONS))
+#define MCQ_RTAB_AT(w, pa) (*(McqLdsU8)(uintptr_t)((pa) + 2u * MCQ_MT_POSITIONS))
+#define MCQ_COUNT_BELOW_FROM(m, l, base) __builtin_amdgcn_mbcnt_hi((uint32_t)((m) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(m), (base)))
+/* bit `lane` of a wave mask as a per-lane condition: v_cmp of mbcnt difference would cost more than the mask AND the
+ * compiler makes of this */
+__device__ __forceinline__ bool mcq_mt_lane_of(uint64_t m) {
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    return ((m >> lane) & 1u) != 0u;
+}
 __device__ __forceinline__ uint32_t mcq_mt_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 __device__ __forceinline__ uint32_t mcq_mt_shfl(uint32_t v, uint32_t idx) {
     return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(idx << 2), (int)v);
@@ -58,8 +82,17 @@ __device__ __forceinline__ uint32_t mcq_mt_shfl(uint32_t v, uint32_t idx) {
 #define MCQ_AT_UNIFORM(name, idx) name[(idx) & 63u]
 #define MCQ_FOR_LANES(l) for (uint32_t l_ = 0, l __attribute__((unused)) = 0; l_ < 64u; l_++, l = l_)
 #define MCQ_BALLOT(name) mcq_mt_host_ballot(name)
+#define MCQ_BALLOT_K(name, k) mcq_mt_host_ballot_k(name, k)
+#define MCQ_KEEP2(a, b) ((void)0)
+#define MCQ_BALLOT_OF(l, expr) ({ uint64_t m_ = 0; for (uint32_t l_ = 0, l __attribute__((unused)) = 0; l_ < 64u; l_++, l = l_) m_ |= (uint64_t)((expr) ? 1u : 0u) << l_; m_; })
+#define MCQ_LANE_OF(m, l) ((((m) >> (l)) & 1u) != 0u)
 #define MCQ_COUNT_BELOW(m, l) mcq_mt_popc64((m) & (((uint64_t)1 << (l)) - 1u))
 #define MCQ_WAVE_SYNC() ((void)0)
+#define MCQ_POS_BASE(w) 0u
+#define MCQ_ETAB_AT(w, pa) ((w).etab[pa])
+#define MCQ_QTAB_AT(w, pa) ((w).qtab[pa])
+#define MCQ_RTAB_AT(w, pa) ((w).rtab[pa])
+#define MCQ_COUNT_BELOW_FROM(m, l, base) ((base) + MCQ_COUNT_BELOW(m, l))
 template <class T>
 static inline uint64_t mcq_mt_host_ballot(const T (&a)[64]) {
     uint64_t m = 0;
@@ -69,16 +102,21 @@ static inline uint64_t mcq_mt_host_ballot(const T (&a)[64]) {
     }
     return m;
 }
+template <class T, size_t N>
+static inline uint64_t mcq_mt_host_ballot_k(const T (&a)[64][N], uint32_t k) {
+    uint64_t m = 0;
+    for (uint32_t i = 0; i < 64; i++) {
+        const uint64_t bit = a[i][k] ? 1u : 0u;
+        m |= bit << i;
+    }
+    return m;
+}
 #endif
 
-MCQ_HD uint32_t mcq_mt_popc64(uint64_t x) { return mcq_popc((uint32_t)x) + mcq_popc((uint32_t)(x >> 32)); }
-MCQ_HD uint32_t mcq_mt_top64(uint64_t x) { /* index of the highest set bit, x != 0 */
-    const uint32_t hi = (uint32_t)(x >> 32);
-    return hi ? 63u - mcq_clz(hi) : 31u - mcq_clz((uint32_t)x);
-}
-MCQ_HD uint32_t mcq_mt_low64(uint64_t x) { /* index of the lowest set bit, x != 0 */
-    return mcq_mt_top64(x & (0 - x));
-}
+/* (device: the arguments are wave-uniform masks -- one scalar instruction each) */
+MCQ_HD uint32_t mcq_mt_popc64(uint64_t x) { return (uint32_t)__builtin_popcountll(x); }
+MCQ_HD uint32_t mcq_mt_top64(uint64_t x) { return 63u - (uint32_t)__builtin_clzll(x); } /* index of the highest set bit, x != 0 */
+MCQ_HD uint32_t mcq_mt_low64(uint64_t x) { return (uint32_t)__builtin_ctzll(x); }        /* index of the lowest set bit, x != 0 */
 
 MCQ_HD uint32_t mcq_mt_twist(uint32_t u, uint32_t v) {
     const uint32_t y = (u & 0x80000000u) | (v & 0x7fffffffu);
@@ -92,31 +130,31 @@ MCQ_HD uint32_t mcq_mt_temper(uint32_t y) {
 }
 
 // Draw number d (0-based within an iteration) of a query with deck length L0 = 50 - n_board, n_opp opponents:
-// bound n of its randint(0, n), packed as rng (= n - 1) | is_r2 << 8 | mask << 16.  rng >= 26 for every legal query
-// (ten players on a flop leave 27 cards for the last table draw), so randint's "rng == 0 consumes nothing" case
-// cannot occur and every attempt is exactly one word.
-MCQ_HD uint32_t mcq_mt_draw_entry(uint32_t L0, uint32_t n_opp, uint32_t d) {
-    uint32_t n, r2 = 0;
-    if (d < 2u * n_opp) {
-        n = L0 - 2u * (d >> 1) - (d & 1u); /* r1: randint(0, L), r2: randint(0, L - 1) (l.169-170) */
-        r2 = d & 1u;
-    } else {
-        n = L0 - 2u * n_opp - (d - 2u * n_opp) - 1u; /* randint(0, len(deck) - 1) (l.188) */
-    }
-    const uint32_t rng = n - 1u;
-    const uint32_t mask = 0xFFFFFFFFu >> mcq_clz(rng | 1u);
-    return rng | (r2 << 8) | (mask << 16);
-}
+// the bound n of its randint(0, n) is L0 - e - 1 + 1 with the EFFECTIVE DEPTH e = d + [d >= 2 n_opp]
+//   r1: randint(0, L), r2: randint(0, L - 1) (l.169-170): n = L0 - d;  table: randint(0, len(deck) - 1) (l.188): n = L0 - d - 1
+// so rng = n - 1 = L0 - 1 - e, strictly falling with d.  rng >= 26 for every legal query (ten players on a flop leave
+// 27 cards for the last table draw), so randint's "rng == 0 consumes nothing" case cannot occur and every attempt is
+// exactly one word; the mask is 63 while rng >= 32 (e <= L0 - 33) and 31 behind that ("zone 31": only with eight or
+// nine opponents).  A word with low bits y63 = y & 63 is therefore accepted at depth e of zone 63 iff e <= L0 - 1 - y63.
+MCQ_HD uint32_t mcq_mt_depth(uint32_t n_opp, uint32_t d) { return d + (d >= 2u * n_opp ? 1u : 0u); }
 
-// floor(p / D) for p < 128, 1 <= D <= 23, as (p * magic) >> 16 (checked exhaustively in the tests)
+// floor(p / D) for p < MCQ_MT_POSITIONS, 1 <= D <= 23, as (p * magic) >> 16 (checked exhaustively in the tests)
 MCQ_HD uint32_t mcq_mt_magic(uint32_t D) { return 65536u / D + 1u; }
 
 // Per-wave working set (device: LDS).
+#define MCQ_MT_ZONE31 0x80u
 struct McqMtWave {
-    uint32_t mt[MCQ_MT_N];
-    uint32_t entry[24];                             /* mcq_mt_draw_entry per draw */
-    uint8_t ring[MCQ_MT_MAX_DRAWS * MCQ_MT_RING];   /* ring[d * 128 + (iteration & 127)] = r | 0x80 */
-    uint8_t pad_[16];
+    uint32_t mt[MCQ_MT_N + 64u]; /* + 64: a batch reads 64 words from its position, the ones past the block unused */
+    /* by position p = (draws of the current iteration already accepted) + (accepted words of the batch before the lane),
+     * p < MCQ_MT_POSITIONS, three byte planes read with ONE address register (a round asks for all three: when the
+     * positions have settled, what the write-out needs has arrived with the last round's answer):
+     *   etab[p]  the effective depth e of draw d = p mod D, | MCQ_MT_ZONE31 in zone 31
+     *   qtab[p]  the iteration offset p / D
+     *   rtab[p]  d, | 0x80 for an r2 */
+    uint8_t etab[MCQ_MT_POSITIONS], qtab[MCQ_MT_POSITIONS], rtab[MCQ_MT_POSITIONS];
+    /* ring[(d + 1) * 128 + (iteration & 127)] = r | 0x80; row 0 is spare: the partner of draw d -- the r1 an r2 is
+     * compared with -- sits one row below it, and the address must exist for d = 0 */
+    uint8_t ring[(MCQ_MT_MAX_DRAWS + 1u) * MCQ_MT_RING];
 };
 
 // np.random.seed(s): init_genrand.  A serial recurrence: every lane computes it (wave-uniform, scalar ALU on the
@@ -132,32 +170,39 @@ MCQ_HD void mcq_mt_seed(W &w, uint32_t s) {
 }
 
 // The next 624 state words.  new[k] needs old[k], old[k+1] and [k+397]: old for k < 227, else new[k-227] -- three
-// sweeps of at most 227 independent elements each, 64 lanes at a time.  Within a 64-element step every lane
-// reads before any lane writes (a wave executes in lockstep), and a step only reads elements of later steps.
+// sweeps of at most 227 independent elements each.  A sweep reads ALL its operands (four steps of 64 lanes, twelve LDS
+// reads in flight) before it writes any of its results: one round trip to LDS per sweep instead of one per step, and
+// within a sweep no element is read after it has been written (a sweep only reads its own range, the word behind it
+// and ranges of other sweeps).
 template <class W>
-MCQ_HD void mcq_mt_regenerate(W &w) {
-    for (uint32_t base = 0; base < MCQ_MT_N; base += 64u) {
-        /* steps must not straddle the sweep boundaries 227 and 454 (a lane would read a word an earlier lane of
-         * the same step has yet to write), nor 623 */
-        uint32_t lim = base < 227u ? 227u : base < 454u ? 454u : 623u;
-        if (lim > base + 64u) lim = base + 64u;
-        MCQ_PL(uint32_t, nv);
-        MCQ_FOR_LANES(l) {
-            const uint32_t k = base + l;
-            MCQ_L(nv) = 0;
+MCQ_HD void mcq_mt_regen_sweep(W &w, uint32_t first, uint32_t lim) {
+    MCQ_PL(uint32_t, nv)[4];
+    MCQ_FOR_LANES(l) {
+#pragma unroll
+        for (uint32_t s = 0; s < 4u; s++) {
+            const uint32_t k = first + 64u * s + l;
+            MCQ_L(nv)[s] = 0;
             if (k < lim) {
                 const uint32_t far = k < 227u ? k + MCQ_MT_M : k - 227u;
-                MCQ_L(nv) = w.mt[far] ^ mcq_mt_twist(w.mt[k], w.mt[k + 1u]);
+                MCQ_L(nv)[s] = w.mt[far] ^ mcq_mt_twist(w.mt[k], w.mt[k + 1u]);
             }
         }
-        MCQ_WAVE_SYNC();
-        MCQ_FOR_LANES(l) {
-            const uint32_t k = base + l;
-            if (k < lim) w.mt[k] = MCQ_L(nv);
-        }
-        MCQ_WAVE_SYNC();
-        if (lim < base + 64u && lim < 623u) base = lim - 64u; /* next step starts at the sweep boundary */
     }
+    MCQ_WAVE_SYNC();
+    MCQ_FOR_LANES(l) {
+#pragma unroll
+        for (uint32_t s = 0; s < 4u; s++) {
+            const uint32_t k = first + 64u * s + l;
+            if (k < lim) w.mt[k] = MCQ_L(nv)[s];
+        }
+    }
+    MCQ_WAVE_SYNC();
+}
+template <class W>
+MCQ_HD void mcq_mt_regenerate(W &w) {
+    mcq_mt_regen_sweep(w, 0u, 227u);
+    mcq_mt_regen_sweep(w, 227u, 454u);
+    mcq_mt_regen_sweep(w, 454u, 623u);
     MCQ_FOR_LANES(l) {
         if (l == 0) w.mt[623] = w.mt[396] ^ mcq_mt_twist(w.mt[623], w.mt[0]);
     }
@@ -168,7 +213,6 @@ struct McqMtState { /* wave-uniform */
     uint32_t pos;     /* next unread state word, 624 = regenerate first */
     uint32_t it_done; /* complete iterations parsed */
     uint32_t d0;      /* draws of the current iteration already accepted */
-    uint32_t v_last;  /* value of the latest accepted word (the r1 an r2 is compared with) */
     uint32_t flushed; /* iterations already written to the global buffer */
     uint64_t passes;
 };
@@ -182,7 +226,7 @@ MCQ_HD void mcq_mt_flush(W &w, McqMtState &st, uint32_t D, uint32_t count, uint8
         MCQ_FOR_LANES(l) {
             const uint32_t d = d4 + (l >> 4), c4 = (l & 15u) * 4u;
             if (d < D && c4 < count) {
-                const uint32_t v = *reinterpret_cast<const uint32_t *>(&w.ring[d * MCQ_MT_RING + ((first + c4) & (MCQ_MT_RING - 1u))]);
+                const uint32_t v = *reinterpret_cast<const uint32_t *>(&w.ring[(d + 1u) * MCQ_MT_RING + ((first + c4) & (MCQ_MT_RING - 1u))]);
                 *reinterpret_cast<uint32_t *>(draws + (uint64_t)d * stride + first + c4) = v;
             }
         }
@@ -191,102 +235,152 @@ MCQ_HD void mcq_mt_flush(W &w, McqMtState &st, uint32_t D, uint32_t count, uint8
     st.flushed += count;
 }
 
+// One batch of up to 64 words.  How a batch is parsed:
+//   1. the lanes' words are tempered; E = L0 - 1 - (y & mask) is the deepest position the word is accepted at;
+//   2. positions: first guess from the words accepted at the query's MIDDLE depth, then rounds of
+//      (depth of my position, from etab) -> (accept bits) -> (position = d0 + accepted words before me) until nothing
+//      moves -- lane 0 is always final and every round makes at least one more lane final, so the fixed point is the
+//      sequential parse as if no pair were ever drawn again;
+//   3. every accepted word goes to the ring; an accepted r2 then looks one row down for its r1 (written by this batch or
+//      an earlier one): r1 == r2 means the pair is drawn again (l.171-176, one pair in fifty).  The parse is right up to
+//      and including the FIRST such word; the batch ends there (the words behind it go back into the stream; what they
+//      wrote to the ring lies beyond every final position and is overwritten when those positions are parsed again),
+//      the position rewinds by the pair, whose two slots the pair drawn again will fill.
+// TWO_ZONE: the query reaches zone 31 (wave-uniform); TAIL: the batch may reach the query's last iteration -- words past
+// it stay unread.
+// Measured on gfx950 (tools/mt_bench): with one wave per query and 4 096 queries a CU holds 16 waves, and this loop is
+// bound by INSTRUCTION ISSUE -- of the scalar unit (one instruction per cycle per CU, shared by the 16 waves) as much
+// as of the vector units -- so it is written for instruction count: positions carry their LDS address (no address
+// arithmetic in a round), masks stay in scalar registers from the compare that made them, the bookkeeping between two
+// batches is a dozen scalar instructions.  (Two words per lane, or taking a re-drawn pair out of the batch in place
+// instead of ending the batch, both cost more instructions than they save: 12.5 / 12.8 ms against 9.5 ms on BASELINE
+// configs[2].)
+struct McqMtPlan { /* wave-uniform constants of a query */
+    uint32_t D, magic, runs;
+    uint32_t k_e;   /* L0 - 1 + 0x80: E = k_e - ((y & mask) | 0x80) */
+    uint32_t e_mid; /* depth of the middle draw: the first guess */
+};
+
+template <bool TWO_ZONE, bool TAIL, class W>
+MCQ_HD void mcq_mt_batch(W &w, McqMtState &st, const McqMtPlan &pl) {
+    const uint32_t rem = MCQ_MT_N - st.pos; /* state words left: lanes from there on hold no word */
+    const uint32_t pos0 = MCQ_POS_BASE(w) + st.d0;
+    const uint32_t p_lim = pos0 - st.d0 + (pl.runs - st.it_done) * pl.D; /* TAIL: positions from here on lie past the last iteration */
+#ifdef MCQ_MT_STATS
+    g_batches++;
+#endif
+    MCQ_PL(uint32_t, yb);  /* (y & 63) | 0x80: the byte an accepted word of zone 63 leaves */
+    MCQ_PL(int32_t, E63);
+    MCQ_PL(int32_t, E31);
+    MCQ_PL(uint32_t, pa);  /* position + pos0 */
+    MCQ_PL(uint32_t, base); /* pos0 in a vector register: the accumulate operand of the counts */
+    MCQ_PL(uint32_t, e8);
+    MCQ_PL(uint32_t, q8);
+    MCQ_PL(uint32_t, r8);
+    MCQ_FOR_LANES(l) {
+        const uint32_t y = mcq_mt_temper(w.mt[st.pos + l]); /* (mt is padded: lanes behind the block read words nobody uses) */
+        MCQ_L(base) = mcq_opaque(pos0);
+        MCQ_L(yb) = (y & 63u) | 0x80u;
+        MCQ_L(E63) = l < rem ? (int32_t)(pl.k_e - MCQ_L(yb)) : -1; /* never accepted */
+        if (TWO_ZONE) MCQ_L(E31) = l < rem ? (int32_t)(pl.k_e - ((y & 31u) | 0x80u)) : -1;
+    }
+    uint64_t M = MCQ_BALLOT_OF(l, MCQ_L(E63) >= (int32_t)pl.e_mid);
+    MCQ_FOR_LANES(l) { MCQ_L(pa) = MCQ_COUNT_BELOW_FROM(M, l, MCQ_L(base)); }
+    /* accept bits of the lanes at positions P; TWO_ZONE: etab's bit 7 picks the zone */
+#define MCQ_MT_ACCEPT_E8(P)                                                                                       \
+    ((TWO_ZONE ? (int32_t)(MCQ_L(e8) & 63u) <= ((MCQ_L(e8) & MCQ_MT_ZONE31) ? MCQ_L(E31) : MCQ_L(E63))            \
+               : (int32_t)MCQ_L(e8) <= MCQ_L(E63)) &&                                                              \
+     (!TAIL || MCQ_L(P) < p_lim))
+#define MCQ_MT_ACCEPT(P)                                                                                          \
+    (MCQ_L(e8) = MCQ_ETAB_AT(w, MCQ_L(P)), MCQ_L(q8) = MCQ_QTAB_AT(w, MCQ_L(P)), MCQ_L(r8) = MCQ_RTAB_AT(w, MCQ_L(P)),  \
+     MCQ_KEEP2(MCQ_L(q8), MCQ_L(r8)), /* (asked for in EVERY round, not once more behind the loop) */                  \
+     MCQ_MT_ACCEPT_E8(P))
+    for (;;) { /* settled when a round answers with the accept bits it was asked with (a scalar compare) */
+        const uint64_t M1 = MCQ_BALLOT_OF(l, MCQ_MT_ACCEPT(pa));
+#ifdef MCQ_MT_STATS
+        g_rounds++;
+#endif
+        if (M1 == M) break;
+        M = M1;
+        MCQ_FOR_LANES(l) { MCQ_L(pa) = MCQ_COUNT_BELOW_FROM(M, l, MCQ_L(base)); }
+    }
+    /* write-out: every lane computes its slot (q8, r8 are those of the final positions), the accepted ones store; then
+     * every lane asks for its partner row, and while that answer travels the wave does the bookkeeping of the usual
+     * case -- no pair drawn again */
+    MCQ_PL(uint32_t, at); /* ring address of the word's partner row = its own row - 128 */
+    MCQ_PL(uint32_t, v);
+    MCQ_PL(uint32_t, pv);
+    MCQ_FOR_LANES(l) {
+        MCQ_L(at) = ((MCQ_L(r8) & 0x7Fu) << 7) | ((st.it_done + MCQ_L(q8)) & (MCQ_MT_RING - 1u));
+        MCQ_L(v) = TWO_ZONE && (MCQ_L(e8) & MCQ_MT_ZONE31) ? (MCQ_L(yb) & 0x9Fu) : MCQ_L(yb);
+        /* the accepted lanes (the compare again: cheaper than turning the mask M back into a lane condition; e8 and pa are
+         * those of the final round) -- lanes behind a re-drawn pair too: see above */
+        if (MCQ_MT_ACCEPT_E8(pa)) w.ring[MCQ_L(at) + MCQ_MT_RING] = (uint8_t)MCQ_L(v);
+    }
+    MCQ_WAVE_SYNC();
+    MCQ_FOR_LANES(l) { MCQ_L(pv) = w.ring[MCQ_L(at)]; }
+    const uint64_t R2 = MCQ_BALLOT_OF(l, MCQ_L(r8) >= 0x80u) & M;
+    uint32_t used = rem < 64u ? rem : 64u;
+    uint32_t n_r2 = mcq_opaque_uniform(mcq_mt_popc64(R2)), p_end = mcq_opaque_uniform(st.d0 + mcq_mt_popc64(M)); /* (here, not behind the wait) */
+    const uint64_t R = MCQ_BALLOT_OF(l, MCQ_L(pv) == MCQ_L(v)) & R2;
+    if (R) { /* one batch in five */
+        const uint32_t j = mcq_mt_low64(R);
+        used = j + 1u;
+        M &= ((uint64_t)2 << j) - 1u;
+        n_r2 = mcq_mt_popc64(R2 & M);
+        p_end = st.d0 + mcq_mt_popc64(M) - 2u;
+    }
+    st.passes += n_r2; /* one accepted r2 per attempt (l.168) */
+    const uint32_t it_add = (p_end * pl.magic) >> 16;
+    st.d0 = p_end - it_add * pl.D;
+    st.it_done += it_add;
+    /* words consumed: up to the re-drawn pair, else all of them -- unless the stream of this query ends here (the last
+     * iteration is complete): then up to the last accepted word */
+    if (TAIL && !R && st.it_done >= pl.runs) used = M ? mcq_mt_top64(M) + 1u : 0u;
+    st.pos += used;
+    MCQ_WAVE_SYNC();
+#undef MCQ_MT_ACCEPT
+#undef MCQ_MT_ACCEPT_E8
+}
+
 // Parse the whole stream of one query: `runs` iterations of D = 2 * n_opp + n_deal draws (D >= 1).  The wave's MT
 // state must be seeded (st.pos = 624).  draws: this query's block of the global buffer, stride = runs rounded up to
 // 64 (rows may be written up to the stride).  Returns passes in st.passes.
+template <bool TWO_ZONE, class W>
+MCQ_HD void mcq_mt_parse_loop(W &w, McqMtState &st, const McqMtPlan &pl, uint8_t *draws, uint64_t stride) {
+    /* a batch advances by at most (22 + 64) / D iterations: before it_tail no batch can reach the last one */
+    const uint32_t reach = ((22u + 64u) * pl.magic >> 16) + 1u, it_tail = pl.runs > reach ? pl.runs - reach : 0u;
+#define MCQ_MT_STEP(TAIL_)                                                                       \
+    do {                                                                                         \
+        if (st.pos >= MCQ_MT_N) {                                                                \
+            MCQ_MT_REGEN(w);                                                                     \
+            st.pos = 0;                                                                          \
+        }                                                                                        \
+        mcq_mt_batch<TWO_ZONE, TAIL_>(w, st, pl);                                                \
+        while (st.it_done - st.flushed >= 64u) MCQ_MT_FLUSH(w, st, pl.D, 64u, draws, stride);    \
+    } while (0)
+    while (st.it_done < it_tail) MCQ_MT_STEP(false);
+    while (st.it_done < pl.runs) MCQ_MT_STEP(true);
+#undef MCQ_MT_STEP
+    if (st.it_done > st.flushed) mcq_mt_flush(w, st, pl.D, st.it_done - st.flushed, draws, stride);
+}
+
 template <class W>
 MCQ_HD void mcq_mt_parse_query(W &w, McqMtState &st, uint32_t L0, uint32_t n_opp, uint32_t n_deal, uint32_t runs,
                                uint8_t *draws, uint64_t stride) {
     const uint32_t D = 2u * n_opp + n_deal, magic = mcq_mt_magic(D);
+    const uint32_t z_max = L0 - 33u; /* deepest position of zone 63 */
+    const bool two_zone = mcq_mt_depth(n_opp, D - 1u) > z_max;
+    const McqMtPlan pl = {D, magic, runs, L0 - 1u + 0x80u, mcq_mt_depth(n_opp, D >> 1)};
     MCQ_FOR_LANES(l) {
-        if (l < D) w.entry[l] = mcq_mt_draw_entry(L0, n_opp, l);
+        for (uint32_t pp = l; pp < MCQ_MT_POSITIONS; pp += 64u) {
+            const uint32_t q = (pp * magic) >> 16, d = pp - q * D, e = mcq_mt_depth(n_opp, d);
+            w.etab[pp] = (uint8_t)(e | (e > z_max ? MCQ_MT_ZONE31 : 0u));
+            w.qtab[pp] = (uint8_t)q;
+            w.rtab[pp] = (uint8_t)(d | ((d < 2u * n_opp && (d & 1u)) ? 0x80u : 0u));
+        }
     }
     MCQ_WAVE_SYNC();
-    while (st.it_done < runs) {
-        if (st.pos >= MCQ_MT_N) {
-            mcq_mt_regenerate(w);
-            st.pos = 0;
-        }
-        const uint32_t cnt = MCQ_MT_N - st.pos < 64u ? MCQ_MT_N - st.pos : 64u;
-        const uint32_t left = runs - st.it_done; /* >= 1: iterations still to parse */
-#ifdef MCQ_MT_STATS
-        g_batches++;
-#endif
-        MCQ_PL(uint32_t, y);
-        MCQ_PL(uint32_t, p);
-        MCQ_FOR_LANES(l) {
-            MCQ_L(y) = l < cnt ? mcq_mt_temper(w.mt[st.pos + l]) : 0u;
-            MCQ_L(p) = st.d0 + ((l * 44u) >> 6); /* first guess: about two words in three are accepted */
-        }
-        MCQ_PL(uint32_t, v);
-        MCQ_PL(uint32_t, dd);
-        MCQ_PL(uint32_t, itr);
-        MCQ_PL(bool, acc);
-        MCQ_PL(bool, isr2);
-        uint64_t M = 0;
-        for (;;) { /* positions of the words as if no pair were ever drawn again (that is settled afterwards) */
-            MCQ_FOR_LANES(l) {
-                const uint32_t q = (MCQ_L(p) * magic) >> 16;
-                const uint32_t d = MCQ_L(p) - q * D;
-                const uint32_t e = w.entry[d];
-                MCQ_L(itr) = q;
-                MCQ_L(dd) = d;
-                MCQ_L(v) = MCQ_L(y) & (e >> 16);
-                MCQ_L(isr2) = (e & 0x100u) != 0u;
-                MCQ_L(acc) = l < cnt && MCQ_L(v) <= (e & 0xFFu) && q < left; /* words past the last iteration stay unread */
-            }
-            M = MCQ_BALLOT(acc);
-            MCQ_PL(bool, moved);
-            MCQ_FOR_LANES(l) {
-                const uint32_t pn = st.d0 + MCQ_COUNT_BELOW(M, l);
-                MCQ_L(moved) = pn != MCQ_L(p);
-                MCQ_L(p) = pn;
-            }
-#ifdef MCQ_MT_STATS
-            g_rounds++;
-#endif
-            if (MCQ_BALLOT(moved) == 0) break;
-        }
-        /* r1 == r2: the pair is drawn again (l.171-176) -- about one pair in fifty.  The parse is right up to and
-         * including the first such word; the batch ends there (the words behind it go back), the position rewinds by
-         * the pair, and the two draws of the pair are dropped: their slots are written by the pair drawn again. */
-        MCQ_PL(uint32_t, prev_ix);
-        MCQ_FOR_LANES(l) {
-            const uint64_t below = M & (((uint64_t)1 << l) - 1u);
-            MCQ_L(prev_ix) = below ? mcq_mt_top64(below) : 64u;
-        }
-        MCQ_PL(bool, red);
-        MCQ_FOR_LANES(l) {
-            const uint32_t sv = MCQ_AT(v, MCQ_L(prev_ix)); /* unconditional: every lane takes part in the exchange */
-            const uint32_t vp = MCQ_L(prev_ix) < 64u ? sv : st.v_last;
-            MCQ_L(red) = MCQ_L(acc) && MCQ_L(isr2) && MCQ_L(v) == vp;
-        }
-        const uint64_t R = MCQ_BALLOT(red);
-        uint32_t used = cnt, rewind = 0, drop_a = 64u, drop_b = 64u; /* words of the batch that count; lanes dropped */
-        if (R) {
-            drop_b = mcq_mt_low64(R);
-            drop_a = MCQ_AT_UNIFORM(prev_ix, drop_b);
-            used = drop_b + 1u;
-            rewind = 2u;
-            M &= ((uint64_t)2 << drop_b) - 1u;
-        }
-        MCQ_FOR_LANES(l) {
-            if (MCQ_L(acc) && l < used && l != drop_a && l != drop_b)
-                w.ring[MCQ_L(dd) * MCQ_MT_RING + ((st.it_done + MCQ_L(itr)) & (MCQ_MT_RING - 1u))] = (uint8_t)(MCQ_L(v) | 0x80u);
-        }
-        MCQ_PL(bool, pass);
-        MCQ_FOR_LANES(l) { MCQ_L(pass) = MCQ_L(acc) && MCQ_L(isr2) && l < used; } /* one accepted r2 per attempt (l.168) */
-        st.passes += mcq_mt_popc64(MCQ_BALLOT(pass));
-        const uint32_t p_end = st.d0 + mcq_mt_popc64(M) - rewind;
-        const uint32_t it_add = (p_end * magic) >> 16;
-        st.d0 = p_end - it_add * D;
-        st.it_done += it_add;
-        if (M) st.v_last = MCQ_AT_UNIFORM(v, mcq_mt_top64(M));
-        /* words consumed: up to the re-drawn pair, else everything up to the last accepted word and the rejected words
-         * behind it unless the stream of this query ends there (the last iteration is complete) */
-        st.pos += R ? used : (st.it_done < runs ? cnt : (M ? mcq_mt_top64(M) + 1u : 0u));
-        MCQ_WAVE_SYNC();
-        while (st.it_done - st.flushed >= 64u) mcq_mt_flush(w, st, D, 64u, draws, stride);
-    }
-    if (st.it_done > st.flushed) mcq_mt_flush(w, st, D, st.it_done - st.flushed, draws, stride);
+    if (two_zone) mcq_mt_parse_loop<true>(w, st, pl, draws, stride);
+    else mcq_mt_parse_loop<false>(w, st, pl, draws, stride);
 }

@@ -117,14 +117,19 @@ int hs_run_replay(const mcq_query *q, uint32_t seed32, mcq_result *out) {
     memset(out, 0, sizeof(*out));
     out->runs = q->runs;
     size_t stride = q->runs ? q->runs : 1;
-    std::vector<uint8_t> draws((size_t)mcq_draws_per_iteration(*q) * stride + 1);
+    std::vector<uint8_t> draws((size_t)mcq_draws_per_iteration(*q) * stride + 4);
     out->passes = mcq_replay_parse(*q, seed32, draws.data(), stride);
-    for (uint32_t it = 0; it < q->runs; it++) {
-        McqReplayDraws dr = {draws.data() + it, stride};
-        McqLaneAcc acc = {0, 0, 0};
-        mcq_iteration(qc, dr, base, t.tf, t.tops, t.sd, acc);
-        acc.passes = 0;
-        fold(acc, out);
+    /* as the kernel reads them: four iterations per 32-bit load of every draw row (McqReplayDraws4) */
+    for (uint32_t it4 = 0; it4 < q->runs; it4 += 4) {
+        McqReplayDraws4 dr;
+        dr.load(draws.data() + it4, stride, qc.n_opp, qc.n_deal);
+        for (uint32_t k = 0; k < 4 && it4 + k < q->runs; k++) {
+            dr.sh = 8u * k;
+            McqLaneAcc acc = {0, 0, 0};
+            mcq_iteration(qc, dr, base, t.tf, t.tops, t.sd, acc);
+            acc.passes = 0;
+            fold(acc, out);
+        }
     }
     return MCQ_OK;
 }
@@ -280,7 +285,7 @@ extern "C" uint64_t hs_mt_parse(const mcq_query *q, uint32_t seed32, uint8_t *dr
     const uint32_t n_opp = q->n_players - 1u, n_deal = 5u - q->n_board;
     if (2u * n_opp + n_deal == 0u || q->runs == 0u) return 0;
     mcq_mt_seed(w, seed32);
-    McqMtState st = {MCQ_MT_N, 0, 0, 0, 0, 0};
+    McqMtState st = {MCQ_MT_N, 0, 0, 0, 0};
     mcq_mt_parse_query(w, st, 50u - q->n_board, n_opp, n_deal, q->runs, draws, stride);
     return st.passes;
 }
@@ -298,7 +303,7 @@ extern "C" void hs_mt_regenerate_words(uint32_t seed32, uint32_t n, uint32_t *ou
 }
 extern "C" uint32_t hs_mt_magic_ok(void) { /* (p * magic) >> 16 == p / D for every p the parse can form */
     for (uint32_t D = 1; D <= MCQ_MT_MAX_DRAWS; D++)
-        for (uint32_t p = 0; p < 128u; p++)
+        for (uint32_t p = 0; p < MCQ_MT_POSITIONS; p++)
             if (((p * mcq_mt_magic(D)) >> 16) != p / D) return 0;
     return 1;
 }
