@@ -770,72 +770,55 @@ int mcq_eval_batch_ext(mcq_ctx *c, const mcq_query *q, const mcq_query_ext *ext,
     HIP_TRY(hipMemcpyAsync(c->d_ext.p, hq + n * sizeof(mcq_query), n * sizeof(mcq_query_ext), hipMemcpyHostToDevice,
                            c->stream));
     c->last_ms = 0.f;
-    std::vector<uint64_t> passes;
     uint32_t grid, block;
     pick_geometry(c, mode, total_tasks, &grid, &block);
-    if (mode == MCQ_MODE_REPLAY_MT19937) { /* one chunk: the extended path is a feature path, not a bulk path */
-        passes.assign(n, 0);
-        std::vector<uint64_t> off(n);
-        uint64_t bytes = 0;
+    if (mode == MCQ_MODE_REPLAY_MT19937) {
+        /* the draw buffer the stream walk fills and the evaluation kernel reads (one chunk: the extended path is a
+         * feature path, not a bulk path); the walk itself runs on the device: mcq_mt_parse_ext_kernel, one wave per query */
+        HIP_TRY(c->h_off.reserve(n * sizeof(uint64_t)));
+        uint64_t *off = (uint64_t *)c->h_off.p, bytes = 0;
         for (size_t i = 0; i < n; i++) {
             off[i] = bytes;
             bytes += (((uint64_t)q[i].runs + 63u) & ~63ull) * mcq_ext_draws_per_iteration(q[i], ext[i]);
         }
-        if (bytes > (1ull << 31)) return mcq_fail(MCQ_EINVAL, "mcq_eval_batch_ext: replay batch too large (split it)");
-        HIP_TRY(c->h_draws.reserve(bytes + 64));
+        if (bytes > (1ull << 32)) return mcq_fail(MCQ_EINVAL, "mcq_eval_batch_ext: replay batch too large (split it)");
         HIP_TRY(c->d_draws.reserve(bytes + 64));
         HIP_TRY(c->d_off.reserve(n * sizeof(uint64_t)));
-        HIP_TRY(c->h_off.reserve(n * sizeof(uint64_t)));
-        memcpy(c->h_off.p, off.data(), n * sizeof(uint64_t));
-        uint8_t *hd = (uint8_t *)c->h_draws.p;
-        std::atomic<size_t> next(0);
-        std::atomic<int> bad(0);
-        unsigned hw = std::thread::hardware_concurrency();
-        size_t nt = hw ? hw : 4;
-        if (nt > 32) nt = 32;
-        if (nt > n) nt = n;
-        auto work = [&]() {
-            for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
-                McqMt19937 g;
-                g.seed((uint32_t)(seed + first_query_id + i));
-                uint64_t stride = ((uint64_t)q[i].runs + 63u) & ~63ull;
-                passes[i] = mcq_replay_parse_ext(q[i], ext[i], g, hd + off[i], stride, 1000000u);
-                if (passes[i] == ~0ull) bad.store(1);
-            }
-        };
-        std::vector<std::thread> th;
-        for (size_t t = 1; t < nt; t++) th.emplace_back(work);
-        work();
-        for (auto &t : th) t.join();
-        if (bad.load()) return mcq_fail(MCQ_EINVAL, "mcq_eval_batch_ext: a range cannot be dealt from the remaining cards");
-        HIP_TRY(hipMemcpyAsync(c->d_draws.p, hd, bytes, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->d_off.p, c->h_off.p, n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_off.p, off, n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     }
     HIP_TRY(mcq_launch_prep_ext((const mcq_query *)c->d_q.p, (const mcq_query_ext *)c->d_ext.p, (uint32_t)n,
                                 (mcq_result *)c->d_res.p, (uint64_t *)c->scratch[0].prefix.p, c->stream));
+    const int slot = (int)(c->n_timed % mcq_ctx::kRing);
+    hipEvent_t t0 = c->timing ? c->ev0[slot] : nullptr; /* parity mode: the timed region starts in front of the stream walk */
+    if (mode == MCQ_MODE_REPLAY_MT19937) {
+        if (t0) HIP_TRY(hipEventRecord(t0, c->stream));
+        t0 = nullptr;
+        HIP_TRY(mcq_launch_mt_parse_ext((const mcq_query *)c->d_q.p, (const mcq_query_ext *)c->d_ext.p, (uint32_t)n,
+                                        (uint32_t)(seed + first_query_id), (uint8_t *)c->d_draws.p, (const uint64_t *)c->d_off.p,
+                                        (mcq_result *)c->d_res.p,
+                                        reinterpret_cast<uint32_t *>((uint64_t *)c->scratch[0].prefix.p + n + 2), (uint32_t)c->n_cu,
+                                        c->stream));
+    }
     if (mode == MCQ_MODE_PHILOX) { /* the candidate lists of the ranges, once per query */
         HIP_TRY(c->d_lists.reserve(n * (size_t)lists_stride * MCQ_EXT_LIST_STRIDE * sizeof(uint16_t)));
         HIP_TRY(c->d_cnts.reserve(n * (size_t)lists_stride * sizeof(uint32_t)));
         HIP_TRY(mcq_launch_ext_lists((const mcq_query *)c->d_q.p, (const mcq_query_ext *)c->d_ext.p, (uint32_t)n, lists_stride,
                                      (uint16_t *)c->d_lists.p, (uint32_t *)c->d_cnts.p, c->stream));
     }
-    const int slot = (int)(c->n_timed % mcq_ctx::kRing);
     HIP_TRY(mcq_launch_eval_ext(mode, (const mcq_query *)c->d_q.p, (const mcq_query_ext *)c->d_ext.p, (uint32_t)n,
                                 (const uint64_t *)c->scratch[0].prefix.p, (mcq_result *)c->d_res.p, seed, first_query_id, c->d_luts,
                                 (const uint8_t *)c->d_draws.p, (const uint64_t *)c->d_off.p, (const uint16_t *)c->d_lists.p,
                                 (const uint32_t *)c->d_cnts.p, lists_stride, grid, block, c->stream,
-                                c->timing ? c->ev0[slot] : nullptr, c->timing ? c->ev1[slot] : nullptr));
+                                t0, c->timing ? c->ev1[slot] : nullptr));
     if (c->timing) c->n_timed++;
     HIP_TRY(hipMemcpyAsync(c->h_res.p, c->d_res.p, n * sizeof(mcq_result), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (!c->timing || mcq_kernel_times(c, &c->last_ms, 1) != 1) c->last_ms = 0.f;
     const mcq_result *hr = (const mcq_result *)c->h_res.p;
     for (size_t i = 0; i < n; i++)
-        if (hr[i].runs != q[i].runs)
+        if (hr[i].runs != q[i].runs || hr[i].passes == ~0ull) /* (parity mode: the stream walk marks such a query) */
             return mcq_fail(MCQ_EINVAL, "mcq_eval_batch_ext: a range cannot be dealt from the remaining cards");
     memcpy(out, hr, n * sizeof(mcq_result));
-    if (mode == MCQ_MODE_REPLAY_MT19937)
-        for (size_t i = 0; i < n; i++) out[i].passes = passes[i];
     return MCQ_OK;
     ABI_GUARD_END("mcq_eval_batch_ext")
 }

@@ -45,6 +45,10 @@ hipError_t mcq_launch_add_u64(uint64_t *d_dst, const uint64_t *d_src, uint64_t n
  * result rows); d_counter must be zero (the prep kernel leaves one behind the cost prefix) */
 hipError_t mcq_launch_mt_parse(const mcq_query *d_q, uint32_t n, uint32_t seed32, uint8_t *d_draws, const uint64_t *d_draw_off,
                                mcq_result *d_res, uint32_t *d_counter, uint32_t n_cu, hipStream_t s);
+/* ... and for extended queries (mcq_mt_ext.hpp); d_counter zero (mcq_prep_ext_kernel leaves one behind its prefix); a
+ * query whose range cannot be dealt gets passes = UINT64_MAX */
+hipError_t mcq_launch_mt_parse_ext(const mcq_query *d_q, const mcq_query_ext *d_ext, uint32_t n, uint32_t seed32, uint8_t *d_draws,
+                                   const uint64_t *d_draw_off, mcq_result *d_res, uint32_t *d_counter, uint32_t n_cu, hipStream_t s);
 /* small queries, one launch and nothing else: work_rec / work_qi (the work laid out wave by wave, see the kernel), res
  * and done_flag may be pinned host memory (device-visible); d_done: a zeroed device word */
 #define MCQ_DIRECT_IDLE 0xFFFFFFFFu

@@ -18,6 +18,7 @@
 #include "mcq_exact.hpp"
 #include "mcq_internal.hpp"
 #include "mcq_mt.hpp"
+#include "mcq_mt_ext.hpp"
 
 namespace {
 
@@ -196,6 +197,37 @@ __global__ __launch_bounds__(kMtBlock) void mcq_mt_parse_kernel(const mcq_query 
             /* every lane stores the same word: a store under `lane == 0` here would be a divergent branch in front of
              * the loop's back edge, and the wave must be whole when it fetches the next query */
             reinterpret_cast<unsigned long long *>(res + qi)[1] = st.passes;
+        }
+    }
+}
+
+// The same for extended queries (mcq_mt_ext.hpp: the reference's loops over ranges, ghost cards and known hands walked
+// stage by stage).  6.5 KB of LDS per wave.  A query whose range cannot be dealt gets passes = UINT64_MAX.
+__global__ __launch_bounds__(kMtBlock) void mcq_mt_parse_ext_kernel(const mcq_query *__restrict__ queries,
+                                                                    const mcq_query_ext *__restrict__ ext, uint32_t n, uint32_t seed32,
+                                                                    uint8_t *__restrict__ draws, const uint64_t *__restrict__ draw_off,
+                                                                    mcq_result *__restrict__ res, uint32_t *__restrict__ counter) {
+    __shared__ __attribute__((aligned(16))) McqMtExtWave ws[kMtBlock / 64];
+    McqMtExtWave &w = ws[threadIdx.x >> 6];
+    const uint32_t lane = threadIdx.x & 63u;
+    for (;;) {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(counter, 1u);
+        const uint32_t qi = __builtin_amdgcn_readfirstlane(t);
+        if (qi >= n) break;
+        const uint4 raw = reinterpret_cast<const uint4 *>(queries)[qi];
+        const McqQueryWords q = {(uint32_t)__builtin_amdgcn_readfirstlane(raw.x), (uint32_t)__builtin_amdgcn_readfirstlane(raw.y),
+                                 (uint32_t)__builtin_amdgcn_readfirstlane(raw.z), (uint32_t)__builtin_amdgcn_readfirstlane(raw.w)};
+        const uint32_t *ew = reinterpret_cast<const uint32_t *>(ext + qi);
+        const McqExtRec er = {ew};
+        if (mcq_query_ext_valid(q, er) && q.runs() != 0u) { /* wave-uniform */
+            MCQ_WAVE_SYNC(); /* the previous query's reads of this wave's LDS are done */
+            mcq_mt_seed(w, seed32 + qi);
+            MCQ_WAVE_SYNC();
+            McqMtExtState st = {MCQ_MT_N, 0u, 0u, 0u, 0u, 0u, 0ull, false};
+            const bool ok = mcq_mt_parse_query_ext(w, st, q, ew, draws + draw_off[qi], ((uint64_t)q.runs() + 63u) & ~63ull);
+            /* (every lane stores the same word: no divergent branch in front of the loop's back edge) */
+            reinterpret_cast<unsigned long long *>(res + qi)[1] = ok ? st.passes : ~0ull;
         }
     }
 }
@@ -684,7 +716,11 @@ __global__ __launch_bounds__(1024) void mcq_prep_ext_kernel(const mcq_query *__r
         if (i < n) prefix[i] = carry + before;
         carry += chunk_total;
     }
-    if (tid == 0) prefix[n] = carry;
+    if (tid == 0) {
+        prefix[n] = carry;
+        prefix[n + 1] = 0;
+        prefix[n + 2] = 0; /* work counter of mcq_mt_parse_ext_kernel */
+    }
 }
 
 // The candidate lists of the production mode: one block per query; list li of the query = all ordered pairs (a, b) of
@@ -1070,6 +1106,16 @@ hipError_t mcq_launch_mt_parse(const mcq_query *d_q, uint32_t n, uint32_t seed32
     if (blocks > 8u * n_cu) blocks = 8u * n_cu; /* what fits a CU at once: 8 blocks x 4 waves */
     hipLaunchKernelGGL(mcq_mt_parse_kernel, dim3(blocks), dim3(kMtBlock), 0, s, d_q, n, seed32, d_draws, d_draw_off, d_res,
                        d_counter);
+    return hipGetLastError();
+}
+
+hipError_t mcq_launch_mt_parse_ext(const mcq_query *d_q, const mcq_query_ext *d_ext, uint32_t n, uint32_t seed32, uint8_t *d_draws,
+                                   const uint64_t *d_draw_off, mcq_result *d_res, uint32_t *d_counter, uint32_t n_cu, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    uint32_t blocks = (n + kMtBlock / 64 - 1) / (kMtBlock / 64);
+    if (blocks > 5u * n_cu) blocks = 5u * n_cu; /* what fits a CU at once: 27 KB of LDS per block */
+    hipLaunchKernelGGL(mcq_mt_parse_ext_kernel, dim3(blocks), dim3(kMtBlock), 0, s, d_q, d_ext, n, seed32, d_draws, d_draw_off,
+                       d_res, d_counter);
     return hipGetLastError();
 }
 

@@ -47,7 +47,7 @@
 #define MCQ_BALLOT(name) __ballot(name)
 #define MCQ_BALLOT_K(name, k) __ballot(name[k])
 #define MCQ_KEEP2(a, b) ({ asm volatile("" : "+v"(a), "+v"(b)); })
-#define MCQ_BALLOT_OF(l, expr) __ballot(expr) /* ballot of an expression of the lane's values */
+#define MCQ_BALLOT_OF(l, expr) ({ const uint32_t l __attribute__((unused)) = mcq_mt_lane(); __ballot(expr); }) /* ballot of an expression of the lane's values */
 #define MCQ_LANE_OF(m, l) mcq_mt_lane_of(m)    /* is this lane's bit set in the wave mask m? */
 /* number of set bits of the wave mask m below this lane */
 #define MCQ_COUNT_BELOW(m, l) __builtin_amdgcn_mbcnt_hi((uint32_t)((m) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(m), 0u))

@@ -12,6 +12,7 @@ _SRCS = [os.path.join(_HERE, "hostsim.cpp"),
          os.path.join(_HERE, "..", "..", "neuron_poker_amd", "csrc", "mcq_replay.hpp"),
          os.path.join(_HERE, "..", "..", "neuron_poker_amd", "csrc", "mcq_exact.hpp"),
          os.path.join(_HERE, "..", "..", "neuron_poker_amd", "csrc", "mcq_mt.hpp"),
+         os.path.join(_HERE, "..", "..", "neuron_poker_amd", "csrc", "mcq_mt_ext.hpp"),
          os.path.join(_HERE, "..", "..", "neuron_poker_amd", "csrc", "mcq_layout.hpp"),
          os.path.join(_HERE, "..", "..", "include", "mcq.h")]
 _lib = None
@@ -131,6 +132,22 @@ def mt_parse(query16, seed32, reference=False):
     f.restype = C.c_uint64
     passes = f(_p(q, C.c_uint8), C.c_uint32(seed32), _p(draws, C.c_uint8), C.c_uint64(max(stride, 64)))
     return draws[:D, :runs], int(passes)
+
+
+def mt_parse_ext(query16, ext, seed32, reference=False):
+    """The same for an extended query (mcq_mt_ext.hpp against mcq_replay_parse_ext) -> (draws [rows, runs], passes);
+    passes = None when a range cannot be dealt."""
+    q = np.ascontiguousarray(query16, np.uint8)
+    e = np.ascontiguousarray(ext).view(np.uint8)
+    runs = int(q[12:16].view(np.uint32)[0])
+    lib().hs_ext_draws_per_iteration.restype = C.c_uint32
+    D = int(lib().hs_ext_draws_per_iteration(_p(q, C.c_uint8), _p(e, C.c_uint8)))
+    stride = max((runs + 63) & ~63, 64)
+    draws = np.zeros((max(D, 1), stride), np.uint8)
+    f = lib().hs_mt_parse_ext_reference if reference else lib().hs_mt_parse_ext
+    f.restype = C.c_uint64
+    passes = int(f(_p(q, C.c_uint8), _p(e, C.c_uint8), C.c_uint32(seed32), _p(draws, C.c_uint8), C.c_uint64(stride)))
+    return draws[:D, :runs], (None if passes == 2 ** 64 - 1 else passes)
 
 
 def mt_wave_words(seed32, n):

@@ -13,6 +13,7 @@
 #include "../../neuron_poker_amd/csrc/mcq_exact.hpp"
 #include "../../neuron_poker_amd/csrc/mcq_layout.hpp"
 #include "../../neuron_poker_amd/csrc/mcq_mt.hpp"
+#include "../../neuron_poker_amd/csrc/mcq_mt_ext.hpp"
 #include "../../neuron_poker_amd/csrc/mcq_replay.hpp"
 
 namespace {
@@ -289,6 +290,21 @@ extern "C" uint64_t hs_mt_parse(const mcq_query *q, uint32_t seed32, uint8_t *dr
     mcq_mt_parse_query(w, st, 50u - q->n_board, n_opp, n_deal, q->runs, draws, stride);
     return st.passes;
 }
+// ... and the same for extended queries (mcq_mt_ext.hpp) against mcq_replay_parse_ext; UINT64_MAX: cannot be dealt
+extern "C" uint64_t hs_mt_parse_ext(const mcq_query *q, const mcq_query_ext *e, uint32_t seed32, uint8_t *draws, uint64_t stride) {
+    static thread_local McqMtExtWave w;
+    if (q->runs == 0u) return 0;
+    mcq_mt_seed(w, seed32);
+    McqMtExtState st = {MCQ_MT_N, 0, 0, 0, 0, 0, 0, false};
+    if (!mcq_mt_parse_query_ext(w, st, mcq_query_words(*q), reinterpret_cast<const uint32_t *>(e), draws, stride)) return ~0ull;
+    return st.passes;
+}
+extern "C" uint64_t hs_mt_parse_ext_reference(const mcq_query *q, const mcq_query_ext *e, uint32_t seed32, uint8_t *draws, uint64_t stride) {
+    McqMt19937 g;
+    g.seed(seed32);
+    return mcq_replay_parse_ext(*q, *e, g, draws, stride, 1000000u);
+}
+extern "C" uint32_t hs_ext_draws_per_iteration(const mcq_query *q, const mcq_query_ext *e) { return mcq_ext_draws_per_iteration(*q, *e); }
 extern "C" uint64_t hs_mt_parse_reference(const mcq_query *q, uint32_t seed32, uint8_t *draws, uint64_t stride) {
     return mcq_replay_parse(*q, seed32, draws, stride);
 }

@@ -260,6 +260,42 @@ def test_wave_cooperative_mt19937_parse_equals_the_sequential_walk():
         assert p1 == p2 and np.array_equal(d1, d2), (nb, npl, runs, seed)
 
 
+def test_wave_cooperative_walk_of_extended_queries_equals_the_sequential_walk():
+    """mcq_mt_ext.hpp -- the device's walk of numpy's stream through the reference's loops over ranges, ghost cards
+    and known hands (stage by stage: every attempt of a batch of 64 words tested at once, first success ends the stage,
+    deck shifted in LDS) compiled with the lanes as arrays: accepted draws (in list.pop order) and `passes` must equal
+    the literal sequential walk of mcq_replay.hpp (which the reference's own runs pin: tests/golden/ext_tallies.json)."""
+    from neuron_poker_amd import _lib
+    ranks = "23456789TJQKA"
+    classes = [a + a for a in ranks] + [ranks[i] + ranks[j] + t for i in range(13) for j in range(i) for t in "SO"]
+    g = np.random.default_rng(20261005)
+
+    def some_range(lo, hi):
+        return sorted(g.choice(classes, size=int(g.integers(lo, hi)), replace=False))
+
+    for t in range(250):
+        nb = int(g.choice([0, 3, 4, 5]))
+        c = [int(x) for x in g.permutation(52)[:14 + nb]]
+        hero_range = some_range(5, 90) if g.random() < 0.3 else None
+        opp = some_range(10, 169) if g.random() < 0.6 else None
+        ghost = c[2:4] if g.random() < 0.3 else None
+        n_known = int(g.choice([0, 0, 1, 1, 2, 3, 4, 9]))
+        known = [some_range(10, 100) if g.random() < 0.35 else c[4 + 2 * k:6 + 2 * k] for k in range(min(n_known, 5))]
+        npl = int(g.integers(max(2, 1 + len(known)), 11))
+        runs = int(g.choice([1, 2, 63, 64, 65, 129, 300]))
+        q = _lib.pack_queries([[0, 1] if hero_range else c[:2]], [c[14:] + [255] * (5 - nb)], npl, runs)
+        if hero_range:
+            q["hole"][0] = 0
+        e = _lib.pack_query_ext(1, ghost=ghost, known=[h if isinstance(h[0], int) else _lib.range_bits(h) for h in known],
+                                hero_range=_lib.range_bits(hero_range) if hero_range else None,
+                                opp_range=_lib.range_bits(opp) if opp else None)
+        seed = int(g.integers(0, 2 ** 32))
+        q16 = q.view(np.uint8).reshape(16)
+        d1, p1 = H.mt_parse_ext(q16, e, seed)
+        d2, p2 = H.mt_parse_ext(q16, e, seed, reference=True)
+        assert p1 == p2 and np.array_equal(d1, d2), (nb, npl, runs, seed, hero_range, opp, known, ghost)
+
+
 def test_one_launch_layout_invariants():
     """mcq_layout.hpp (host side of mcq_eval_direct_kernel): every query owns 2^lg consecutive, size-aligned waves of
     ONE block and round with cut numbers 0 .. 2^lg - 1 in order; no slot is used twice; waves follow cost (within a
