@@ -343,7 +343,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
         "config": {"workload": "%d random preflop states per GPU (default_rng(4096+rank), as BASELINE configs[2]) x "
-                               "%d players x %d iterations, production RNG (Philox-keyed jsf32), queries and "
+                               "%d players x %d iterations, production RNG (Philox-keyed MWC64X, MCQ-CTR v5), queries and "
                                "tallies resident in HBM%s" %
                                (B, N, runs, ", one %s all-reduce of the [%d,13] int64 tally matrix per step" %
                                 ("RCCL" if args.backend == "nccl" else args.backend, world * B) if grouped else ""),

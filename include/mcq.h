@@ -41,7 +41,7 @@ extern "C" {
 #define MCQ_ENOMEM (-3)  /* host or device allocation failed */
 
 /* random-number front ends (the deal -> evaluate -> tally body is shared) */
-#define MCQ_MODE_PHILOX 0         /* production: counter-based streams, Philox4x32-10 keyed jsf32 (MCQ-CTR v4) */
+#define MCQ_MODE_PHILOX 0         /* production: counter-based streams, Philox4x32-10 keyed MWC64X (MCQ-CTR v5) */
 #define MCQ_MODE_REPLAY_MT19937 1 /* parity: query i replays np.random.seed((seed + first_query_id + i) mod 2^32)
                                      exactly as tools/montecarlo_python.py consumes it -> bit-exact tallies */
 

@@ -31,7 +31,7 @@
 #define MCQ_HDM inline
 #endif
 
-#define MCQ_STREAM_ITERS 16u /* iterations per RNG stream (MCQ-CTR v4) */
+#define MCQ_STREAM_ITERS 16u /* iterations per RNG stream (MCQ-CTR v5) */
 #define MCQ_WAVE 64u
 #define MCQ_TASK_ITERS (MCQ_STREAM_ITERS * MCQ_WAVE) /* iterations per wave task */
 #define MCQ_MAX_OPP 9
@@ -218,7 +218,7 @@ static inline void mcq_fill_tables(McqTables *t) {
     }
 }
 
-// ------------------------------------------------------------------------------------------ RNG: MCQ-CTR v4
+// ------------------------------------------------------------------------------------------ RNG: MCQ-CTR v5
 MCQ_HD void mcq_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                               uint32_t out[4]) {
 #pragma unroll
@@ -257,33 +257,36 @@ struct McqXoshiro { /* xoshiro128++ (Blackman & Vigna): the table driver's per-t
     }
 };
 
-// The production mode's generator: Bob Jenkins' small noncryptographic PRNG ("jsf32", rotations 27 / 17; passes
-// PractRand and BigCrush), 7 instructions per word against 9-10 of xoshiro128++ (measured: 6.85 -> 6.69 ms on the
-// headline workload); its four state words are the Philox block of (seed, query id, stream).
-struct McqJsf32 {
-    uint32_t a, b, c, d;
+// The production mode's per-stream generator (MCQ-CTR v5): MWC64X -- David B. Thomas' multiply-with-carry generator
+// for GPUs: (x, c) -> (lo, hi) of A * x + c, A = 4294883355, output x ^ c, period ~2^63, passes TestU01 BigCrush.
+// ONE v_mad_u64_u32, a move of the carry into the addend pair and the output xor: three instructions per word against
+// seven of v4's jsf32 (measured on the headline workload: 548 -> 516 VALU instructions per wave-iteration, 6.01 ->
+// 5.73 ms).  Its two state words come from the Philox block of (seed, query id, stream).
+struct McqMwc64x {
+    uint32_t x, c;
     MCQ_HDM void seed(uint64_t seed, uint64_t qid, uint32_t stream) {
         uint32_t o[4];
         mcq_philox4x32_10((uint32_t)qid, (uint32_t)(qid >> 32), stream, 0x4D435131u, (uint32_t)seed,
                           (uint32_t)(seed >> 32), o);
-        a = o[0]; b = o[1]; c = o[2]; d = o[3];
-        if ((a | b | c | d) == 0) a = 0xf1ea5eedu; /* the all-zero state is a fixed point */
+        x = o[0];
+        c = o[1] >> 1; /* carry < A; (2^32 - 1, A - 1), the other fixed point, cannot be seeded */
+        if ((x | c) == 0) x = 0xf1ea5eedu; /* (0, 0) is a fixed point */
     }
     MCQ_HDM uint32_t next() {
 #ifdef MCQ_ABLATE_RNG /* diagnostic timing build: wrong results */
-        a += 0x9E3779B9u;
-        return a;
+        x += 0x9E3779B9u;
+        return x;
 #endif
-        const uint32_t e = a - mcq_rotl(b, 27);
-        a = b ^ mcq_rotl(c, 17);
-        b = c + d;
-        c = d + e;
-        d = e + a;
-        return d;
+        const uint32_t r = x ^ c;
+        const uint64_t t = (uint64_t)4294883355u * x + c;
+        x = (uint32_t)t;
+        c = (uint32_t)(t >> 32);
+        return r;
     }
 };
+typedef McqMwc64x McqStreamRng;
 
-// Draw policy of the production mode, "MCQ-CTR v4": the reference's dealing law without its re-draw loop.
+// Draw policy of the production mode, "MCQ-CTR v5": the reference's dealing law without its re-draw loop.
 //   Opponent pair on a deck of length L from ONE word u, d = L - 1:  a = mulhi32(u, d), c = mulhi32(u * d mod 2^32, d)
 //   -- (a, c) is uniform on [0, d)^2 up to d^2 / 2^32 -- and (r1, r2) = (a, c) if a != c else (d, a).  That is a
 //   bijection from [0, d)^2 onto the pairs the reference accepts (r1 in [0,L), r2 in [0,L-1), r1 != r2;
@@ -299,7 +302,7 @@ struct McqJsf32 {
 template <bool UNIFORM>
 struct McqCtrDrawsT {
     static constexpr uint32_t kTableShort = UNIFORM ? 0u : 1u; /* table draw range = deck length - kTableShort */
-    McqJsf32 rng;
+    McqStreamRng rng;
     uint32_t w;
     uint64_t bias; /* mcq_p128_bias(), set once per stream (start) */
     MCQ_HDM void start(uint64_t seed, uint64_t qid, uint32_t stream) {
@@ -853,7 +856,7 @@ MCQ_HD void mcq_iterations(const McqQueryCtx &qc, Draws &dr, const McqCard *base
 // A range is a 169-bit set; the bit of two cards is how get_two_short_notation (:24-34) names them:
 // suited -> 13*min+max, off-suit -> 13*max+min, pair -> 14*rank.
 //
-// Production mode ("MCQ-CTR v4x") deals the reference's LAW without its index arithmetic and without its re-draw
+// Production mode ("MCQ-CTR v5x") deals the reference's LAW without its index arithmetic and without its re-draw
 // loop over all L(L-1) index pairs.  The reference accepts, equally often, every ordered index pair (r1, r2),
 // r1 in [0,L), r2 in [0,L-1), r1 != r2, whose classes are allowed (:167-176); as cards: every ordered pair (A, B) of
 // distinct cards of the current deck with B not the deck's highest card.  Per range there is a fixed CANDIDATE LIST
@@ -865,7 +868,7 @@ MCQ_HD void mcq_iterations(const McqQueryCtx &qc, Draws &dr, const McqCard *base
 // opponent is dealt A and, as deck.pop(r1); deck.pop(r2) deal (:178-179), B if B lies below A, else the card that
 // FOLLOWS B in the deck (the reference's quirk: the range test looks at the unpopped list).  With the top quarter of
 // the classes a trial of the reference's loop succeeds one time in ~25, a trial here three times in four.
-// Opponents to whom every class is allowed are dealt by index exactly as the plain path deals them (MCQ-CTR v4, one
+// Opponents to whom every class is allowed are dealt by index exactly as the plain path deals them (MCQ-CTR v5, one
 // word per pair), so an extension record that restricts nothing gives the plain path's tallies bit for bit.
 #define MCQ_EXT_WORDS 76u         /* sizeof(mcq_query_ext) / 4 */
 #define MCQ_EXT_MAX_LISTS 11u     /* ten known hands as ranges + the opponents */
@@ -1035,7 +1038,7 @@ MCQ_HD uint32_t mcq_deck_next(uint32_t lo, uint32_t hi, uint32_t c) { /* the car
 // Draw policies (the extended path is not unrolled).
 struct McqExtCtrDraws {
     static constexpr bool kReplay = false;
-    McqJsf32 rng;
+    McqStreamRng rng;
     uint32_t w;
     MCQ_HDM void start(uint64_t seed, uint64_t qid, uint32_t stream) {
         w = 0;
@@ -1043,7 +1046,7 @@ struct McqExtCtrDraws {
     }
     MCQ_HDM uint32_t pick(uint32_t n) { return mcq_mulhi(rng.next(), n); } /* a candidate of a list of n */
     MCQ_HDM void pair(uint32_t &, uint32_t &) {}
-    MCQ_HDM void index_pair(uint32_t L, uint32_t &r1, uint32_t &r2) { /* MCQ-CTR v4 as the plain path: McqCtrDrawsT::pair */
+    MCQ_HDM void index_pair(uint32_t L, uint32_t &r1, uint32_t &r2) { /* MCQ-CTR v5 as the plain path: McqCtrDrawsT::pair */
         const uint32_t dd = L - 1u;
         const uint32_t u = rng.next();
         uint32_t frac;

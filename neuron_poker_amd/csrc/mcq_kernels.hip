@@ -431,7 +431,7 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
                 for (uint32_t k = sub * chunk * (qc.n_opp + ((qc.n_deal + 1u) >> 1)); k != 0; k--) dr.rng.next();
                 const uint32_t cnt = (uint32_t)min((uint64_t)chunk, (uint64_t)qc.runs - it0);
                 mcq_iterations<true>(qc, dr, base - 128, g_tab->tf, tab.tops, tab.sd, acc, cnt); /* both dealing laws */
-                acc.passes = cnt * qc.n_opp; /* MCQ-CTR v4: one attempt per opponent, never re-drawn */
+                acc.passes = cnt * qc.n_opp; /* MCQ-CTR v5: one attempt per opponent, never re-drawn */
             }
         } else {
             /* a lane takes FOUR consecutive iterations at a time (one 32-bit load per draw row, McqReplayDraws4); a task

@@ -85,8 +85,9 @@ static uint32_t np_randint(mt_t *s, uint32_t n) {
 }
 
 /* ------------------------------------------------------- counter-based front end (product's CTR mode) */
-/* Spec (DESIGN.md "MCQ-CTR v4"): iterations are grouped in streams of 16; stream s of query id q under
- * seed k starts jsf32 (state a, b, c, d) from Philox4x32-10(counter = {q_lo, q_hi, s, 'MCQ1'}, key = {k_lo, k_hi}).
+/* Spec (DESIGN.md "MCQ-CTR v5"): iterations are grouped in streams of 16; stream s of query id q under
+ * seed k starts MWC64X (state x, c) from Philox4x32-10(counter = {q_lo, q_hi, s, 'MCQ1'}, key = {k_lo, k_hi}):
+ * x = word 0, c = word 1 >> 1.
  * Opponent pair on a deck of length L, ONE word u, d = L-1: a = mulhi32(u, d), c = mulhi32(u * d mod 2^32, d);
  * (r1, r2) = (a, c) if a != c else (d, a) -- a bijection onto the pairs the reference accepts
  * (r1 in [0,L), r2 in [0,L-1), r1 != r2), so they are equally likely exactly as after its re-draw loop
@@ -108,40 +109,39 @@ static void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-/* Bob Jenkins' small noncryptographic PRNG ("jsf32", two-rotate version 27/17) */
-typedef struct { uint32_t s[4]; } js_t;
+/* MWC64X (David B. Thomas' multiply-with-carry generator: (x, c) -> (lo, hi) of A * x + c, output x ^ c) */
+typedef struct { uint32_t x, c; } js_t;
 
-static inline uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
-
-static uint32_t js_next(js_t *x) {
-    uint32_t *s = x->s; /* a, b, c, d */
-    uint32_t e = s[0] - rotl32(s[1], 27);
-    s[0] = s[1] ^ rotl32(s[2], 17);
-    s[1] = s[2] + s[3];
-    s[2] = s[3] + e;
-    s[3] = e + s[0];
-    return s[3];
+static uint32_t js_next(js_t *s) {
+    const uint32_t r = s->x ^ s->c;
+    const uint64_t t = (uint64_t)4294883355u * s->x + s->c;
+    s->x = (uint32_t)t;
+    s->c = (uint32_t)(t >> 32);
+    return r;
 }
 
-static void js_seed(js_t *x, uint64_t seed, uint64_t qid, uint32_t stream) {
+static void js_seed(js_t *s, uint64_t seed, uint64_t qid, uint32_t stream) {
     uint32_t ctr[4] = {(uint32_t)qid, (uint32_t)(qid >> 32), stream, 0x4D435131u};
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-    philox4x32_10(ctr, key, x->s);
-    if ((x->s[0] | x->s[1] | x->s[2] | x->s[3]) == 0) x->s[0] = 0xf1ea5eedu; /* the all-zero state is a fixed point */
+    uint32_t o[4];
+    philox4x32_10(ctr, key, o);
+    s->x = o[0];
+    s->c = o[1] >> 1;                              /* carry < A */
+    if ((s->x | s->c) == 0) s->x = 0xf1ea5eedu;    /* (0, 0) is a fixed point */
 }
 
 static uint32_t js_draw(js_t *x, uint32_t n) { return (uint32_t)(((uint64_t)js_next(x) * n) >> 32); }
 
 /* one RNG handle for the dealing code */
 typedef struct {
-    int kind; /* 0 = MT19937 + numpy randint, 1 = jsf32 + mulhi */
+    int kind; /* 0 = MT19937 + numpy randint, 1 = MWC64X + mulhi */
     mt_t *mt;
     js_t *xo;
 } rng_t;
 
 static uint32_t draw(rng_t *r, uint32_t n) { return r->kind == 0 ? np_randint(r->mt, n) : js_draw(r->xo, n); }
-/* kind: 0 = MT19937 + numpy randint (the reference), 1 = MCQ-CTR v4 with the reference's dealing law,
- * 2 = MCQ-CTR v4 with the UNIFORM law (what montecarlo_cython.pyx:188 and Montecarlo.cpp:296-312 intend) */
+/* kind: 0 = MT19937 + numpy randint (the reference), 1 = MCQ-CTR v5 with the reference's dealing law,
+ * 2 = MCQ-CTR v5 with the UNIFORM law (what montecarlo_cython.pyx:188 and Montecarlo.cpp:296-312 intend) */
 
 /* ------------------------------------------------------------------------------------------ evaluator */
 enum { T_HIGH, T_PAIR, T_TWOPAIR, T_TRIPS, T_STRAIGHT, T_FLUSH, T_FULL, T_QUADS, T_SF };
@@ -341,7 +341,7 @@ static uint32_t deal_iteration(rng_t *rng, const uint8_t hero[2], const uint8_t 
     hole[0][0] = hero[0]; hole[0][1] = hero[1];
     deck_remove(&d, hero[0]); /* l.154-161 */
     deck_remove(&d, hero[1]);
-    for (int p = 1; p < n_players && rng->kind == 2; p++) { /* MCQ-CTR v4, UNIFORM law */
+    for (int p = 1; p < n_players && rng->kind == 2; p++) { /* MCQ-CTR v5, UNIFORM law */
         uint32_t dd = (uint32_t)d.n - 1, u = js_next(rng->xo);
         uint32_t r1 = (uint32_t)(((uint64_t)u * (dd + 1)) >> 32);                   /* in [0, L) */
         uint32_t r2 = (uint32_t)(((uint64_t)(uint32_t)(u * (dd + 1)) * dd) >> 32);  /* in [0, L-1): every ordered pair */
@@ -349,7 +349,7 @@ static uint32_t deal_iteration(rng_t *rng, const uint8_t hero[2], const uint8_t 
         hole[p][0] = deck_pop(&d, (int)r1);
         hole[p][1] = deck_pop(&d, (int)r2);
     }
-    for (int p = 1; p < n_players && rng->kind == 1; p++) { /* MCQ-CTR v4 */
+    for (int p = 1; p < n_players && rng->kind == 1; p++) { /* MCQ-CTR v5 */
         uint32_t dd = (uint32_t)d.n - 1, u = js_next(rng->xo);
         uint32_t a = (uint32_t)(((uint64_t)u * dd) >> 32), c = (uint32_t)(((uint64_t)(uint32_t)(u * dd) * dd) >> 32);
         uint32_t r1 = a != c ? a : dd, r2 = a != c ? c : a;
@@ -458,7 +458,7 @@ int mcqo_compare(const uint8_t *a, const uint8_t *b) {
 
 int mcqo_best_hand(const uint8_t *hands, int n, int *type, int *tie) { return best_hand(hands, n, type, tie); }
 
-/* mode 0: np.random.seed((uint32)seed) then the reference loop; mode 1: MCQ-CTR v4 with query id qid.
+/* mode 0: np.random.seed((uint32)seed) then the reference loop; mode 1: MCQ-CTR v5 with query id qid.
  * trace (optional): first `keep` iterations' hands [keep][n_players][7]; words (optional, mode 0): MT words
  * per kept iteration; total_words (optional). Returns 0, or -1 on invalid input. */
 int mcqo_run(int mode, const uint8_t *hero, const uint8_t *board, int nb, int n_players, uint32_t runs,
@@ -577,7 +577,7 @@ static int in_range(const uint32_t *bits, uint8_t a, uint8_t b) {
  * there any more: the reference's try/except), a random opponent is tested on the unpopped list and then popped in turn
  * (l.165-181).
  *
- * mode 1 (production, "MCQ-CTR v4x"): the same LAW without index arithmetic.  The reference accepts every ordered
+ * mode 1 (production, "MCQ-CTR v5x"): the same LAW without index arithmetic.  The reference accepts every ordered
  * index pair (r1, r2), r1 in [0,L), r2 in [0,L-1), r1 != r2, whose classes are allowed, equally often; as cards that
  * is every ordered pair (A, B) of distinct cards of the current deck with B not the deck's highest card and
  * class(A, B) allowed.  Per draw (range hand h, or the opponents) there is a fixed candidate list
@@ -672,7 +672,7 @@ int mcqo_run_ex2(int mode, int n_known, const uint8_t *known_cards, const uint32
                     A = deck_pop(&d, (int)r1);
                     B = deck_pop(&d, (int)r2);
                 }
-            } else if (!is_known && opp_all) { /* MCQ-CTR v4, one word, never re-drawn */
+            } else if (!is_known && opp_all) { /* MCQ-CTR v5, one word, never re-drawn */
                 uint32_t dd = (uint32_t)d.n - 1, u = js_next(&xo);
                 uint32_t a = (uint32_t)(((uint64_t)u * dd) >> 32), c = (uint32_t)(((uint64_t)(uint32_t)(u * dd) * dd) >> 32);
                 out[1]++;

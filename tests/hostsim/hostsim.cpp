@@ -89,7 +89,7 @@ static int run_ctr_t(const mcq_query *q, uint64_t seed, uint64_t qid, mcq_result
         const uint32_t cnt = left < MCQ_STREAM_ITERS ? (uint32_t)left : MCQ_STREAM_ITERS;
         if (STRAIGHT) mcq_iterations<true>(qc, dr, base, t.tf, t.tops, t.sd, acc, cnt); /* as the bulk kernel runs them */
         else for (uint32_t j = 0; j < cnt; j++) mcq_iteration(qc, dr, base, t.tf, t.tops, t.sd, acc);
-        acc.passes += cnt * qc.n_opp; /* MCQ-CTR v4: one attempt per opponent, never re-drawn */
+        acc.passes += cnt * qc.n_opp; /* MCQ-CTR v5: one attempt per opponent, never re-drawn */
         fold(acc, out);
     }
     return MCQ_OK;

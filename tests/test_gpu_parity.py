@@ -2,7 +2,7 @@
 
 Bar (integer work): bit-exact.  The only floating-point number on the path is wins / runs.
   * parity mode (MT19937 replay)  == the reference's own tallies under np.random.seed (tests/golden/tallies.json)
-  * production mode (MCQ-CTR v4)  == the oracle's CTR mode, query by query
+  * production mode (MCQ-CTR v5)  == the oracle's CTR mode, query by query
   * evaluator                     == the reference's _calc_score ordering on the golden hands / showdowns
   * full-size configs             -> size-independent properties (sum of types, shard invariance, exact
                                      expectation from exhaustive enumeration)

@@ -180,7 +180,7 @@ def _ext_case(t):
 
 def test_extended_queries_replay_equals_reference_and_ctr_equals_oracle():
     """ranges, ghost cards, any number of known hands (cards or ranges) through the product's lane code:
-    parity mode == the reference's own seeded runs, production mode == the oracle's implementation of MCQ-CTR v4x."""
+    parity mode == the reference's own seeded runs, production mode == the oracle's implementation of MCQ-CTR v5x."""
     with open(os.path.join(G, "ext_tallies.json")) as f:
         rows = json.load(f)
     for t in rows:

@@ -58,21 +58,24 @@ def test_philox_known_answers():
                                                                            '0x24126ea1']
 
 
-def test_jsf32_reference_sequence():
-    # independent restatement of Bob Jenkins' small PRNG (jsf32, rotations 27 / 17) in Python ints, seeded with the
-    # Philox block of (seed, query id, stream) as MCQ-CTR v4 does
-    def rotl(x, k):
-        return ((x << k) | (x >> (32 - k))) & 0xffffffff
-    a, b, c, d = [int(x) for x in O.philox4x32_10([5, 0, 3, 0x4D435131], [77, 1])]
+def test_mwc64x_reference_sequence():
+    # independent restatement of MWC64X (D. B. Thomas: x' = lo, c' = hi of A * x + c, A = 4294883355, output x ^ c)
+    # in Python ints, seeded with the Philox block of (seed, query id, stream) as MCQ-CTR v5 does
+    o = [int(v) for v in O.philox4x32_10([5, 0, 3, 0x4D435131], [77, 1])]
+    x, c = o[0], o[1] >> 1
     exp = []
     for _ in range(64):
-        e = (a - rotl(b, 27)) & 0xffffffff
-        a = b ^ rotl(c, 17)
-        b = (c + d) & 0xffffffff
-        c = (d + e) & 0xffffffff
-        d = (e + a) & 0xffffffff
-        exp.append(d)
+        exp.append(x ^ c)
+        t = 4294883355 * x + c
+        x, c = t & 0xffffffff, t >> 32
     assert list(O.ctr_stream(77 + (1 << 32), 5, 3, 64)) == exp
+    # Thomas' published recurrence in its OpenCL form (mul_hi / carry) gives the same step
+    x, c = 12345, 678
+    hi = (x * 4294883355) >> 32
+    nx = (x * 4294883355 + c) & 0xffffffff
+    nc = hi + (1 if nx < c else 0)
+    t = 4294883355 * x + c
+    assert (nx, nc) == (t & 0xffffffff, t >> 32)
 
 
 # ------------------------------------------------------------------ evaluator
@@ -236,7 +239,7 @@ def test_reference_range_tests_statistically():
 
 
 def test_production_law_of_extended_queries_equals_the_reference_law():
-    """The production sampler of extended queries (MCQ-CTR v4x: rejection from a fixed candidate list, no index
+    """The production sampler of extended queries (MCQ-CTR v5x: rejection from a fixed candidate list, no index
     arithmetic) must deal the reference's LAW: on cases small enough to see differences of a few 1e-3, its equity
     agrees with the literal MT19937 walk of the reference's loops within Monte-Carlo noise (both 400k iterations,
     sigma of the difference 1.1e-3; bound 4.5e-3)."""
