@@ -172,43 +172,71 @@ def launch_ranks(n, argv):
 
 
 def native_multi(args):
-    """--native-multi: the whole job in one process through mcq_multi_eval_batch (include/mcq.h)."""
+    """--native-multi: the whole job in ONE process through the C ABI's multi-GPU entry (include/mcq.h): shards -> one
+    ncclAllReduce of the tally matrix.  Queries and tallies resident in HBM (mcq_multi_eval_batch_device; torch only holds
+    the buffers), so the figure carries no PCIe -- the same keys as the one-rank-per-GPU line."""
+    import torch
     import neuron_poker_amd as npa
     n_dev = npa.load_library().mcq_device_count()
     devices = [0] * args.gpus if args.single_device else list(range(args.gpus))
     if not args.single_device and args.gpus > n_dev:
         raise SystemExit("--gpus %d but %d devices visible" % (args.gpus, n_dev))
     me = npa.MultiEngine(devices)
-    B, N, runs = args.states * args.gpus, args.players, args.iters
-    hole = np.concatenate([make_states(args.states, r)[0] for r in range(args.gpus)])
+    k = len(devices)
+    B, N, runs = args.states * k, args.players, args.iters
+    hole = np.concatenate([make_states(args.states, r)[0] for r in range(k)])
     board = np.full((B, 5), 255, np.uint8)
-    q = npa.pack_queries(hole, board, N, runs)
+    raw = npa.pack_queries(hole, board, N, runs).view(np.uint8).reshape(B, 16)
+    d_q = [torch.from_numpy(raw[B * s // k:B * (s + 1) // k].copy()).to("cuda:%d" % d) for s, d in enumerate(devices)]
+    d_res = [torch.zeros((B, 13), dtype=torch.int64, device="cuda:%d" % d) for d in devices]
+    qp, rp = [t.data_ptr() for t in d_q], [t.data_ptr() for t in d_res]
     seed = 20261004
+
+    def fence():
+        for d in set(devices):
+            torch.cuda.synchronize(d)
+
     for i in range(args.warmup):
-        me.eval_batch(q, seed + i)
+        me.eval_batch_device(qp, B, seed + i, rp, partition="queries")
+    fence()
     kmax, ar = [], []
     t0 = time.perf_counter()
     for i in range(args.steps):
-        res = me.eval_batch(q, seed + args.warmup + i)
+        me.eval_batch_device(qp, B, seed + args.warmup + i, rp, partition="queries")   # returns when every device is done
         t = me.last_times_ms
         kmax.append(t["kernel_max"])
         ar.append(t["all_reduce"])
+    fence()
     elapsed = time.perf_counter() - t0
-    t = res.view(np.uint64).reshape(-1, 13)
+    t = d_res[0].cpu().numpy().view(np.uint64)
     assert (t[:, 0] == runs).all() and np.array_equal(t[:, 2] + t[:, 3], t[:, 4:].sum(1))
+    assert all(torch.equal(d_res[0].cpu(), r.cpu()) for r in d_res[1:]), "the shards' matrices differ after the all-reduce"
     evals = float(B) * runs * N
     info = me.info
+    kernel_ms = float(np.mean(kmax))
+    pc, fresh = profile_counters()
+    if pc and pc.get("workload") != {"states": args.states, "iters": runs, "players": N}:
+        pc = None
+    roof = issue_roofline("mcq_eval_kernel<0, false>", kernel_ms, pc, fresh,
+                          model_ops_per_launch=float(args.states) * runs * alg_ops_per_iteration(N, 0),
+                          model_basis="SURVEY 8(d): %d lane-ops per iteration" % alg_ops_per_iteration(N, 0))
+    roof["traffic"] = pc.get("hbm_bytes_per_launch") if pc else None
+    roof["note"] = "per shard: the slowest shard's evaluation kernel"
     print(json.dumps({
         "metric": "Monte Carlo hand evals/sec @100k iters, 6-max preflop", "value": evals * args.steps / elapsed,
         "unit": "hand-evals/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic",
         "config": {"workload": "%d random preflop states per GPU x %d players x %d iterations, ONE process, %d shards on "
-                               "devices %s via mcq_multi_eval_batch (host buffers: PCIe-inclusive), partition '%s', one "
-                               "ncclAllReduce over %d device(s)" % (args.states, N, runs, info["shards"], devices,
-                                                                    info["last_partition"], info["devices"]),
-                   "states_per_gpu": args.states, "n_players": N, "iterations": runs, "hand_evals_per_step": evals},
-        "native_multi": {"kernel_max_ms": float(np.mean(kmax)), "all_reduce_ms": float(np.mean(ar)),
+                               "devices %s via mcq_multi_eval_batch_device (queries and tallies resident in HBM), partition "
+                               "'%s', one ncclAllReduce of the [%d,13] uint64 tally matrix over %d device(s)" %
+                               (args.states, N, runs, info["shards"], devices, info["last_partition"], B, info["devices"]),
+                   "states_per_gpu": args.states, "n_players": N, "iterations": runs, "n_board": 0,
+                   "hand_evals_per_step": evals},
+        "roofline": roof,
+        "collective": {"all_reduce_ms": float(np.mean(ar)), "bytes": B * 104, "ranks": info["devices"],
+                       "rccl_version": info["rccl_version"]},
+        "native_multi": {"kernel_max_ms": kernel_ms, "all_reduce_ms": float(np.mean(ar)),
                          "rccl_version": info["rccl_version"]}}), file=JSON_OUT, flush=True)
     me.close()
 
@@ -318,6 +346,15 @@ def main():
     assert (t[:, 0] == runs).all(), "runs column wrong"
     assert np.array_equal(t[:, 2] + t[:, 3], t[:, 4:].sum(1)), "sum(by_type) != win + tie"
 
+    ar_ms = None
+    if grouped and args.backend == "nccl":   # the collective alone (outside the timed region): same key as --native-multi
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dist.all_reduce(tallies, op=dist.ReduceOp.SUM)
+        e1.record()
+        torch.cuda.synchronize()
+        ar_ms = e0.elapsed_time(e1) / 5
     kt = eng.kernel_times(min(args.steps, 64))  # HIP events on the launch stream, recorded inside the timed region
     kernel_ms = float(np.mean(kt)) if len(kt) else float("nan")
     evals_per_step = float(world) * B * runs * N
@@ -351,6 +388,9 @@ def main():
                    "hand_evals_per_step": evals_per_step},
         "roofline": roof,
     }
+    if grouped:
+        out["collective"] = {"all_reduce_ms": ar_ms, "bytes": world * B * 104, "ranks": world,
+                             "backend": "RCCL (torch.distributed nccl)" if args.backend == "nccl" else args.backend}
     side_counters = (profile_counters()[0] or {}).get("side_kernels", {})  # PMC passes of tools/side_kernels.py's workloads
     if world == 1 and not args.no_extras:  # single-GPU side measurements; never delay the other ranks' teardown
         extras = {}

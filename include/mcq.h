@@ -256,6 +256,14 @@ MCQ_API mcq_multi *mcq_multi_create(const int *devices, int n_shards, int flags)
 MCQ_API void mcq_multi_destroy(mcq_multi *m);
 MCQ_API int mcq_multi_eval_batch(mcq_multi *m, const mcq_query *q, size_t n, uint64_t seed, uint64_t first_query_id,
                                  int partition, mcq_result *out);
+/* The same with queries and results RESIDENT IN HBM (no PCIe in the call): one device pointer pair per shard, on that
+ * shard's device.  d_queries[s]: MCQ_PARTITION_QUERIES -> the shard's block, queries [n*s/k, n*(s+1)/k) of the batch
+ * (k shards); MCQ_PARTITION_ITERATIONS -> all n queries.  d_results[s] -> mcq_result[n], overwritten: after the
+ * all-reduce EVERY shard's buffer holds the complete matrix.  Blocks until all devices have finished.  The host never
+ * sees the queries, so they are validated on the device: an invalid query's row has runs = 0 (and, under
+ * MCQ_PARTITION_QUERIES, passes = UINT64_MAX). */
+MCQ_API int mcq_multi_eval_batch_device(mcq_multi *m, const void *const *d_queries, size_t n, uint64_t seed,
+                                        uint64_t first_query_id, int partition, void *const *d_results);
 MCQ_API int mcq_multi_set_dealing_law(mcq_multi *m, int law);
 /* info: shards, distinct devices (= ranks of the all-reduce), RCCL version code, partition of the last call */
 MCQ_API int mcq_multi_info(const mcq_multi *m, int info[4]);

@@ -127,6 +127,8 @@ def load_library():
         L.mcq_multi_destroy.restype = None
         L.mcq_multi_eval_batch.argtypes = [vp, vp, sz, u64, u64, C.c_int, vp]
         L.mcq_multi_eval_batch.restype = C.c_int
+        L.mcq_multi_eval_batch_device.argtypes = [vp, vp, sz, u64, u64, C.c_int, vp]
+        L.mcq_multi_eval_batch_device.restype = C.c_int
         L.mcq_multi_set_dealing_law.argtypes = [vp, C.c_int]
         L.mcq_multi_set_dealing_law.restype = C.c_int
         L.mcq_multi_info.argtypes = [vp, vp]
@@ -430,6 +432,20 @@ class MultiEngine:
         if rc:
             _raise(rc)
         return out
+
+    def eval_batch_device(self, d_queries, n, seed, d_results, first_query_id=0, partition="auto"):
+        """Queries and results resident in HBM: d_queries / d_results = one raw device pointer (int) per shard, on that
+        shard's device -- the shard's block of the n queries (partition "queries") or all of them ("iterations"), and
+        room for the complete [n] result matrix, which every shard's buffer holds afterwards.  Blocks until done."""
+        k = len(self.devices)
+        if len(d_queries) != k or len(d_results) != k:
+            raise ValueError("one device pointer pair per shard")
+        qp = (C.c_void_p * k)(*[int(p) if p else None for p in d_queries])
+        rp = (C.c_void_p * k)(*[int(p) if p else None for p in d_results])
+        rc = self._lib.mcq_multi_eval_batch_device(self._m, qp, int(n), int(seed) & (2 ** 64 - 1),
+                                                   int(first_query_id) & (2 ** 64 - 1), _PARTITIONS[partition], rp)
+        if rc:
+            _raise(rc)
 
     @property
     def info(self):

@@ -1003,6 +1003,7 @@ struct McqExtWaveCtx { /* per wave, in LDS: what the iteration indexes at run ti
     uint32_t hand[10];                  /* mcq_ext_hand of every known hand */
     uint32_t cnt[MCQ_EXT_MAX_LISTS];    /* sizes of the candidate lists */
     uint32_t pad_[3];
+    const uint16_t *list[MCQ_EXT_MAX_LISTS]; /* where each list lies: HBM, or the block's LDS when its queries' lists fit */
 };
 
 MCQ_HD void mcq_ext_ctx(const McqQueryWords &q, const McqExtRec &e, McqExtCtx &c) {
@@ -1082,12 +1083,12 @@ struct McqExtReplayDraws { /* accepted draws from the host, all in list.pop orde
 };
 
 // One iteration of an extended query.  ids: this lane's slot array (stride `ids_stride` words) for the dealt
-// hands; cards: the 52-entry card table; lists: the query's candidate lists (MCQ_EXT_LIST_STRIDE entries each),
+// hands; cards: the 52-entry card table; wc.list: the query's candidate lists,
 // wc: the known hands and the list sizes.  Returns false when a range could not be dealt within
 // MCQ_EXT_MAX_TRIALS attempts.
 template <class Draws>
 MCQ_HD bool mcq_iteration_ext(const McqExtCtx &qc, const McqExtWaveCtx &wc, Draws &dr, const McqCard *cards,
-                              const uint32_t *sel8, const uint16_t *lists, uint32_t *ids, uint32_t ids_stride,
+                              const uint32_t *sel8, uint16_t *ids, uint32_t ids_stride,
                               const uint32_t *tf, const uint32_t *tops, const uint32_t *sd, McqLaneAcc &acc) {
     uint32_t dlo = qc.deck_lo, dhi = qc.deck_hi;
     bool dealt = true;
@@ -1112,7 +1113,7 @@ MCQ_HD bool mcq_iteration_ext(const McqExtCtx &qc, const McqExtWaveCtx &wc, Draw
             c2 = mcq_select_pop(dlo, dhi, r2, sel8);
         } else {
             const uint32_t n = wc.cnt[li];
-            const uint16_t *list = lists + li * MCQ_EXT_LIST_STRIDE;
+            const uint16_t *list = wc.list[li];
             const uint32_t top = mcq_deck_top(dlo, dhi);
             bool ok = false;
             c1 = c2 = 0;
@@ -1129,7 +1130,7 @@ MCQ_HD bool mcq_iteration_ext(const McqExtCtx &qc, const McqExtWaveCtx &wc, Draw
         if (known && (hd >> 16)) li++;
         mcq_deck_take(dlo, dhi, c1 < 52u ? c1 : 0u);
         mcq_deck_take(dlo, dhi, c2 < 52u ? c2 : 0u);
-        ids[h * ids_stride] = c1 | (c2 << 8);
+        ids[h * ids_stride] = (uint16_t)(c1 | (c2 << 8));
     }
     McqBoard b = qc.board;
     for (uint32_t k = 0; k < qc.n_deal; k++) {

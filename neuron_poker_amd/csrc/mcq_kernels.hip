@@ -788,7 +788,16 @@ __global__ __launch_bounds__(kExtBlock) void mcq_eval_ext_kernel(const mcq_query
     __shared__ __attribute__((aligned(16))) LdsTablesEval tab;
     __shared__ McqCard cards[64];
     __shared__ McqExtWaveCtx wave_ctx[kExtBlock / 64];
-    __shared__ uint32_t ids[(MCQ_MAX_OPP + 1) * kExtBlock];
+    __shared__ uint16_t ids[(MCQ_MAX_OPP + 1) * kExtBlock];
+    /* The candidate lists of the production mode are read once per trial at a random index: from HBM that is a
+     * dependent ~700-cycle load per trial, several per opponent, and it -- not the arithmetic -- bounded the kernel
+     * (34 000 cycles per wave-iteration at the top quarter of the classes).  So a block first brings the lists of ITS
+     * queries -- a block's waves cover a contiguous piece of the cost axis, hence consecutive queries -- into LDS when
+     * they fit (36 KB beside the tables; 2 B per ordered card pair), and the trials read them there. */
+    constexpr uint32_t kStageEntries = 18u * 1024u, kStageLists = 96u;
+    __shared__ __attribute__((aligned(16))) uint16_t s_lists[kStageEntries];
+    __shared__ uint32_t s_list_off[kStageLists + 1];
+    __shared__ uint32_t s_stage[3]; /* first query, number of queries, staged? */
     if (threadIdx.x < 64) cards[threadIdx.x] = mcq_card(threadIdx.x < 52 ? threadIdx.x : 0u);
     load_tables(tab, g_tab);
 
@@ -798,9 +807,55 @@ __global__ __launch_bounds__(kExtBlock) void mcq_eval_ext_kernel(const mcq_query
     const uint64_t n_waves = (uint64_t)gridDim.x * waves_per_block;
     const uint64_t total = prefix[n];
     const uint64_t lo = total * wave / n_waves, hi = total * (wave + 1ull) / n_waves;
+    if (MODE == MCQ_MODE_PHILOX) {
+        if (threadIdx.x == 0) { /* the block's queries: those whose cost interval meets the block's piece of the axis */
+            const uint64_t blo = total * ((uint64_t)blockIdx.x * waves_per_block) / n_waves;
+            const uint64_t bhi = total * ((uint64_t)(blockIdx.x + 1u) * waves_per_block) / n_waves;
+            uint32_t qa = 0, qb = 0, nq = 0, staged = 0;
+            if (blo < bhi) {
+                uint32_t a = 0, b = n;
+                while (b - a > 1) {
+                    const uint32_t mid = (a + b) >> 1;
+                    if (prefix[mid] <= blo) a = mid; else b = mid;
+                }
+                qa = a;
+                a = qa, b = n;
+                while (b - a > 1) { /* last query that starts before the block's end */
+                    const uint32_t mid = (a + b) >> 1;
+                    if (prefix[mid] < bhi) a = mid; else b = mid;
+                }
+                qb = a;
+                nq = qb - qa + 1u;
+                if ((uint64_t)nq * lists_stride <= kStageLists) {
+                    uint32_t at = 0;
+                    for (uint32_t k = 0; k < nq * lists_stride; k++) {
+                        s_list_off[k] = at;
+                        at += (cnts[(size_t)qa * lists_stride + k] + 1u) & ~1u; /* whole 32-bit words */
+                        if (at > kStageEntries) break;
+                    }
+                    s_list_off[nq * lists_stride] = at;
+                    staged = at <= kStageEntries ? 1u : 0u;
+                }
+            }
+            s_stage[0] = qa;
+            s_stage[1] = nq;
+            s_stage[2] = staged;
+        }
+        __syncthreads();
+        if (s_stage[2]) {
+            const uint32_t qa = s_stage[0], n_l = s_stage[1] * lists_stride;
+            for (uint32_t k = 0; k < n_l; k++) { /* (block-uniform loop; 1024 threads copy 4 KB in one step) */
+                const uint32_t off = s_list_off[k], words = (s_list_off[k + 1] - off) >> 1;
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(lists + ((size_t)qa * lists_stride + k) * MCQ_EXT_LIST_STRIDE);
+                uint32_t *dst = reinterpret_cast<uint32_t *>(s_lists + off);
+                for (uint32_t w = threadIdx.x; w < words; w += blockDim.x) dst[w] = src[w];
+            }
+        }
+        __syncthreads();
+    }
     if (lo >= hi) return;
     McqExtWaveCtx &wc = wave_ctx[threadIdx.x >> 6];
-    uint32_t *my_ids = ids + threadIdx.x;
+    uint16_t *my_ids = ids + threadIdx.x;
 
     uint32_t a = 0, b = n;
     while (b - a > 1) {
@@ -811,7 +866,6 @@ __global__ __launch_bounds__(kExtBlock) void mcq_eval_ext_kernel(const mcq_query
     uint32_t task = 0, n_tasks = 0, weight = 1;
     uint64_t pfx = 0;
     McqExtCtx qc;
-    const uint16_t *my_lists = lists;
     WaveTally tally;
     tally.clear();
     bool failed = false, fresh = true;
@@ -837,12 +891,15 @@ __global__ __launch_bounds__(kExtBlock) void mcq_eval_ext_kernel(const mcq_query
                     if (lane < MCQ_EXT_MAX_LISTS) {
                         c = lane < n_lists ? cnts[(size_t)qi * lists_stride + lane] : 1u;
                         wc.cnt[lane] = c;
+                        const uint16_t *lp = lists + ((size_t)qi * lists_stride + (lane < lists_stride ? lane : 0u)) * MCQ_EXT_LIST_STRIDE;
+                        if (s_stage[2] && qi - s_stage[0] < s_stage[1] && lane < lists_stride)
+                            lp = s_lists + s_list_off[(qi - s_stage[0]) * lists_stride + lane];
+                        wc.list[lane] = lp;
                     }
                     if (__any(c == 0u)) { /* a range no pair of cards can satisfy: nothing to deal from */
                         failed = true;
                         ok = false;
                     }
-                    my_lists = lists + (size_t)qi * lists_stride * MCQ_EXT_LIST_STRIDE;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -870,8 +927,7 @@ __global__ __launch_bounds__(kExtBlock) void mcq_eval_ext_kernel(const mcq_query
                 dr.start(seed, first_qid + qi, stream);
                 const uint32_t cnt = (uint32_t)min((uint64_t)MCQ_STREAM_ITERS, (uint64_t)qc.runs - it0);
                 for (uint32_t j = 0; j < cnt && !failed; j++)
-                    failed = !mcq_iteration_ext(qc, wc, dr, cards, tab.sel8, my_lists, my_ids, kExtBlock, g_tab->tf, tab.tops,
-                                                tab.sd, acc);
+                    failed = !mcq_iteration_ext(qc, wc, dr, cards, tab.sel8, my_ids, kExtBlock, g_tab->tf, tab.tops, tab.sd, acc);
             }
         } else {
             const uint64_t stride = (qc.runs + 63u) & ~63ull;
@@ -880,7 +936,7 @@ __global__ __launch_bounds__(kExtBlock) void mcq_eval_ext_kernel(const mcq_query
                 const uint64_t it = (uint64_t)task * MCQ_TASK_ITERS + j * MCQ_WAVE + lane;
                 if (it < qc.runs) {
                     McqExtReplayDraws dr = {dbase + it, stride};
-                    mcq_iteration_ext(qc, wc, dr, cards, tab.sel8, my_lists, my_ids, kExtBlock, g_tab->tf, tab.tops, tab.sd, acc);
+                    mcq_iteration_ext(qc, wc, dr, cards, tab.sel8, my_ids, kExtBlock, g_tab->tf, tab.tops, tab.sd, acc);
                 }
             }
             acc.passes = 0;

@@ -169,16 +169,19 @@ struct Shard {
     int group = 0;       /* index of this shard's device among the distinct devices */
     bool primary = false; /* first shard on its device: holds the device's sum and takes part in the all-reduce */
     DevBuf tally;        /* [n, 13] uint64 on the shard's device */
+    mcq_result *matrix = nullptr; /* the matrix of the call in flight: tally.p or the caller's buffer on this device */
     hipEvent_t launched = nullptr;
     Worker worker;
 };
 
 struct Call { /* arguments of the call in flight, read by the workers */
     struct mcq_multi *m;
-    const mcq_query *q;
+    const mcq_query *q; /* host buffers (mcq_multi_eval_batch) ... */
     size_t n;
     uint64_t seed, first_qid;
     int partition;
+    const void *const *d_q = nullptr; /* ... or one device pointer pair per shard (mcq_multi_eval_batch_device) */
+    void *const *d_res = nullptr;
 };
 
 }  // namespace
@@ -216,8 +219,14 @@ int shard_job(void *arg, int s) {
     const size_t k = m->shards.size(), n = cl.n;
     McqDeviceScope dev(sh.device);
     HIP_TRY(dev.err);
-    HIP_TRY(sh.tally.reserve(n * sizeof(mcq_result)));
-    HIP_TRY(hipMemsetAsync(sh.tally.p, 0, n * sizeof(mcq_result), c->stream));
+    /* the shard's matrix: its own buffer, or the caller's on this shard's device */
+    mcq_result *tally = cl.d_res ? static_cast<mcq_result *>(cl.d_res[s]) : nullptr;
+    if (!tally) {
+        HIP_TRY(sh.tally.reserve(n * sizeof(mcq_result)));
+        tally = (mcq_result *)sh.tally.p;
+    }
+    sh.matrix = tally;
+    HIP_TRY(hipMemsetAsync(tally, 0, n * sizeof(mcq_result), c->stream));
     size_t lo = 0, hi = n;
     uint32_t part = 0, n_parts = 1;
     if (cl.partition == MCQ_PARTITION_QUERIES) {
@@ -229,7 +238,11 @@ int shard_job(void *arg, int s) {
     }
     const size_t cnt = hi - lo;
     c->last_ms = 0.f;
-    if (cnt) {
+    if (cnt && cl.d_q) { /* queries resident in this shard's HBM: priced by the prep kernel (the host has not seen them) */
+        int rc = mcq_run_slice(c, MCQ_MODE_PHILOX, static_cast<const mcq_query *>(cl.d_q[s]), (uint32_t)cnt, tally + lo, cl.seed,
+                               cl.first_qid + lo, 0, nullptr, nullptr, c->stream, true, 0, part, n_parts);
+        if (rc) return rc;
+    } else if (cnt) {
         uint64_t total_tasks = 0, max_tasks = 0;
         for (size_t i = lo; i < hi; i++) {
             const McqPart pt = mcq_part(mcq_tasks_of(cl.q[i]), cl.q[i].runs, part, n_parts);
@@ -242,7 +255,7 @@ int shard_job(void *arg, int s) {
         HIP_TRY(c->d_q.reserve(cnt * sizeof(mcq_query)));
         memcpy(c->h_q.p, cl.q + lo, cnt * sizeof(mcq_query));
         HIP_TRY(hipMemcpyAsync(c->d_q.p, c->h_q.p, cnt * sizeof(mcq_query), hipMemcpyHostToDevice, c->stream));
-        int rc = mcq_run_slice(c, MCQ_MODE_PHILOX, (const mcq_query *)c->d_q.p, (uint32_t)cnt, (mcq_result *)sh.tally.p + lo,
+        int rc = mcq_run_slice(c, MCQ_MODE_PHILOX, (const mcq_query *)c->d_q.p, (uint32_t)cnt, tally + lo,
                                cl.seed, cl.first_qid + lo, total_tasks, nullptr, nullptr, c->stream, true, max_tasks, part,
                                n_parts);
         if (rc) return rc;
@@ -252,18 +265,20 @@ int shard_job(void *arg, int s) {
 }
 
 int multi_eval(mcq_multi *m, const mcq_query *q, size_t n, uint64_t seed, uint64_t first_qid, int partition,
-               mcq_result *out) {
+               mcq_result *out, const void *const *d_q = nullptr, void *const *d_res = nullptr) {
     const auto t0 = std::chrono::steady_clock::now();
     const size_t k = m->shards.size();
-    int rc = mcq_validate_queries(q, n);
-    if (rc) return rc;
-    uint64_t total_tasks = 0;
-    for (size_t i = 0; i < n; i++) total_tasks += mcq_tasks_of(q[i]);
-    if (total_tasks > 0xfffffff0ull) return mcq_fail(MCQ_EINVAL, "mcq_multi_eval_batch: too many iterations in one call");
+    if (q) {
+        int rc = mcq_validate_queries(q, n);
+        if (rc) return rc;
+        uint64_t total_tasks = 0;
+        for (size_t i = 0; i < n; i++) total_tasks += mcq_tasks_of(q[i]);
+        if (total_tasks > 0xfffffff0ull) return mcq_fail(MCQ_EINVAL, "mcq_multi_eval_batch: too many iterations in one call");
+    }
     if (partition == MCQ_PARTITION_AUTO) /* block-distribute the queries when there are >= 256 per shard */
         partition = n >= k * 256u ? MCQ_PARTITION_QUERIES : MCQ_PARTITION_ITERATIONS;
     m->last_partition = partition;
-    m->call = Call{m, q, n, seed, first_qid, partition};
+    m->call = Call{m, q, n, seed, first_qid, partition, d_q, d_res};
 
     /* 1. every shard enqueues its work from its own thread (shard 0: this thread) */
     for (size_t s = 1; s < k; s++) m->shards[s].worker.submit(shard_job, &m->call);
@@ -292,7 +307,7 @@ int multi_eval(mcq_multi *m, const mcq_query *q, size_t n, uint64_t seed, uint64
         McqDeviceScope dev(pr.device);
         HIP_TRY(dev.err);
         HIP_TRY(hipStreamWaitEvent(pr.ctx->stream, sh.launched, 0));
-        HIP_TRY(mcq_launch_add_u64((uint64_t *)pr.tally.p, (const uint64_t *)sh.tally.p, words, pr.ctx->stream));
+        HIP_TRY(mcq_launch_add_u64((uint64_t *)pr.matrix, (const uint64_t *)sh.matrix, words, pr.ctx->stream));
     }
 
     /* 3. the path's one collective: integer sum of the tally matrices over the distinct devices */
@@ -305,7 +320,7 @@ int multi_eval(mcq_multi *m, const mcq_query *q, size_t n, uint64_t seed, uint64
     NCCL_TRY(m, m->rccl->GroupStart());
     for (size_t g = 0; g < m->devices.size(); g++) {
         Shard &pr = m->shards[(size_t)m->primary_shard[g]];
-        ncclResult_t r = m->rccl->AllReduce(pr.tally.p, pr.tally.p, (size_t)words, ncclUint64, ncclSum, m->comms[g],
+        ncclResult_t r = m->rccl->AllReduce(pr.matrix, pr.matrix, (size_t)words, ncclUint64, ncclSum, m->comms[g],
                                             pr.ctx->stream);
         if (r != ncclSuccess) {
             (void)m->rccl->GroupEnd();
@@ -320,16 +335,26 @@ int multi_eval(mcq_multi *m, const mcq_query *q, size_t n, uint64_t seed, uint64
         McqDeviceScope dev(p0.device);
         HIP_TRY(dev.err);
         HIP_TRY(hipEventRecord(m->ar1, p0.ctx->stream));
-        HIP_TRY(m->h_out.reserve(n * sizeof(mcq_result)));
-        HIP_TRY(hipMemcpyAsync(m->h_out.p, p0.tally.p, n * sizeof(mcq_result), hipMemcpyDeviceToHost, p0.ctx->stream));
+        if (out) {
+            HIP_TRY(m->h_out.reserve(n * sizeof(mcq_result)));
+            HIP_TRY(hipMemcpyAsync(m->h_out.p, p0.matrix, n * sizeof(mcq_result), hipMemcpyDeviceToHost, p0.ctx->stream));
+        }
     }
+    if (d_res) /* device entry: every shard's buffer gets the complete matrix -- the primary's own copy on a shared device */
+        for (Shard &sh : m->shards) {
+            if (sh.primary) continue;
+            Shard &pr = m->shards[(size_t)m->primary_shard[(size_t)sh.group]];
+            McqDeviceScope dev(pr.device);
+            HIP_TRY(dev.err);
+            HIP_TRY(hipMemcpyAsync(sh.matrix, pr.matrix, n * sizeof(mcq_result), hipMemcpyDeviceToDevice, pr.ctx->stream));
+        }
     for (size_t g = 0; g < m->devices.size(); g++) {
         Shard &pr = m->shards[(size_t)m->primary_shard[g]];
         McqDeviceScope dev(pr.device);
         HIP_TRY(dev.err);
         HIP_TRY(hipStreamSynchronize(pr.ctx->stream));
     }
-    memcpy(out, m->h_out.p, n * sizeof(mcq_result));
+    if (out) memcpy(out, m->h_out.p, n * sizeof(mcq_result));
 
     float kmax = 0.f;
     for (Shard &sh : m->shards) {
@@ -460,6 +485,26 @@ int mcq_multi_eval_batch(mcq_multi *m, const mcq_query *q, size_t n, uint64_t se
     if (n > 0x7fffffffu) return mcq_fail(MCQ_EINVAL, "mcq_multi_eval_batch: n too large");
     return multi_eval(m, q, n, seed, first_query_id, partition, out);
     ABI_GUARD_END("mcq_multi_eval_batch")
+}
+
+int mcq_multi_eval_batch_device(mcq_multi *m, const void *const *d_queries, size_t n, uint64_t seed, uint64_t first_query_id,
+                                int partition, void *const *d_results) {
+    ABI_GUARD_BEGIN
+    if (!m) return mcq_fail(MCQ_EINVAL, "mcq_multi_eval_batch_device: null object");
+    if (partition != MCQ_PARTITION_AUTO && partition != MCQ_PARTITION_QUERIES && partition != MCQ_PARTITION_ITERATIONS)
+        return mcq_fail(MCQ_EINVAL, "mcq_multi_eval_batch_device: bad partition");
+    if (n == 0) return MCQ_OK;
+    if (!d_queries || !d_results) return mcq_fail(MCQ_EINVAL, "mcq_multi_eval_batch_device: null buffer");
+    if (n > 0x7fffffffu) return mcq_fail(MCQ_EINVAL, "mcq_multi_eval_batch_device: n too large");
+    const size_t k = m->shards.size();
+    const int eff = partition != MCQ_PARTITION_AUTO ? partition : (n >= k * 256u ? MCQ_PARTITION_QUERIES : MCQ_PARTITION_ITERATIONS);
+    for (size_t s = 0; s < k; s++) {
+        const bool has_work = eff != MCQ_PARTITION_QUERIES || shard_lo(n, s + 1, k) > shard_lo(n, s, k);
+        if (!d_results[s] || (has_work && !d_queries[s]))
+            return mcq_fail(MCQ_EINVAL, "mcq_multi_eval_batch_device: null device pointer of a shard");
+    }
+    return multi_eval(m, nullptr, n, seed, first_query_id, partition, nullptr, d_queries, d_results);
+    ABI_GUARD_END("mcq_multi_eval_batch_device")
 }
 
 int mcq_multi_info(const mcq_multi *m, int info[4]) {

@@ -193,13 +193,14 @@ extern "C" int hs_run_ext(int replay, const mcq_query *q, const mcq_query_ext *e
         for (uint32_t c = 0; c < 2704u; c++)
             if (mcq_ext_candidate(U, er.w + set_off, c)) lists[(size_t)li * MCQ_EXT_LIST_STRIDE + cnt++] = (uint16_t)((c / 52u) | ((c % 52u) << 8));
         wc.cnt[li] = cnt;
+        wc.list[li] = lists.data() + (size_t)li * MCQ_EXT_LIST_STRIDE;
         if (cnt == 0 && !replay) return MCQ_EINVAL;
     }
     McqCard cards[64];
     for (uint32_t c = 0; c < 64; c++) cards[c] = mcq_card(c < 52 ? c : 0);
     memset(out, 0, sizeof(*out));
     out->runs = q->runs;
-    uint32_t ids[MCQ_MAX_OPP + 1];
+    uint16_t ids[MCQ_MAX_OPP + 1];
     if (replay) {
         size_t stride = q->runs ? q->runs : 1;
         std::vector<uint8_t> draws((size_t)mcq_ext_draws_per_iteration(*q, *e) * stride + 1);
@@ -211,7 +212,7 @@ extern "C" int hs_run_ext(int replay, const mcq_query *q, const mcq_query_ext *e
         for (uint32_t it = 0; it < q->runs; it++) {
             McqExtReplayDraws dr = {draws.data() + it, stride};
             McqLaneAcc acc = {0, 0, 0};
-            mcq_iteration_ext(qc, wc, dr, cards, t.sel8, lists.data(), ids, 1, t.tf, t.tops, t.sd, acc);
+            mcq_iteration_ext(qc, wc, dr, cards, t.sel8, ids, 1, t.tf, t.tops, t.sd, acc);
             acc.passes = 0;
             fold(acc, out);
         }
@@ -224,7 +225,7 @@ extern "C" int hs_run_ext(int replay, const mcq_query *q, const mcq_query_ext *e
         McqLaneAcc acc = {0, 0, 0};
         for (uint32_t j = 0; j < MCQ_STREAM_ITERS; j++) {
             if ((uint64_t)s * MCQ_STREAM_ITERS + j >= q->runs) break;
-            if (!mcq_iteration_ext(qc, wc, dr, cards, t.sel8, lists.data(), ids, 1, t.tf, t.tops, t.sd, acc))
+            if (!mcq_iteration_ext(qc, wc, dr, cards, t.sel8, ids, 1, t.tf, t.tops, t.sd, acc))
                 return MCQ_EINVAL;
         }
         fold(acc, out);

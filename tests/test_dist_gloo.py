@@ -13,6 +13,7 @@ import torch.distributed as dist  # noqa: E402
 import torch.multiprocessing as mp  # noqa: E402
 
 from neuron_poker_amd import sharding  # noqa: E402
+import neuron_poker_amd as npa  # noqa: E402
 from neuron_poker_amd._lib import pack_queries  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
@@ -100,3 +101,19 @@ def test_single_process_without_group():
     q = _batch()[:5]
     t = sharding.eval_batch_sharded(q, 3, _oracle_eval(O.MODE_CTR))
     assert np.array_equal(t, _oracle_eval(O.MODE_CTR)(q, 3, 0))
+
+
+def test_launcher_hands_a_failing_rank_through_and_prints_no_json_line():
+    """`python bench.py --gpus 2` starts its ranks as a child torch.distributed.run.  Where the ranks cannot run (no GPU
+    in this container: the engine refuses to start without a HIP device -- there is no CPU fallback) the command must
+    fail with the child's exit code and must not print a JSON result line."""
+    import subprocess
+    import sys
+    if npa.load_library().mcq_device_count() > 0:
+        pytest.skip("a GPU is present: the ranks would run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--states", "8", "--iters", "100", "--no-cpu-baseline", "--no-extras"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.lstrip().startswith("{")], r.stdout[-500:]

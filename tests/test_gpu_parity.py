@@ -826,6 +826,57 @@ def test_bench_rccl_branch_runs_on_this_gpu():
     assert len(line) == 1, out.stdout
     d = _json.loads(line[0])
     assert d["n_gpus"] == 1 and "RCCL all-reduce" in d["config"]["workload"] and d["value"] > 0
+    assert d["collective"]["ranks"] == 1 and d["collective"]["all_reduce_ms"] > 0 and "roofline" in d
+
+
+def test_bench_native_multi_prints_the_same_keys():
+    """`bench.py --native-multi` (ONE process, mcq_multi_eval_batch_device: shards -> one ncclAllReduce) rehearsed with two
+    shards on this GPU: one JSON line with the keys of the one-rank-per-GPU line (roofline, collective)."""
+    import json as _json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--native-multi", "--single-device", "--gpus", "2",
+                          "--steps", "2", "--warmup", "1", "--states", "256", "--iters", "3000"],
+                         capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [x for x in out.stdout.splitlines() if x.startswith("{")]
+    assert len(line) == 1, out.stdout
+    d = _json.loads(line[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["collective"]["all_reduce_ms"] >= 0 and d["roofline"]["kernel_ms"] > 0 and d["native_multi"]["kernel_max_ms"] > 0
+
+
+def test_multi_gpu_device_entry_equals_single_context(eng):
+    """mcq_multi_eval_batch_device: queries and results resident in HBM, one pointer pair per shard (here all shards on
+    the one GPU; on a multi-GPU lease also one shard per device): every shard's buffer ends up holding the complete
+    matrix, equal to mcq_eval_batch on one context."""
+    import torch
+    g = np.random.default_rng(77)
+    B = 600
+    hole = np.array([g.permutation(52)[:2] for _ in range(B)], np.uint8)
+    q = npa.pack_queries(hole, np.full((B, 5), 255, np.uint8), 1 + np.arange(B) % 6, g.choice([1, 500, 1024, 2100], B))
+    want = u64(eng.eval_batch(q, seed=5, first_query_id=9))
+    raw = q.view(np.uint8).reshape(B, 16)
+    n_dev = npa.load_library().mcq_device_count()
+    layouts = [[0], [0, 0], [0, 0, 0]] + ([list(range(n_dev))] if n_dev > 1 else [])
+    for devices in layouts:
+        k = len(devices)
+        me = npa.MultiEngine(devices)
+        try:
+            for part in ("queries", "iterations"):
+                qs, rs = [], []
+                for s, d in enumerate(devices):
+                    lo, hi = (B * s // k, B * (s + 1) // k) if part == "queries" else (0, B)
+                    qs.append(torch.from_numpy(raw[lo:hi].copy()).to("cuda:%d" % d))
+                    rs.append(torch.full((B, 13), -1, dtype=torch.int64, device="cuda:%d" % d))
+                torch.cuda.synchronize()
+                me.eval_batch_device([t.data_ptr() if t.numel() else 0 for t in qs], B, 5, [t.data_ptr() for t in rs],
+                                     first_query_id=9, partition=part)
+                for t in rs:
+                    assert np.array_equal(t.cpu().numpy().view(np.uint64), want), (devices, part)
+        finally:
+            me.close()
 
 
 def test_multi_gpu_entry_partitions_equal_single_context(eng):
@@ -845,13 +896,19 @@ def test_multi_gpu_entry_partitions_equal_single_context(eng):
     q = npa.pack_queries(hole, board, npl, runs)
     want = u64(eng.eval_batch(q, seed=11, first_query_id=500))
     assert np.array_equal(want, O.run_batch(O.MODE_CTR, q.view(np.uint8).reshape(-1, 16), 11, first_qid=500, threads=8))
-    for shards in (1, 2, 3, 8):
-        me = npa.MultiEngine([0] * shards)
+    n_dev = npa.load_library().mcq_device_count()
+    layouts = [[0] * shards for shards in (1, 2, 3, 8)]
+    if n_dev > 1:   # a multi-GPU lease: every visible device once, and twice (the cross-device all-reduce for real)
+        layouts += [list(range(n_dev)), list(range(n_dev)) * 2]
+    for devices in layouts:
+        shards = len(devices)
+        me = npa.MultiEngine(devices)
         try:
             for part in ("queries", "iterations", "auto"):
                 got = u64(me.eval_batch(q, seed=11, first_query_id=500, partition=part))
-                assert np.array_equal(got, want), (shards, part)
+                assert np.array_equal(got, want), (devices, part)
             assert me.info["last_partition"] == "iterations"      # 41 < 256 * shards
+            assert me.info["devices"] == len(set(devices))
             assert np.array_equal(u64(me.eval_batch(q[:2], seed=11, first_query_id=500, partition="queries")), want[:2])
             bad = q.copy()
             bad["hole"][7] = (3, 3)
