@@ -610,23 +610,8 @@ static int eval_host_philox(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t s
             work_rec = reinterpret_cast<mcq_query *>(karg.rec);
             work_qi = karg.qi;
         }
-        memset(work_qi, 0xFF, a_words * sizeof(uint32_t)); /* MCQ_DIRECT_IDLE */
-        {   /* as two 64-bit words per record (reserved[0], reserved[1] = bytes 1, 2 of the second): a byte patched into
-             * a struct that is then copied whole stalls on the store it has just made */
-            static_assert(offsetof(mcq_query, reserved) == 9 && sizeof(mcq_query) == 16, "record words");
-            unsigned char *rec_bytes = reinterpret_cast<unsigned char *>(work_rec);
-            for (size_t i = 0; i < n; i++) {
-                uint64_t w[2];
-                memcpy(w, &q[i], 16);
-                const uint32_t l = lay.lg[i], at = lay.slot0[i];
-                w[1] |= (uint64_t)l << 8;
-                for (uint32_t sub = 0; sub < (1u << l); sub++) {
-                    const uint64_t o[2] = {w[0], w[1] | ((uint64_t)sub << 16)};
-                    memcpy(rec_bytes + 16u * (size_t)(at + sub), o, 16); /* (one 16-byte store) */
-                    work_qi[at + sub] = (uint32_t)i;
-                }
-            }
-        }
+        if (!mcq_direct_write_records(lay, q, n, work_rec, work_qi, by_karg ? (size_t)MCQ_DIRECT_KARG_SLOTS : a_cap))
+            return mcq_fail(MCQ_EDEVICE, who, "internal: wave layout does not fit its slots");
         rc = flag_ready(c);
         if (rc) return rc;
         const uint32_t ticket = next_ticket(c);
@@ -908,8 +893,24 @@ int mcq_exact_batch(mcq_ctx *c, const mcq_query *q, size_t n, int law, mcq_resul
     c->res_clean = 0;
     HIP_TRY(c->h_res.reserve(n * sizeof(mcq_result)));
     HIP_TRY(hipMemsetAsync(c->d_res.p, 0, n * sizeof(mcq_result), c->stream));
+    /* one launch per kind (two opponents / fewer) and 65 535 queries: the jobs travel in pinned memory */
+    HIP_TRY(c->h_misc.reserve(n * sizeof(McqExactJob)));
+    McqExactJob *jobs = static_cast<McqExactJob *>(c->h_misc.p);
+    const McqExactJob *d_jobs = static_cast<const McqExactJob *>(c->h_misc.dev);
+    size_t n_two = 0;
+    for (size_t i = 0; i < n; i++) /* the two-opponent queries first, the others behind them */
+        if (q[i].n_players == 3) mcq_exact_plan(&q[i], (uint32_t)i, (uint32_t)c->n_cu, &jobs[n_two++]);
+    size_t at = n_two;
     for (size_t i = 0; i < n; i++)
-        HIP_TRY(mcq_launch_exact(&q[i], law, (mcq_result *)c->d_res.p + i, c->d_luts, (uint32_t)c->n_cu, c->stream));
+        if (q[i].n_players != 3) mcq_exact_plan(&q[i], (uint32_t)i, (uint32_t)c->n_cu, &jobs[at++]);
+    for (size_t a = 0; a < n;) {
+        const bool two = a < n_two;
+        const size_t end = two ? n_two : n, b = a + 65535u < end ? a + 65535u : end;
+        uint32_t max_grid = 0;
+        for (size_t i = a; i < b; i++) max_grid = jobs[i].grid > max_grid ? jobs[i].grid : max_grid;
+        HIP_TRY(mcq_launch_exact(d_jobs + a, (uint32_t)(b - a), max_grid, two, law, (mcq_result *)c->d_res.p, c->d_luts, c->stream));
+        a = b;
+    }
     HIP_TRY(hipMemcpyAsync(c->h_res.p, c->d_res.p, n * sizeof(mcq_result), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     memcpy(out, c->h_res.p, n * sizeof(mcq_result));

@@ -15,9 +15,15 @@ hipError_t mcq_launch_eval(int mode, const mcq_query *d_q, uint32_t n, const uin
                            uint64_t seed, uint64_t first_qid, const McqTables *d_luts, const uint8_t *d_draws,
                            const uint64_t *d_draw_off, uint32_t grid, uint32_t block, uint32_t split, uint32_t part,
                            uint32_t n_parts, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr, uint32_t work_wpb = 0);
-/* exact enumeration of ONE query (host pointer q; n_players <= 3): adds into the zeroed row d_row */
-hipError_t mcq_launch_exact(const mcq_query *q, int law, mcq_result *d_row, const McqTables *d_luts, uint32_t n_cu,
-                            hipStream_t s);
+/* exact enumeration (n_players <= 3), any number of queries per launch: one job per query (blockIdx.y), all of the same
+ * kind -- two opponents or fewer; every job adds into its zeroed row d_rows[job.row] */
+struct McqExactJob {
+    uint32_t rec[4];                        /* the 16-byte query record */
+    uint32_t n_boards, slices, row, grid;   /* table completions, cuts of the first-opponent loop, result row, blocks that work */
+};
+void mcq_exact_plan(const mcq_query *q, uint32_t row, uint32_t n_cu, McqExactJob *job);
+hipError_t mcq_launch_exact(const McqExactJob *d_jobs, uint32_t n_jobs, uint32_t max_grid, bool two_opp, int law,
+                            mcq_result *d_rows, const McqTables *d_luts, hipStream_t s);
 /* hands / winner / wtype / keys: device-visible memory (pinned host memory or HBM), 16-byte aligned and padded to whole
  * tiles of 256 tables; *bad is set when a hand is not seven distinct ids < 52; ticket != 0: the last block raises
  * *done_flag behind a system-scope release (d_done: a zeroed device word) */

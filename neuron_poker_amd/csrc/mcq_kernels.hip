@@ -1038,9 +1038,15 @@ __global__ __launch_bounds__(kShowBlock) void mcq_showdown_kernel(const uint8_t 
 // weight (-> runs), lane 2 strict wins, lane 3 ties, lane 4 + t hero's winning hand type t; one atomic each
 // at the end.
 template <bool TWO_OPP>
-__global__ __launch_bounds__(TWO_OPP ? 384 : 1024) void mcq_exact_kernel(uint4 raw, int law, uint32_t n_boards,
-                                                                        uint32_t slices, mcq_result *__restrict__ row,
+__global__ __launch_bounds__(TWO_OPP ? 384 : 1024) void mcq_exact_kernel(const McqExactJob *__restrict__ jobs, int law,
+                                                                        mcq_result *__restrict__ rows,
                                                                         const McqTables *__restrict__ g_tab) {
+    /* blockIdx.y = the job (one query); its first `grid` blocks work, the others leave at once */
+    const McqExactJob job = jobs[blockIdx.y];
+    if (blockIdx.x >= job.grid) return;
+    const uint4 raw = make_uint4(job.rec[0], job.rec[1], job.rec[2], job.rec[3]);
+    const uint32_t n_boards = job.n_boards, slices = job.slices;
+    mcq_result *row = rows + job.row;
     constexpr uint32_t kWaves = TWO_OPP ? 6u : 16u; /* what fits beside the 97 KB of tables */
     __shared__ __attribute__((aligned(16))) LdsTablesEval tab; /* tf from global memory, as in the evaluation kernels */
     __shared__ uint16_t pair_xy[MCQ_EXACT_PAIRS + 2];
@@ -1061,7 +1067,7 @@ __global__ __launch_bounds__(TWO_OPP ? 384 : 1024) void mcq_exact_kernel(uint4 r
     if (!mcq_exact_query(q, law, e)) return; /* the host has validated the query */
     const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * kWaves + wib);
-    const uint32_t n_waves = gridDim.x * kWaves;
+    const uint32_t n_waves = job.grid * kWaves;
     McqCard *rem_card = rem_card_all[wib];
     uint32_t *rem_pos = rem_pos_all[wib];
     uint32_t *keys = TWO_OPP ? keys_all[wib] : nullptr;
@@ -1234,23 +1240,32 @@ hipError_t mcq_launch_showdown(const uint8_t *hands, uint32_t n_tables, uint32_t
     return hipGetLastError();
 }
 
-hipError_t mcq_launch_exact(const mcq_query *q, int law, mcq_result *d_row, const McqTables *d_luts, uint32_t n_cu,
-                            hipStream_t s) {
-    uint4 raw;
-    __builtin_memcpy(&raw, q, 16);
+void mcq_exact_plan(const mcq_query *q, uint32_t row, uint32_t n_cu, McqExactJob *job) {
+    __builtin_memcpy(job->rec, q, 16);
     const uint32_t L = 50u - q->n_board, k = 5u - q->n_board;
-    const uint32_t n_boards = mcq_exact_binom(L, k);
+    job->n_boards = mcq_exact_binom(L, k);
+    job->row = row;
     if (q->n_players == 3) {
         /* few completions (turn, river): cut the first-opponent loop so that every wave has work */
         uint32_t slices = 1;
-        while (slices < 64u && (uint64_t)n_boards * slices < 6ull * n_cu * 4ull) slices *= 2u;
-        const uint64_t units = (uint64_t)n_boards * slices;
-        const uint32_t grid = (uint32_t)((units + 5u) / 6u < n_cu ? (units + 5u) / 6u : n_cu);
-        hipLaunchKernelGGL(mcq_exact_kernel<true>, dim3(grid), dim3(384), 0, s, raw, law, n_boards, slices, d_row, d_luts);
+        while (slices < 64u && (uint64_t)job->n_boards * slices < 6ull * n_cu * 4ull) slices *= 2u;
+        const uint64_t units = (uint64_t)job->n_boards * slices;
+        job->slices = slices;
+        job->grid = (uint32_t)((units + 5u) / 6u < n_cu ? (units + 5u) / 6u : n_cu);
     } else {
-        const uint32_t grid = (n_boards + 15u) / 16u < n_cu ? (n_boards + 15u) / 16u : n_cu;
-        hipLaunchKernelGGL(mcq_exact_kernel<false>, dim3(grid), dim3(1024), 0, s, raw, law, n_boards, 1u, d_row, d_luts);
+        job->slices = 1u;
+        job->grid = (job->n_boards + 15u) / 16u < n_cu ? (job->n_boards + 15u) / 16u : n_cu;
     }
+}
+
+hipError_t mcq_launch_exact(const McqExactJob *d_jobs, uint32_t n_jobs, uint32_t max_grid, bool two_opp, int law,
+                            mcq_result *d_rows, const McqTables *d_luts, hipStream_t s) {
+    if (n_jobs == 0) return hipSuccess;
+    if (n_jobs > 65535u || max_grid == 0) return hipErrorInvalidValue;
+    if (two_opp)
+        hipLaunchKernelGGL(mcq_exact_kernel<true>, dim3(max_grid, n_jobs), dim3(384), 0, s, d_jobs, law, d_rows, d_luts);
+    else
+        hipLaunchKernelGGL(mcq_exact_kernel<false>, dim3(max_grid, n_jobs), dim3(1024), 0, s, d_jobs, law, d_rows, d_luts);
     return hipGetLastError();
 }
 

@@ -10,7 +10,11 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <string.h>
+
 #include <vector>
+
+#include "../../include/mcq.h"
 
 #define MCQ_LAYOUT_IDLE 0xFFFFFFFFu
 #define MCQ_LAYOUT_WAVES 16u /* waves of a block */
@@ -77,4 +81,29 @@ static inline void mcq_direct_layout_slots(const McqDirectLayout &L, uint32_t *s
             slot_qi[L.slot0[i] + sub] = (uint32_t)i;
             slot_sub[L.slot0[i] + sub] = (uint8_t)sub;
         }
+}
+
+/* The work of a launch as mcq_eval_direct_kernel reads it: per wave slot a copy of the query's 16-byte record whose
+ * reserved bytes carry log2(waves of the query) and the wave's cut number, and the query's index (MCQ_LAYOUT_IDLE for a
+ * slot without work).  rec / qi hold `cap` slots: false (nothing written) when the layout needs more.  Written as two
+ * 64-bit words per record: a byte patched into a struct that is then copied whole stalls on its own store. */
+static inline bool mcq_direct_write_records(const McqDirectLayout &L, const mcq_query *q, size_t n, void *rec, uint32_t *qi,
+                                            size_t cap) {
+    static_assert(offsetof(mcq_query, reserved) == 9 && sizeof(mcq_query) == 16, "record words");
+    if (L.slots > cap || L.lg.size() != n || L.slot0.size() != n) return false;
+    memset(qi, 0xFF, L.slots * sizeof(uint32_t)); /* MCQ_LAYOUT_IDLE */
+    unsigned char *rec_bytes = static_cast<unsigned char *>(rec);
+    for (size_t i = 0; i < n; i++) {
+        uint64_t w[2];
+        memcpy(w, &q[i], 16);
+        const uint32_t l = L.lg[i], at = L.slot0[i];
+        if ((size_t)at + (1u << l) > L.slots) return false;
+        w[1] |= (uint64_t)l << 8; /* reserved[0] */
+        for (uint32_t sub = 0; sub < (1u << l); sub++) {
+            const uint64_t o[2] = {w[0], w[1] | ((uint64_t)sub << 16)}; /* reserved[1] */
+            memcpy(rec_bytes + 16u * (size_t)(at + sub), o, 16);
+            qi[at + sub] = (uint32_t)i;
+        }
+    }
+    return true;
 }

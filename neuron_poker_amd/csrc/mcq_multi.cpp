@@ -28,6 +28,7 @@
 #include "mcq_ctx.hpp"
 #include "mcq_device.hpp"
 #include "mcq_internal.hpp"
+#include "mcq_worker.hpp"
 
 namespace {
 
@@ -104,65 +105,6 @@ const Rccl *rccl_get(std::string *error /* out: why not, copied while the lock i
     return nullptr;
 }
 
-/* one worker thread per shard: runs the closure handed to it, then reports back */
-struct Worker {
-    std::thread th;
-    std::mutex mu;
-    std::condition_variable cv;
-    bool has_job = false, stop = false, done = true;
-    int (*fn)(void *, int) = nullptr;
-    void *arg = nullptr;
-    int index = 0, rc = 0;
-    std::string err;
-
-    void start(int idx) {
-        index = idx;
-        th = std::thread([this] { loop(); });
-    }
-    void loop() {
-        std::unique_lock<std::mutex> lk(mu);
-        for (;;) {
-            cv.wait(lk, [this] { return has_job || stop; });
-            if (stop) return;
-            has_job = false;
-            lk.unlock();
-            int r;
-            try {
-                r = fn(arg, index);
-            } catch (...) {
-                r = mcq_fail(MCQ_EDEVICE, "mcq_multi: exception in a shard worker");
-            }
-            const char *e = r ? mcq_last_error() : "";
-            lk.lock();
-            rc = r;
-            err = e;
-            done = true;
-            cv.notify_all();
-        }
-    }
-    void submit(int (*f)(void *, int), void *a) {
-        std::lock_guard<std::mutex> lk(mu);
-        fn = f;
-        arg = a;
-        has_job = true;
-        done = false;
-        cv.notify_all();
-    }
-    int wait() {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [this] { return done; });
-        return rc;
-    }
-    void join() {
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            stop = true;
-            cv.notify_all();
-        }
-        if (th.joinable()) th.join();
-    }
-};
-
 struct Shard {
     mcq_ctx *ctx = nullptr;
     int device = 0;
@@ -171,7 +113,7 @@ struct Shard {
     DevBuf tally;        /* [n, 13] uint64 on the shard's device */
     mcq_result *matrix = nullptr; /* the matrix of the call in flight: tally.p or the caller's buffer on this device */
     hipEvent_t launched = nullptr;
-    Worker worker;
+    McqWorker worker;
 };
 
 struct Call { /* arguments of the call in flight, read by the workers */

@@ -176,3 +176,21 @@ def direct_layout(cost, n_cu=256, max_lg=4):
     assert rounds != 0xFFFFFFFF
     slots = rounds * grid.value * 16
     return grid.value, rounds, lg[:n], qi[:slots], sub[:slots]
+
+
+def direct_records(cost, queries16, n_cu=256, max_lg=4, cap=None):
+    """The per-wave work records the library writes for mcq_eval_direct_kernel (mcq_layout.hpp): (rec [slots, 16] u8,
+    qi [slots] u32), or None when `cap` slots do not hold the layout (exact-size buffers: a write past them is an
+    AddressSanitizer finding under tests/sanitize_cpu.sh)."""
+    cost = np.ascontiguousarray(cost, np.uint64)
+    q = np.ascontiguousarray(queries16, np.uint8).reshape(-1, 16)
+    n = len(cost)
+    if cap is None:
+        grid, rounds, _, _, _ = direct_layout(cost, n_cu, max_lg)
+        cap = rounds * grid * 16
+    rec = np.zeros((max(cap, 1), 16), np.uint8)
+    qi = np.zeros(max(cap, 1), np.uint32)
+    lib().hs_direct_records.restype = C.c_size_t
+    slots = lib().hs_direct_records(_p(cost, C.c_uint64), _p(q, C.c_uint8), C.c_size_t(n), C.c_uint32(n_cu), C.c_uint32(max_lg),
+                                    _p(rec, C.c_uint8), _p(qi, C.c_uint32), C.c_size_t(cap))
+    return (rec[:slots], qi[:slots]) if slots else None

@@ -336,3 +336,12 @@ extern "C" uint32_t hs_direct_layout(const uint64_t *cost, size_t n, uint32_t n_
     mcq_direct_layout_slots(L, slot_qi, slot_sub);
     return L.rounds;
 }
+// ... and the records the library writes from it (mcq_direct_write_records): rec = slots x 16 bytes, qi = slots words;
+// returns the slot count, 0 when `cap` slots do not hold the layout
+extern "C" size_t hs_direct_records(const uint64_t *cost, const mcq_query *q, size_t n, uint32_t n_cu, uint32_t max_lg, uint8_t *rec,
+                                    uint32_t *qi, size_t cap) {
+    McqDirectLayout L;
+    mcq_direct_layout(cost, n, n_cu, max_lg, L);
+    if (!mcq_direct_write_records(L, q, n, rec, qi, cap)) return 0;
+    return L.slots;
+}

@@ -52,3 +52,6 @@ g++ -O1 -g -fsanitize=thread -fno-omit-frame-pointer -shared -fPIC -std=c++17 -W
     -o $T/libmcq_tsan.so $T/stub.cpp $R/neuron_poker_amd/csrc/mcq_tables.cpp -lpthread
 LD_PRELOAD="$(gcc -print-file-name=libtsan.so)" TSAN_OPTIONS="report_signal_unsafe=0 exitcode=66" \
 MCQ_LIBRARY=$T/libmcq_tsan.so MCQ_SAN_STUB=1 python3 -m pytest tests/test_table_driver.py -x -q -k "stand_in or thread_count or half_way" -p no:cacheprovider
+# ... and over the shard workers of the multi-GPU entry (csrc/mcq_worker.hpp: submit / wait / join as mcq_multi.cpp drives them)
+g++ -O1 -g -fsanitize=thread -fno-omit-frame-pointer -std=c++17 -I$R/include -o $T/tsan_worker $R/tests/tsan_worker.cpp -lpthread
+TSAN_OPTIONS="exitcode=66" $T/tsan_worker

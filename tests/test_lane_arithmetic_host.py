@@ -327,3 +327,22 @@ def test_one_launch_layout_invariants():
         blocks = (np.arange(len(qi)) // 16) % grid
         np.add.at(per_block, blocks[used], 1)
         assert per_block.max() - per_block.min() <= 31
+
+
+def test_one_launch_work_records_fit_their_slots():
+    """mcq_direct_write_records (mcq_layout.hpp): what the library hands mcq_eval_direct_kernel -- per wave slot the query's
+    record with log2(waves) and the cut number in its reserved bytes, and the query index -- written into buffers of
+    EXACTLY the layout's size (under tests/sanitize_cpu.sh a write past them is an AddressSanitizer finding); a buffer
+    one slot short is refused, nothing written."""
+    g = np.random.default_rng(11)
+    for n, n_cu, max_lg in [(1, 256, 3), (7, 256, 3), (100, 256, 3), (1024, 256, 3), (3000, 256, 2), (5, 8, 4)]:
+        cost = g.integers(1, 40, n).astype(np.uint64) * 1000
+        q = O.pack_queries(g.integers(0, 52, (n, 2)), np.full((n, 5), 255), g.integers(1, 11, n), g.integers(1, 8000, n))
+        rec, qi = H.direct_records(cost, q, n_cu, max_lg)
+        grid, rounds, lg, slot_qi, slot_sub = H.direct_layout(cost, n_cu, max_lg)
+        assert len(qi) == rounds * grid * 16 and np.array_equal(qi, slot_qi)
+        used = qi != 0xFFFFFFFF
+        assert np.array_equal(rec[used][:, [0, 1, 2, 3, 4, 5, 6, 7, 8, 12, 13, 14, 15]],
+                              q[qi[used]][:, [0, 1, 2, 3, 4, 5, 6, 7, 8, 12, 13, 14, 15]])
+        assert np.array_equal(rec[used][:, 9], lg[qi[used]]) and np.array_equal(rec[used][:, 10], slot_sub[used])
+        assert H.direct_records(cost, q, n_cu, max_lg, cap=len(qi) - 1) is None
