@@ -165,49 +165,96 @@ __global__ __launch_bounds__(1024) void mcq_prep_kernel(const mcq_query *__restr
 }
 
 // ---------------------------------------------------------------------------------------------- parity mode: MT19937
-// One wave per query walks np.random.seed(seed32 + query index)'s stream (mcq_mt.hpp) and leaves the accepted draws
-// in the draw-major global buffer the evaluation kernel reads, `passes` in the query's result row.  Queries are
-// handed out through an atomic counter (their lengths differ); every wave leaves when the counter passes n.
-// 5.5 KB of LDS per wave (MT state, draw table, ring), no lookup tables: several blocks per CU.
-constexpr int kMtBlock = 256;
+// TWO waves per query walk np.random.seed(seed32 + query index)'s stream (mcq_mt.hpp) and leave the accepted draws in
+// the draw-major global buffer the evaluation kernel reads, `passes` in the query's result row:
+//   wave 0, the PRODUCER, owns the 624-word state: it regenerates a block and tempers it into a buffer of
+//           (y & 63) | 0x80 bytes -- independent work at the full issue rate, a block ahead of
+//   wave 1, the PARSER, whose chain of dependent steps per batch of 64 words (mcq_mt_batch) is what bounds the walk: it
+//           only reads bytes.
+// One block = one pair = 128 threads: the block barrier is the pair's hand-over, once per 624 words (two buffers: the
+// producer fills block b + 1 while block b is parsed).  The parser tells the producer at which barrier to stop.
+// Queries are handed out through an atomic counter (their lengths differ).  7.7 KB of LDS per pair: 16 pairs per CU.
+constexpr int kMtBlock = 128;
+struct McqMtPairWave { /* what mcq_mt_batch touches: the position tables and the ring as in McqMtWave, the words as bytes */
+    uint32_t ptab[MCQ_MT_POSITIONS];
+    uint8_t ring[(MCQ_MT_MAX_DRAWS + 1u) * MCQ_MT_ROW];
+    uint8_t yb[2][MCQ_MT_N + 64u]; /* + 64: a batch reads 64 bytes from its position */
+    uint32_t cur, barriers;        /* the buffer being parsed; barriers the parser has passed */
+    volatile uint32_t stop_at;     /* the producer leaves behind its barrier number stop_at (0 = not yet known) */
+    uint32_t qi;
+};
+struct McqMtProducer {
+    uint32_t mt[MCQ_MT_N + 64u];
+};
+__device__ __forceinline__ uint32_t mcq_mt_word_yb(const McqMtPairWave &w, uint32_t i) { return w.yb[w.cur][i]; }
+__device__ __forceinline__ void mcq_mt_next_block(McqMtPairWave &w) {
+    __syncthreads(); /* the producer has filled the other buffer; it may now overwrite the one just parsed */
+    if ((threadIdx.x & 63u) == 0u) {
+        w.cur ^= 1u;
+        w.barriers += 1u;
+    }
+    MCQ_WAVE_SYNC();
+}
+
 __global__ __launch_bounds__(kMtBlock) void mcq_mt_parse_kernel(const mcq_query *__restrict__ queries, uint32_t n,
                                                                 uint32_t seed32, uint8_t *__restrict__ draws,
                                                                 const uint64_t *__restrict__ draw_off,
                                                                 mcq_result *__restrict__ res, uint32_t *__restrict__ counter) {
-    __shared__ __attribute__((aligned(16))) McqMtWave ws[kMtBlock / 64];
-    McqMtWave &w = ws[threadIdx.x >> 6];
+    __shared__ __attribute__((aligned(16))) McqMtPairWave w;
+    __shared__ __attribute__((aligned(16))) McqMtProducer prod;
     const uint32_t lane = threadIdx.x & 63u;
+    const bool producer = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0u;
     for (;;) {
-        uint32_t t = 0;
-        if (lane == 0) t = atomicAdd(counter, 1u);
-        const uint32_t qi = __builtin_amdgcn_readfirstlane(t);
+        if (threadIdx.x == 0) {
+            w.qi = atomicAdd(counter, 1u);
+            w.cur = 1u; /* the first hand-over flips it to buffer 0 */
+            w.barriers = 0u;
+            w.stop_at = 0u;
+        }
+        __syncthreads();
+        const uint32_t qi = __builtin_amdgcn_readfirstlane(w.qi);
         if (qi >= n) break;
         const uint4 raw = reinterpret_cast<const uint4 *>(queries)[qi];
         const McqQueryWords q = {(uint32_t)__builtin_amdgcn_readfirstlane(raw.x), (uint32_t)__builtin_amdgcn_readfirstlane(raw.y),
                                  (uint32_t)__builtin_amdgcn_readfirstlane(raw.z), (uint32_t)__builtin_amdgcn_readfirstlane(raw.w)};
         const uint32_t n_opp = q.n_players() - 1u, n_deal = 5u - q.n_board(), runs = q.runs();
-        /* wave-uniform: invalid queries and queries that draw nothing keep passes = 0 */
+        /* block-uniform: invalid queries and queries that draw nothing keep passes = 0 */
         if (mcq_query_valid(q) && 2u * n_opp + n_deal != 0u && runs != 0u) {
-            MCQ_WAVE_SYNC(); /* the previous query's reads of this wave's LDS are done */
-            mcq_mt_seed(w, seed32 + qi);
-            MCQ_WAVE_SYNC();
-            McqMtState st = {MCQ_MT_N, 0u, 0u, 0u, 0ull};
-            mcq_mt_parse_query(w, st, 50u - q.n_board(), n_opp, n_deal, runs, draws + draw_off[qi],
-                               ((uint64_t)runs + 63u) & ~63ull);
-            /* every lane stores the same word: a store under `lane == 0` here would be a divergent branch in front of
-             * the loop's back edge, and the wave must be whole when it fetches the next query */
-            reinterpret_cast<unsigned long long *>(res + qi)[1] = st.passes;
+            if (producer) {
+                mcq_mt_seed(prod, seed32 + qi);
+                MCQ_WAVE_SYNC();
+                for (uint32_t b = 0;; b++) {
+                    mcq_mt_regenerate(prod);
+                    uint8_t *dst = w.yb[b & 1u];
+#pragma unroll
+                    for (uint32_t k = 0; k < MCQ_MT_N + 63u; k += 64u) /* ten steps of independent lanes */
+                        if (k + lane < MCQ_MT_N) dst[k + lane] = (uint8_t)((mcq_mt_temper(prod.mt[k + lane]) & 63u) | 0x80u);
+                    __syncthreads(); /* barrier number b + 1: block b is there */
+                    if (w.stop_at == b + 1u) break;
+                }
+            } else {
+                McqMtState st = {MCQ_MT_N, 0u, 0u, 0u, 0ull};
+                mcq_mt_parse_query(w, st, 50u - q.n_board(), n_opp, n_deal, runs, draws + draw_off[qi],
+                                   ((uint64_t)runs + 63u) & ~63ull);
+                /* every lane stores the same word: a store under `lane == 0` here would be a divergent branch in front of
+                 * the barrier */
+                reinterpret_cast<unsigned long long *>(res + qi)[1] = st.passes;
+                if (lane == 0) w.stop_at = w.barriers + 1u; /* the producer is filling one more block: it leaves behind the next barrier */
+                __syncthreads();
+            }
         }
+        __syncthreads(); /* both waves are done with this query's LDS */
     }
 }
 
 // The same for extended queries (mcq_mt_ext.hpp: the reference's loops over ranges, ghost cards and known hands walked
 // stage by stage).  6.5 KB of LDS per wave.  A query whose range cannot be dealt gets passes = UINT64_MAX.
-__global__ __launch_bounds__(kMtBlock) void mcq_mt_parse_ext_kernel(const mcq_query *__restrict__ queries,
+constexpr int kMtExtBlock = 256;
+__global__ __launch_bounds__(kMtExtBlock) void mcq_mt_parse_ext_kernel(const mcq_query *__restrict__ queries,
                                                                     const mcq_query_ext *__restrict__ ext, uint32_t n, uint32_t seed32,
                                                                     uint8_t *__restrict__ draws, const uint64_t *__restrict__ draw_off,
                                                                     mcq_result *__restrict__ res, uint32_t *__restrict__ counter) {
-    __shared__ __attribute__((aligned(16))) McqMtExtWave ws[kMtBlock / 64];
+    __shared__ __attribute__((aligned(16))) McqMtExtWave ws[kMtExtBlock / 64];
     McqMtExtWave &w = ws[threadIdx.x >> 6];
     const uint32_t lane = threadIdx.x & 63u;
     for (;;) {
@@ -1164,8 +1211,8 @@ hipError_t mcq_launch_eval_direct(int mode, const void *work_rec, const uint32_t
 hipError_t mcq_launch_mt_parse(const mcq_query *d_q, uint32_t n, uint32_t seed32, uint8_t *d_draws, const uint64_t *d_draw_off,
                                mcq_result *d_res, uint32_t *d_counter, uint32_t n_cu, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    uint32_t blocks = (n + kMtBlock / 64 - 1) / (kMtBlock / 64);
-    if (blocks > 8u * n_cu) blocks = 8u * n_cu; /* what fits a CU at once: 8 blocks x 4 waves */
+    uint32_t blocks = n; /* one pair of waves per query */
+    if (blocks > 16u * n_cu) blocks = 16u * n_cu; /* what a CU holds at once: 16 work-groups */
     hipLaunchKernelGGL(mcq_mt_parse_kernel, dim3(blocks), dim3(kMtBlock), 0, s, d_q, n, seed32, d_draws, d_draw_off, d_res,
                        d_counter);
     return hipGetLastError();
@@ -1174,9 +1221,9 @@ hipError_t mcq_launch_mt_parse(const mcq_query *d_q, uint32_t n, uint32_t seed32
 hipError_t mcq_launch_mt_parse_ext(const mcq_query *d_q, const mcq_query_ext *d_ext, uint32_t n, uint32_t seed32, uint8_t *d_draws,
                                    const uint64_t *d_draw_off, mcq_result *d_res, uint32_t *d_counter, uint32_t n_cu, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    uint32_t blocks = (n + kMtBlock / 64 - 1) / (kMtBlock / 64);
+    uint32_t blocks = (n + kMtExtBlock / 64 - 1) / (kMtExtBlock / 64);
     if (blocks > 5u * n_cu) blocks = 5u * n_cu; /* what fits a CU at once: 27 KB of LDS per block */
-    hipLaunchKernelGGL(mcq_mt_parse_ext_kernel, dim3(blocks), dim3(kMtBlock), 0, s, d_q, d_ext, n, seed32, d_draws, d_draw_off,
+    hipLaunchKernelGGL(mcq_mt_parse_ext_kernel, dim3(blocks), dim3(kMtExtBlock), 0, s, d_q, d_ext, n, seed32, d_draws, d_draw_off,
                        d_res, d_counter);
     return hipGetLastError();
 }

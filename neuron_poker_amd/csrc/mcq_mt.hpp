@@ -30,12 +30,17 @@
 
 #include "mcq_device.hpp"
 
+#ifndef MCQ_MT_STAMP
+#define MCQ_MT_STAMP(k) /* tuning builds (tools/mt_bench) take a cycle-counter stamp here */
+#endif
 #define MCQ_MT_N 624u
 #define MCQ_MT_M 397u
 #define MCQ_MT_RING 128u   /* iterations the ring holds: < 64 pending + at most 64 from one batch of words */
+#define MCQ_MT_ROW 132u    /* bytes from one ring row to the next: 128 + 4, so that the rows of ONE iteration -- what the
+                            * lanes of a batch write and read side by side -- fall into different LDS banks (at 128 they
+                            * all met in one bank: 44 % of the LDS cycles of the walk were bank conflicts) */
 #define MCQ_MT_MAX_DRAWS 23u /* 2 * 9 opponents + 5 table cards */
 #define MCQ_MT_POSITIONS 128u /* positions a batch can form: d0 <= 22, + 64 words, rounded up */
-#define MCQ_MT_REGEN(w) mcq_mt_regenerate(w)
 #define MCQ_MT_FLUSH(w, st, D, n, draws, stride) mcq_mt_flush(w, st, D, n, draws, stride)
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -46,7 +51,6 @@
 #define MCQ_FOR_LANES(l) for (uint32_t l __attribute__((unused)) = mcq_mt_lane(), once_ = 1; once_; once_ = 0)
 #define MCQ_BALLOT(name) __ballot(name)
 #define MCQ_BALLOT_K(name, k) __ballot(name[k])
-#define MCQ_KEEP2(a, b) ({ asm volatile("" : "+v"(a), "+v"(b)); })
 #define MCQ_BALLOT_OF(l, expr) ({ const uint32_t l __attribute__((unused)) = mcq_mt_lane(); __ballot(expr); }) /* ballot of an expression of the lane's values */
 #define MCQ_LANE_OF(m, l) mcq_mt_lane_of(m)    /* is this lane's bit set in the wave mask m? */
 /* number of set bits of the wave mask m below this lane */
@@ -56,15 +60,13 @@
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");           \
         __builtin_amdgcn_wave_barrier();                                 \
     } while (0)
-/* positions travel as the LDS byte address of their etab entry (device) / as the index itself (host): the base rides
- * in the accumulate operand of v_mbcnt, so a round needs no address arithmetic */
+/* positions travel as the LDS byte address of their ptab word (device) / as four times the index (host): a round asks
+ * for that word with no further address arithmetic */
 typedef __attribute__((address_space(3))) const uint8_t *McqLdsU8;
 typedef __attribute__((address_space(3))) const uint32_t *McqLdsU32;
-#define MCQ_POS_BASE(w) ((uint32_t)(uintptr_t)(McqLdsU8)((w).etab))
-#define MCQ_ETAB_AT(w, pa) (*(McqLdsU8)(uintptr_t)(pa))
-#define MCQ_QTAB_AT(w, pa) (*(McqLdsU8)(uintptr_t)((pa) + MCQ_MT_POSITIONS))
-#define MCQ_RTAB_AT(w, pa) (*(McqLdsU8)(uintptr_t)((pa) + 2u * MCQ_MT_POSITIONS))
-#define MCQ_COUNT_BELOW_FROM(m, l, base) __builtin_amdgcn_mbcnt_hi((uint32_t)((m) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(m), (base)))
+#define MCQ_POS_BASE(w) ((uint32_t)(uintptr_t)(McqLdsU32)((w).ptab))
+#define MCQ_PTAB_AT(w, pa4) (*(McqLdsU32)(uintptr_t)(pa4))
+#define MCQ_POS4_FROM(m, l, base4) ((base4) + 4u * __builtin_amdgcn_mbcnt_hi((uint32_t)((m) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(m), 0u)))
 /* bit `lane` of a wave mask as a per-lane condition: v_cmp of mbcnt difference would cost more than the mask AND the
  * compiler makes of this */
 __device__ __forceinline__ bool mcq_mt_lane_of(uint64_t m) {
@@ -83,16 +85,13 @@ __device__ __forceinline__ uint32_t mcq_mt_shfl(uint32_t v, uint32_t idx) {
 #define MCQ_FOR_LANES(l) for (uint32_t l_ = 0, l __attribute__((unused)) = 0; l_ < 64u; l_++, l = l_)
 #define MCQ_BALLOT(name) mcq_mt_host_ballot(name)
 #define MCQ_BALLOT_K(name, k) mcq_mt_host_ballot_k(name, k)
-#define MCQ_KEEP2(a, b) ((void)0)
 #define MCQ_BALLOT_OF(l, expr) ({ uint64_t m_ = 0; for (uint32_t l_ = 0, l __attribute__((unused)) = 0; l_ < 64u; l_++, l = l_) m_ |= (uint64_t)((expr) ? 1u : 0u) << l_; m_; })
 #define MCQ_LANE_OF(m, l) ((((m) >> (l)) & 1u) != 0u)
 #define MCQ_COUNT_BELOW(m, l) mcq_mt_popc64((m) & (((uint64_t)1 << (l)) - 1u))
 #define MCQ_WAVE_SYNC() ((void)0)
 #define MCQ_POS_BASE(w) 0u
-#define MCQ_ETAB_AT(w, pa) ((w).etab[pa])
-#define MCQ_QTAB_AT(w, pa) ((w).qtab[pa])
-#define MCQ_RTAB_AT(w, pa) ((w).rtab[pa])
-#define MCQ_COUNT_BELOW_FROM(m, l, base) ((base) + MCQ_COUNT_BELOW(m, l))
+#define MCQ_PTAB_AT(w, pa4) ((w).ptab[(pa4) >> 2])
+#define MCQ_POS4_FROM(m, l, base4) ((base4) + 4u * MCQ_COUNT_BELOW(m, l))
 template <class T>
 static inline uint64_t mcq_mt_host_ballot(const T (&a)[64]) {
     uint64_t m = 0;
@@ -146,15 +145,16 @@ MCQ_HD uint32_t mcq_mt_magic(uint32_t D) { return 65536u / D + 1u; }
 struct McqMtWave {
     uint32_t mt[MCQ_MT_N + 64u]; /* + 64: a batch reads 64 words from its position, the ones past the block unused */
     /* by position p = (draws of the current iteration already accepted) + (accepted words of the batch before the lane),
-     * p < MCQ_MT_POSITIONS, three byte planes read with ONE address register (a round asks for all three: when the
-     * positions have settled, what the write-out needs has arrived with the last round's answer):
-     *   etab[p]  the effective depth e of draw d = p mod D, | MCQ_MT_ZONE31 in zone 31
-     *   qtab[p]  the iteration offset p / D
-     *   rtab[p]  d, | 0x80 for an r2 */
-    uint8_t etab[MCQ_MT_POSITIONS], qtab[MCQ_MT_POSITIONS], rtab[MCQ_MT_POSITIONS];
-    /* ring[(d + 1) * 128 + (iteration & 127)] = r | 0x80; row 0 is spare: the partner of draw d -- the r1 an r2 is
+     * p < MCQ_MT_POSITIONS, ONE word per position (a round asks for it with one LDS read -- the LDS pipe, 70 % busy, is
+     * what bounds the walk -- and when the positions have settled, what the write-out needs has arrived with it):
+     *   bits 0-7    the effective depth e of draw d = p mod D, | MCQ_MT_ZONE31 in zone 31
+     *   bits 8-15   the iteration offset p / D
+     *   bits 16-27  d * MCQ_MT_ROW: the ring offset of the row BELOW the draw's own (its partner's row)
+     *   bit 31      set for an r2 */
+    uint32_t ptab[MCQ_MT_POSITIONS];
+    /* ring[(d + 1) * MCQ_MT_ROW + (iteration & 127)] = r | 0x80; row 0 is spare: the partner of draw d -- the r1 an r2 is
      * compared with -- sits one row below it, and the address must exist for d = 0 */
-    uint8_t ring[(MCQ_MT_MAX_DRAWS + 1u) * MCQ_MT_RING];
+    uint8_t ring[(MCQ_MT_MAX_DRAWS + 1u) * MCQ_MT_ROW];
 };
 
 // np.random.seed(s): init_genrand.  A serial recurrence: every lane computes it (wave-uniform, scalar ALU on the
@@ -209,6 +209,13 @@ MCQ_HD void mcq_mt_regenerate(W &w) {
     MCQ_WAVE_SYNC();
 }
 
+// Where a batch takes its words from.  One wave per query (this struct; tests/hostsim, the extended walk): the wave
+// regenerates its own state block and tempers the words it parses.  Two waves per query (McqMtPairWave in
+// mcq_kernels.hip): a PRODUCER wave regenerates and tempers a block ahead into a double buffer of (y & 63) | 0x80
+// bytes, the parsing wave only reads bytes.
+MCQ_HD uint32_t mcq_mt_word_yb(const McqMtWave &w, uint32_t i) { return (mcq_mt_temper(w.mt[i]) & 63u) | 0x80u; }
+MCQ_HD void mcq_mt_next_block(McqMtWave &w) { mcq_mt_regenerate(w); }
+
 struct McqMtState { /* wave-uniform */
     uint32_t pos;     /* next unread state word, 624 = regenerate first */
     uint32_t it_done; /* complete iterations parsed */
@@ -226,7 +233,7 @@ MCQ_HD void mcq_mt_flush(W &w, McqMtState &st, uint32_t D, uint32_t count, uint8
         MCQ_FOR_LANES(l) {
             const uint32_t d = d4 + (l >> 4), c4 = (l & 15u) * 4u;
             if (d < D && c4 < count) {
-                const uint32_t v = *reinterpret_cast<const uint32_t *>(&w.ring[(d + 1u) * MCQ_MT_RING + ((first + c4) & (MCQ_MT_RING - 1u))]);
+                const uint32_t v = *reinterpret_cast<const uint32_t *>(&w.ring[(d + 1u) * MCQ_MT_ROW + ((first + c4) & (MCQ_MT_RING - 1u))]);
                 *reinterpret_cast<uint32_t *>(draws + (uint64_t)d * stride + first + c4) = v;
             }
         }
@@ -238,7 +245,7 @@ MCQ_HD void mcq_mt_flush(W &w, McqMtState &st, uint32_t D, uint32_t count, uint8
 // One batch of up to 64 words.  How a batch is parsed:
 //   1. the lanes' words are tempered; E = L0 - 1 - (y & mask) is the deepest position the word is accepted at;
 //   2. positions: first guess from the words accepted at the query's MIDDLE depth, then rounds of
-//      (depth of my position, from etab) -> (accept bits) -> (position = d0 + accepted words before me) until nothing
+//      (depth of my position, from ptab) -> (accept bits) -> (position = d0 + accepted words before me) until nothing
 //      moves -- lane 0 is always final and every round makes at least one more lane final, so the fixed point is the
 //      sequential parse as if no pair were ever drawn again;
 //   3. every accepted word goes to the ring; an accepted r2 then looks one row down for its r1 (written by this batch or
@@ -264,37 +271,31 @@ struct McqMtPlan { /* wave-uniform constants of a query */
 template <bool TWO_ZONE, bool TAIL, class W>
 MCQ_HD void mcq_mt_batch(W &w, McqMtState &st, const McqMtPlan &pl) {
     const uint32_t rem = MCQ_MT_N - st.pos; /* state words left: lanes from there on hold no word */
-    const uint32_t pos0 = MCQ_POS_BASE(w) + st.d0;
-    const uint32_t p_lim = pos0 - st.d0 + (pl.runs - st.it_done) * pl.D; /* TAIL: positions from here on lie past the last iteration */
+    const uint32_t pos0 = MCQ_POS_BASE(w) + 4u * st.d0;
+    const uint32_t p_lim = pos0 + 4u * ((pl.runs - st.it_done) * pl.D - st.d0); /* TAIL: positions from here on lie past the last iteration */
 #ifdef MCQ_MT_STATS
     g_batches++;
 #endif
+    MCQ_MT_STAMP(0);
     MCQ_PL(uint32_t, yb);  /* (y & 63) | 0x80: the byte an accepted word of zone 63 leaves */
     MCQ_PL(int32_t, E63);
     MCQ_PL(int32_t, E31);
-    MCQ_PL(uint32_t, pa);  /* position + pos0 */
-    MCQ_PL(uint32_t, base); /* pos0 in a vector register: the accumulate operand of the counts */
-    MCQ_PL(uint32_t, e8);
-    MCQ_PL(uint32_t, q8);
-    MCQ_PL(uint32_t, r8);
+    MCQ_PL(uint32_t, pa);  /* the position as the byte address of its ptab word: pos0 + 4 * (accepted words before the lane) */
+    MCQ_PL(uint32_t, t);   /* that word */
     MCQ_FOR_LANES(l) {
-        const uint32_t y = mcq_mt_temper(w.mt[st.pos + l]); /* (mt is padded: lanes behind the block read words nobody uses) */
-        MCQ_L(base) = mcq_opaque(pos0);
-        MCQ_L(yb) = (y & 63u) | 0x80u;
+        MCQ_L(yb) = mcq_mt_word_yb(w, st.pos + l); /* (padded: lanes behind the block read words nobody uses) */
         MCQ_L(E63) = l < rem ? (int32_t)(pl.k_e - MCQ_L(yb)) : -1; /* never accepted */
-        if (TWO_ZONE) MCQ_L(E31) = l < rem ? (int32_t)(pl.k_e - ((y & 31u) | 0x80u)) : -1;
+        if (TWO_ZONE) MCQ_L(E31) = l < rem ? (int32_t)(pl.k_e - (MCQ_L(yb) & 0x9Fu)) : -1; /* (y & 31) | 0x80 */
     }
     uint64_t M = MCQ_BALLOT_OF(l, MCQ_L(E63) >= (int32_t)pl.e_mid);
-    MCQ_FOR_LANES(l) { MCQ_L(pa) = MCQ_COUNT_BELOW_FROM(M, l, MCQ_L(base)); }
-    /* accept bits of the lanes at positions P; TWO_ZONE: etab's bit 7 picks the zone */
-#define MCQ_MT_ACCEPT_E8(P)                                                                                       \
-    ((TWO_ZONE ? (int32_t)(MCQ_L(e8) & 63u) <= ((MCQ_L(e8) & MCQ_MT_ZONE31) ? MCQ_L(E31) : MCQ_L(E63))            \
-               : (int32_t)MCQ_L(e8) <= MCQ_L(E63)) &&                                                              \
+    MCQ_MT_STAMP(1);
+    MCQ_FOR_LANES(l) { MCQ_L(pa) = MCQ_POS4_FROM(M, l, pos0); }
+    /* accept bits of the lanes at positions P; TWO_ZONE: bit 7 of the depth byte picks the zone */
+#define MCQ_MT_ACCEPT_T(P)                                                                                        \
+    ((TWO_ZONE ? (int32_t)(MCQ_L(t) & 63u) <= ((MCQ_L(t) & MCQ_MT_ZONE31) ? MCQ_L(E31) : MCQ_L(E63))              \
+               : (int32_t)(MCQ_L(t) & 0xFFu) <= MCQ_L(E63)) &&                                                     \
      (!TAIL || MCQ_L(P) < p_lim))
-#define MCQ_MT_ACCEPT(P)                                                                                          \
-    (MCQ_L(e8) = MCQ_ETAB_AT(w, MCQ_L(P)), MCQ_L(q8) = MCQ_QTAB_AT(w, MCQ_L(P)), MCQ_L(r8) = MCQ_RTAB_AT(w, MCQ_L(P)),  \
-     MCQ_KEEP2(MCQ_L(q8), MCQ_L(r8)), /* (asked for in EVERY round, not once more behind the loop) */                  \
-     MCQ_MT_ACCEPT_E8(P))
+#define MCQ_MT_ACCEPT(P) (MCQ_L(t) = MCQ_PTAB_AT(w, MCQ_L(P)), MCQ_MT_ACCEPT_T(P))
     for (;;) { /* settled when a round answers with the accept bits it was asked with (a scalar compare) */
         const uint64_t M1 = MCQ_BALLOT_OF(l, MCQ_MT_ACCEPT(pa));
 #ifdef MCQ_MT_STATS
@@ -302,24 +303,26 @@ MCQ_HD void mcq_mt_batch(W &w, McqMtState &st, const McqMtPlan &pl) {
 #endif
         if (M1 == M) break;
         M = M1;
-        MCQ_FOR_LANES(l) { MCQ_L(pa) = MCQ_COUNT_BELOW_FROM(M, l, MCQ_L(base)); }
+        MCQ_FOR_LANES(l) { MCQ_L(pa) = MCQ_POS4_FROM(M, l, pos0); }
     }
-    /* write-out: every lane computes its slot (q8, r8 are those of the final positions), the accepted ones store; then
+    MCQ_MT_STAMP(2);
+    /* write-out: every lane computes its slot (t is the word of the final position), the accepted ones store; then
      * every lane asks for its partner row, and while that answer travels the wave does the bookkeeping of the usual
      * case -- no pair drawn again */
-    MCQ_PL(uint32_t, at); /* ring address of the word's partner row = its own row - 128 */
+    MCQ_PL(uint32_t, at); /* ring address of the word's partner row = its own row - MCQ_MT_ROW */
     MCQ_PL(uint32_t, v);
     MCQ_PL(uint32_t, pv);
     MCQ_FOR_LANES(l) {
-        MCQ_L(at) = ((MCQ_L(r8) & 0x7Fu) << 7) | ((st.it_done + MCQ_L(q8)) & (MCQ_MT_RING - 1u));
-        MCQ_L(v) = TWO_ZONE && (MCQ_L(e8) & MCQ_MT_ZONE31) ? (MCQ_L(yb) & 0x9Fu) : MCQ_L(yb);
-        /* the accepted lanes (the compare again: cheaper than turning the mask M back into a lane condition; e8 and pa are
+        MCQ_L(at) = ((MCQ_L(t) >> 16) & 0xFFFu) + ((st.it_done + ((MCQ_L(t) >> 8) & 0xFFu)) & (MCQ_MT_RING - 1u));
+        MCQ_L(v) = TWO_ZONE && (MCQ_L(t) & MCQ_MT_ZONE31) ? (MCQ_L(yb) & 0x9Fu) : MCQ_L(yb);
+        /* the accepted lanes (the compare again: cheaper than turning the mask M back into a lane condition; t and pa are
          * those of the final round) -- lanes behind a re-drawn pair too: see above */
-        if (MCQ_MT_ACCEPT_E8(pa)) w.ring[MCQ_L(at) + MCQ_MT_RING] = (uint8_t)MCQ_L(v);
+        if (MCQ_MT_ACCEPT_T(pa)) w.ring[MCQ_L(at) + MCQ_MT_ROW] = (uint8_t)MCQ_L(v);
     }
     MCQ_WAVE_SYNC();
+    MCQ_MT_STAMP(3);
     MCQ_FOR_LANES(l) { MCQ_L(pv) = w.ring[MCQ_L(at)]; }
-    const uint64_t R2 = MCQ_BALLOT_OF(l, MCQ_L(r8) >= 0x80u) & M;
+    const uint64_t R2 = MCQ_BALLOT_OF(l, (int32_t)MCQ_L(t) < 0) & M;
     uint32_t used = rem < 64u ? rem : 64u;
     uint32_t n_r2 = mcq_opaque_uniform(mcq_mt_popc64(R2)), p_end = mcq_opaque_uniform(st.d0 + mcq_mt_popc64(M)); /* (here, not behind the wait) */
     const uint64_t R = MCQ_BALLOT_OF(l, MCQ_L(pv) == MCQ_L(v)) & R2;
@@ -330,6 +333,7 @@ MCQ_HD void mcq_mt_batch(W &w, McqMtState &st, const McqMtPlan &pl) {
         n_r2 = mcq_mt_popc64(R2 & M);
         p_end = st.d0 + mcq_mt_popc64(M) - 2u;
     }
+    MCQ_MT_STAMP(4);
     st.passes += n_r2; /* one accepted r2 per attempt (l.168) */
     const uint32_t it_add = (p_end * pl.magic) >> 16;
     st.d0 = p_end - it_add * pl.D;
@@ -339,8 +343,9 @@ MCQ_HD void mcq_mt_batch(W &w, McqMtState &st, const McqMtPlan &pl) {
     if (TAIL && !R && st.it_done >= pl.runs) used = M ? mcq_mt_top64(M) + 1u : 0u;
     st.pos += used;
     MCQ_WAVE_SYNC();
+    MCQ_MT_STAMP(5);
 #undef MCQ_MT_ACCEPT
-#undef MCQ_MT_ACCEPT_E8
+#undef MCQ_MT_ACCEPT_T
 }
 
 // Parse the whole stream of one query: `runs` iterations of D = 2 * n_opp + n_deal draws (D >= 1).  The wave's MT
@@ -353,7 +358,7 @@ MCQ_HD void mcq_mt_parse_loop(W &w, McqMtState &st, const McqMtPlan &pl, uint8_t
 #define MCQ_MT_STEP(TAIL_)                                                                       \
     do {                                                                                         \
         if (st.pos >= MCQ_MT_N) {                                                                \
-            MCQ_MT_REGEN(w);                                                                     \
+            mcq_mt_next_block(w);                                                                \
             st.pos = 0;                                                                          \
         }                                                                                        \
         mcq_mt_batch<TWO_ZONE, TAIL_>(w, st, pl);                                                \
@@ -375,9 +380,8 @@ MCQ_HD void mcq_mt_parse_query(W &w, McqMtState &st, uint32_t L0, uint32_t n_opp
     MCQ_FOR_LANES(l) {
         for (uint32_t pp = l; pp < MCQ_MT_POSITIONS; pp += 64u) {
             const uint32_t q = (pp * magic) >> 16, d = pp - q * D, e = mcq_mt_depth(n_opp, d);
-            w.etab[pp] = (uint8_t)(e | (e > z_max ? MCQ_MT_ZONE31 : 0u));
-            w.qtab[pp] = (uint8_t)q;
-            w.rtab[pp] = (uint8_t)(d | ((d < 2u * n_opp && (d & 1u)) ? 0x80u : 0u));
+            w.ptab[pp] = (e | (e > z_max ? MCQ_MT_ZONE31 : 0u)) | (q << 8) | ((d * MCQ_MT_ROW) << 16) |
+                         ((d < 2u * n_opp && (d & 1u)) ? 0x80000000u : 0u);
         }
     }
     MCQ_WAVE_SYNC();

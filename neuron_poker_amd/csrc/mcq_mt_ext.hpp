@@ -47,7 +47,7 @@ struct McqMtExtWave {
     uint32_t hand[12];           /* hand h: mcq_ext_hand(h) | word offset of its class set << 24 */
     uint8_t deck[80], deck0[80]; /* the ordered remaining deck (card ids) now / at the start of an iteration */
     uint8_t vals[80];            /* vals[1 + rank] = value of the accepted word of that rank; vals[0] = the pending r1 */
-    uint8_t ring[(MCQ_MTX_MAX_DRAWS + 1u) * MCQ_MT_RING]; /* rows as in McqMtWave: draw d in row d + 1 */
+    uint8_t ring[(MCQ_MTX_MAX_DRAWS + 1u) * MCQ_MT_ROW]; /* rows as in McqMtWave: draw d in row d + 1 */
 };
 
 struct McqMtExtState { /* wave-uniform */
@@ -277,7 +277,7 @@ MCQ_HD bool mcq_mt_parse_query_ext(W &w, McqMtExtState &st, const McqQueryWords 
             st.n--;
         }
         MCQ_FOR_LANES(l) {
-            if (l < rows) w.ring[(l + 1u) * MCQ_MT_RING + (st.it_done & (MCQ_MT_RING - 1u))] = (uint8_t)MCQ_L(out);
+            if (l < rows) w.ring[(l + 1u) * MCQ_MT_ROW + (st.it_done & (MCQ_MT_RING - 1u))] = (uint8_t)MCQ_L(out);
         }
         MCQ_WAVE_SYNC();
         st.it_done++;

@@ -10,6 +10,18 @@
 
 #include <vector>
 
+#ifdef MT_STAMPS /* where a lone wave's batch spends its cycles: s_memtime deltas between the stamps of mcq_mt_batch */
+__device__ unsigned long long g_stamps[8], g_last, g_nb;
+#define MCQ_MT_STAMP(k)                                                                     \
+    do {                                                                                    \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                                          \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();                   \
+            if (k == 0) g_nb++; else g_stamps[k] += now_ - g_last;                          \
+            if (k == 0 && g_last) g_stamps[0] += now_ - g_last; /* loop, regeneration, flush */ \
+            g_last = now_;                                                                  \
+        }                                                                                   \
+    } while (0)
+#endif
 #include "../../neuron_poker_amd/csrc/mcq_mt.hpp"
 #include "../../neuron_poker_amd/csrc/mcq_replay.hpp"
 
@@ -86,5 +98,12 @@ int main(int argc, char **argv) {
     const double words = (double)n * runs * (D * 64.0 / 50.0); /* rough: 78 % of the words are accepted */
     printf("%u queries x %u runs x %u players, %u board: %.3f ms  (~%.3g words/s)  query 0 %s\n", n, runs, npl, nb, best,
            words / (best * 1e-3), ok ? "== sequential walk" : "MISMATCH");
+#ifdef MT_STAMPS
+    unsigned long long st[8], nbatch;
+    CHECK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof st));
+    CHECK(hipMemcpyFromSymbol(&nbatch, HIP_SYMBOL(g_nb), sizeof nbatch));
+    const char *names[6] = {"between batches (loop, regeneration, flush)", "words -> E, first guess", "rounds", "slot, ring write", "partner read, masks", "bookkeeping"};
+    for (int k = 0; k < 6; k++) printf("  %-46s %7.1f memtime ticks per batch\n", names[k], (double)st[k] / (double)nbatch);
+#endif
     return ok ? 0 : 1;
 }
