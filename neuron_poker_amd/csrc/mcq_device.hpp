@@ -998,6 +998,11 @@ struct McqExtCtx { /* wave-uniform */
     uint32_t n_players, n_hands, n_deal, runs; /* n_hands = 1 + n_known */
     bool opp_all;                         /* every class allowed to the opponents: dealt by index as in the plain path */
     McqBoard board;
+    /* the common ranged query -- hero two cards, no further known hand, every opponent drawn from ONE candidate list --
+     * takes mcq_iteration_ext_fast: */
+    bool fast;
+    uint32_t fdeck_lo, fdeck_hi;          /* the deck without hero's cards too */
+    McqHole hero;
 };
 struct McqExtWaveCtx { /* per wave, in LDS: what the iteration indexes at run time */
     uint32_t hand[10];                  /* mcq_ext_hand of every known hand */
@@ -1017,6 +1022,12 @@ MCQ_HD void mcq_ext_ctx(const McqQueryWords &q, const McqExtRec &e, McqExtCtx &c
     c.n_deal = 5u - q.n_board();
     c.runs = q.runs();
     c.opp_all = mcq_ext_opp_all(e);
+    c.fast = !e.hero_is_range() && e.n_known() == 0u && !c.opp_all && q.n_players() >= 2u;
+    const uint32_t h0 = q.card(0), h1 = q.card(1);
+    const uint64_t fdeck = deck & ~(((uint64_t)1 << (h0 & 63u)) | ((uint64_t)1 << (h1 & 63u)));
+    c.fdeck_lo = (uint32_t)fdeck;
+    c.fdeck_hi = (uint32_t)(fdeck >> 32);
+    c.hero.set(mcq_card(h0 < 52u ? h0 : 0u), mcq_card(h1 < 52u ? h1 : 0u));
 }
 
 /* deck mask helpers (52 bits in two words) */
@@ -1149,6 +1160,70 @@ MCQ_HD bool mcq_iteration_ext(const McqExtCtx &qc, const McqExtWaveCtx &wc, Draw
         if (h == 0) hk = k;
         else best = k > best ? k : best;
     }
+    uint64_t won = hk >= best ? 1u : 0u;
+    acc.types += won << (6u * (hk >> MCQ_KEY_SHIFT));
+    acc.tie += hk == best ? 1u : 0u;
+    return dealt;
+}
+
+// The common ranged query in straight code: hero two cards, no further known hand, all n_players - 1 opponents drawn
+// from ONE candidate list (wc.list[0]).  The same draws in the same order as mcq_iteration_ext -- one word per trial,
+// then the table cards two per word -- hence the same tallies bit for bit; what it saves is the general form's
+// bookkeeping: the deck is one 64-bit mask tested with two shifts per trial, the opponents' hands stay in registers
+// (unrolled over the opponent number, as in mcq_iteration) instead of travelling through LDS as card ids, the deck's
+// length is known without counting (every lane deals two cards per opponent), hero's hand is part of the query context.
+// 6-max at the top quarter of the classes: ~1650 -> ~900 VALU instructions per wave-iteration.
+template <class Draws>
+MCQ_HD bool mcq_iteration_ext_fast(const McqExtCtx &qc, const McqExtWaveCtx &wc, Draws &dr, const McqCard *cards,
+                                   const uint32_t *sel8, const uint32_t *tf, const uint32_t *tops, const uint32_t *sd,
+                                   McqLaneAcc &acc) {
+    uint64_t deck = ((uint64_t)qc.fdeck_hi << 32) | qc.fdeck_lo;
+    const uint32_t n = wc.cnt[0];
+    const uint16_t *list = wc.list[0];
+    const uint32_t n_opp = mcq_opaque_uniform(qc.n_players - 1u);
+    McqHole opp[MCQ_MAX_OPP];
+    bool dealt = true;
+#define MCQ_XOPP(P)                                                                                                 \
+    if (P < n_opp) {                                                                                                \
+        const uint32_t dhi = (uint32_t)(deck >> 32), dlo = (uint32_t)deck;                                          \
+        const uint32_t top = mcq_deck_top(dlo, dhi);                                                                \
+        uint32_t c1 = 0, c2 = 0;                                                                                    \
+        bool ok = false;                                                                                            \
+        for (uint32_t trial = 0; trial < MCQ_EXT_MAX_TRIALS && !ok; trial++) {                                      \
+            acc.passes++;                                                                                           \
+            const uint32_t e = list[dr.pick(n)];                                                                    \
+            c1 = e & 0xFFu;                                                                                         \
+            c2 = e >> 8;                                                                                            \
+            ok = (((deck >> c1) & (deck >> c2)) & 1u) != 0u && c2 != top; /* both still there, B not the highest */ \
+        }                                                                                                           \
+        dealt = dealt && ok;                                                                                        \
+        if (ok && c2 > c1) c2 = mcq_deck_next(dlo, dhi, c2); /* deck.pop(r2) after deck.pop(r1), l.178-179 */       \
+        c1 = c1 < 52u ? c1 : 0u;                                                                                    \
+        c2 = c2 < 52u ? c2 : 0u;                                                                                    \
+        deck &= ~(((uint64_t)1 << c1) | ((uint64_t)1 << c2));                                                       \
+        opp[P].set(cards[c1], cards[c2]);                                                                           \
+    }
+    MCQ_XOPP(0) MCQ_XOPP(1) MCQ_XOPP(2) MCQ_XOPP(3) MCQ_XOPP(4) MCQ_XOPP(5) MCQ_XOPP(6) MCQ_XOPP(7) MCQ_XOPP(8)
+#undef MCQ_XOPP
+    uint32_t dlo = (uint32_t)deck, dhi = (uint32_t)(deck >> 32);
+    uint32_t L = mcq_popc(qc.fdeck_lo) + mcq_popc(qc.fdeck_hi) - 2u * n_opp; /* wave-uniform: no counting per lane */
+    McqBoard b = qc.board;
+    for (uint32_t k = 0; k < qc.n_deal; k++, L--) {
+        const uint32_t c = mcq_select_pop(dlo, dhi, dr.table(k, L - 1u), sel8);
+        b.add(cards[c < 52u ? c : 0u]);
+    }
+    McqFlushSel fs;
+    fs.from_board(b);
+    const uint32_t hk = mcq_eval_key(b, fs, qc.hero, tf, tops, sd);
+    uint32_t best = 0;
+    const uint32_t n_opp_e = mcq_opaque_uniform(qc.n_players - 1u);
+#define MCQ_XEVAL(P)                                                  \
+    if (P < n_opp_e) {                                                \
+        const uint32_t k = mcq_eval_key(b, fs, opp[P], tf, tops, sd); \
+        best = k > best ? k : best;                                   \
+    }
+    MCQ_XEVAL(0) MCQ_XEVAL(1) MCQ_XEVAL(2) MCQ_XEVAL(3) MCQ_XEVAL(4) MCQ_XEVAL(5) MCQ_XEVAL(6) MCQ_XEVAL(7) MCQ_XEVAL(8)
+#undef MCQ_XEVAL
     uint64_t won = hk >= best ? 1u : 0u;
     acc.types += won << (6u * (hk >> MCQ_KEY_SHIFT));
     acc.tie += hk == best ? 1u : 0u;

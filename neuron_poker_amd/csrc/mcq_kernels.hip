@@ -973,8 +973,12 @@ __global__ __launch_bounds__(kExtBlock) void mcq_eval_ext_kernel(const mcq_query
                 McqExtCtrDraws dr;
                 dr.start(seed, first_qid + qi, stream);
                 const uint32_t cnt = (uint32_t)min((uint64_t)MCQ_STREAM_ITERS, (uint64_t)qc.runs - it0);
-                for (uint32_t j = 0; j < cnt && !failed; j++)
-                    failed = !mcq_iteration_ext(qc, wc, dr, cards, tab.sel8, my_ids, kExtBlock, g_tab->tf, tab.tops, tab.sd, acc);
+                if (qc.fast) /* (wave-uniform) */
+                    for (uint32_t j = 0; j < cnt && !failed; j++)
+                        failed = !mcq_iteration_ext_fast(qc, wc, dr, cards, tab.sel8, g_tab->tf, tab.tops, tab.sd, acc);
+                else
+                    for (uint32_t j = 0; j < cnt && !failed; j++)
+                        failed = !mcq_iteration_ext(qc, wc, dr, cards, tab.sel8, my_ids, kExtBlock, g_tab->tf, tab.tops, tab.sd, acc);
             }
         } else {
             const uint64_t stride = (qc.runs + 63u) & ~63ull;

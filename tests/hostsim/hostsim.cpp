@@ -225,7 +225,8 @@ extern "C" int hs_run_ext(int replay, const mcq_query *q, const mcq_query_ext *e
         McqLaneAcc acc = {0, 0, 0};
         for (uint32_t j = 0; j < MCQ_STREAM_ITERS; j++) {
             if ((uint64_t)s * MCQ_STREAM_ITERS + j >= q->runs) break;
-            if (!mcq_iteration_ext(qc, wc, dr, cards, t.sel8, ids, 1, t.tf, t.tops, t.sd, acc))
+            if (!(qc.fast ? mcq_iteration_ext_fast(qc, wc, dr, cards, t.sel8, t.tf, t.tops, t.sd, acc)   /* as the kernel picks */
+                          : mcq_iteration_ext(qc, wc, dr, cards, t.sel8, ids, 1, t.tf, t.tops, t.sd, acc)))
                 return MCQ_EINVAL;
         }
         fold(acc, out);
