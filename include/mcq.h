@@ -152,6 +152,15 @@ MCQ_API int mcq_eval_batch_numpy_stream(mcq_ctx *ctx, const mcq_query *q, size_t
 MCQ_API int mcq_eval_batch_device(mcq_ctx *ctx, const void *d_queries, size_t n, uint64_t seed, uint64_t first_query_id,
                           void *d_results, void *hip_stream);
 
+/* mcq_eval_batch_device for SMALL queries -- at most 8192 iterations each, the reference's own call pattern (1000 runs,
+ * gym_env/env.py:22) -- in ONE kernel launch: no pricing kernel in front, no atomics; every query is owned by a few
+ * waves of one block and its finished row is stored once.  Same arguments, same tallies (the RNG streams are keyed by
+ * query id and iteration, not by the schedule).  A query with more than 8192 iterations is NOT evaluated here: like an
+ * invalid one it gets runs = 0, passes = UINT64_MAX.  Asynchronous on hip_stream; can be captured into a HIP graph after
+ * one ordinary call on the context. */
+MCQ_API int mcq_eval_batch_device_small(mcq_ctx *ctx, const void *d_queries, size_t n, uint64_t seed, uint64_t first_query_id,
+                                        void *d_results, void *hip_stream);
+
 /* Showdown with the same device evaluator (tools/hand_evaluator.py:9-24 get_winner / eval_best_hand):
  * hands = n_tables x n_players x 7 card ids (host); winner[t] = index of the best hand (first of equals),
  * winner_type[t] = its by_type index, keys (optional, n_tables x n_players) = the 32-bit ranking keys: a

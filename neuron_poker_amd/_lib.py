@@ -95,6 +95,8 @@ def load_library():
         L.mcq_eval_batch_numpy_stream.restype = C.c_int
         L.mcq_eval_batch_device.argtypes = [vp, vp, sz, u64, u64, vp, vp]
         L.mcq_eval_batch_device.restype = C.c_int
+        L.mcq_eval_batch_device_small.argtypes = [vp, vp, sz, u64, u64, vp, vp]
+        L.mcq_eval_batch_device_small.restype = C.c_int
         L.mcq_showdown.argtypes = [vp, vp, sz, C.c_int, vp, vp, vp]
         L.mcq_showdown.restype = C.c_int
         L.mcq_exact_batch.argtypes = [vp, vp, sz, C.c_int, vp]
@@ -347,6 +349,15 @@ class Engine:
         rc = self._lib.mcq_eval_batch_device(self._ctx, int(d_queries), int(n), int(seed) & (2 ** 64 - 1),
                                              int(first_query_id) & (2 ** 64 - 1), int(d_results),
                                              int(stream) if stream else None)
+        if rc:
+            _raise(rc)
+
+    def eval_batch_device_small(self, d_queries, n, seed, d_results, first_query_id=0, stream=None):
+        """eval_batch_device for queries of at most 8192 iterations each: ONE kernel launch, no pricing kernel, no
+        atomics (a longer query gets runs = 0, passes = 2**64 - 1 like an invalid one)."""
+        rc = self._lib.mcq_eval_batch_device_small(self._ctx, int(d_queries), int(n), int(seed) & (2 ** 64 - 1),
+                                                   int(first_query_id) & (2 ** 64 - 1), int(d_results),
+                                                   int(stream) if stream else None)
         if rc:
             _raise(rc)
 

@@ -132,10 +132,12 @@ struct mcq_ctx {
     DevBuf d_q, d_res, d_draws, d_off, d_ext, d_mt, d_lists, d_cnts;
     PinBuf h_q, h_res, h_draws, h_off, h_misc, h_flag;
     DevBuf d_done;                /* block counter of the one-launch path */
+    DevBuf d_done_dev;            /* ... of mcq_eval_batch_device_small: one 64-byte line per scratch slot (stream), zeroed once */
     uint32_t direct_ticket = 0;   /* value the kernel raises the flag in h_flag to */
     McqDirectKarg direct_karg; /* one-launch path: the work of a small launch, passed by value */
     size_t publish_max_rows = 8192; /* host-buffer calls of at most this many rows get them through mcq_publish_kernel + flag (MCQ_PUBLISH_MAX_ROWS, 0 = never) */
     bool timing = false; /* mcq_set_kernel_timing: launches carry timestamp events */
+    size_t direct_uniform_min = 128; /* one-launch path: from this many queries on the kernel lays its own work out (MCQ_DIRECT_UNIFORM_MIN; measured: 512 queries 39 -> 33 us per call, 1024: 48 -> 42, 4096: 137 -> 113) */
     bool direct_poll = true;      /* pick the rows up at the flag instead of synchronising the stream (MCQ_DIRECT_POLL) */
     McqDirectLayout direct_layout;      /* the one-launch path's layout of the current call */
     std::vector<uint64_t> direct_cost;

@@ -334,6 +334,7 @@ mcq_ctx *mcq_ctx_clone(const mcq_ctx *c) {
         d->load_waves = c->load_waves;
         d->direct_max_tasks = c->direct_max_tasks;
         d->direct_poll = c->direct_poll;
+        d->direct_uniform_min = c->direct_uniform_min;
         d->publish_max_rows = c->publish_max_rows;
         d->timing = c->timing;
         d->replay_device_bytes = c->replay_device_bytes;
@@ -367,6 +368,7 @@ void mcq_destroy(mcq_ctx *c) {
     for (DevBuf *b : db) b->release();
     PinBuf *pb[] = {&c->h_q, &c->h_res, &c->h_draws, &c->h_off, &c->h_misc, &c->h_flag};
     c->d_done.release();
+    c->d_done_dev.release();
     for (PinBuf *b : pb) b->release();
     if (c->d_luts) (void)hipFree(c->d_luts);
     for (int i = 0; i < mcq_ctx::kRing; i++) {
@@ -419,6 +421,10 @@ mcq_ctx *mcq_create(int device, int flags) {
         c->direct_max_tasks = (uint32_t)(v < 0 ? 0 : v > (int)MCQ_DIRECT_TASKS_LIMIT ? (int)MCQ_DIRECT_TASKS_LIMIT : v);
     }
     if (const char *e = getenv("MCQ_DIRECT_POLL")) c->direct_poll = atoi(e) != 0;
+    if (const char *e = getenv("MCQ_DIRECT_UNIFORM_MIN")) { /* tuning knob, see eval_host_philox */
+        const long v = atol(e);
+        c->direct_uniform_min = (size_t)(v < 0 ? 0 : v);
+    }
     if (const char *e = getenv("MCQ_PUBLISH_MAX_ROWS")) { /* tuning knob, see eval_host_philox */
         const long v = atol(e);
         c->publish_max_rows = (size_t)(v < 0 ? 0 : v);
@@ -502,6 +508,55 @@ int mcq_eval_batch_device(mcq_ctx *c, const void *d_queries, size_t n, uint64_t 
     return mcq_run_slice(c, MCQ_MODE_PHILOX, (const mcq_query *)d_queries, (uint32_t)n, (mcq_result *)d_results, seed,
                      first_query_id, 0, nullptr, nullptr, s, true);
     ABI_GUARD_END("mcq_eval_batch_device")
+}
+
+/* Small queries resident in HBM -- the reference's call pattern (gym_env/env.py:22,261-262: 1000 runs per query) for a
+ * caller whose states already live on the GPU: ONE kernel launch and nothing else (mcq_eval_direct_kernel in its device
+ * mode): no prep kernel, no cost prefix, no atomics -- every query is owned by 2^lg waves of one block, lg chosen from
+ * the query count alone, validation happens in the kernel. */
+int mcq_eval_batch_device_small(mcq_ctx *c, const void *d_queries, size_t n, uint64_t seed, uint64_t first_query_id,
+                                void *d_results, void *hip_stream) {
+    ABI_GUARD_BEGIN
+    if (!c) return mcq_fail(MCQ_EINVAL, "mcq_eval_batch_device_small: null context");
+    if (n == 0) return MCQ_OK;
+    if (!d_queries || !d_results) return mcq_fail(MCQ_EINVAL, "mcq_eval_batch_device_small: null buffer");
+    if (n >= (1u << 24)) return mcq_fail(MCQ_EINVAL, "mcq_eval_batch_device_small: n too large");
+    McqDeviceScope dev_(c->device);
+    HIP_TRY(dev_.err);
+    hipStream_t s = (hipStream_t)hip_stream;
+    const bool capturing = stream_capturing(s);
+    /* the block counter of this stream (calls on different streams may overlap): a line of d_done_dev per scratch slot */
+    if (!c->d_done_dev.p) {
+        if (capturing)
+            return mcq_fail(MCQ_EINVAL, "mcq_eval_batch_device_small: issue one call on this context before capturing");
+        HIP_TRY(c->d_done_dev.reserve(64 * mcq_ctx::kScratch));
+        HIP_TRY(hipMemset(c->d_done_dev.p, 0, 64 * mcq_ctx::kScratch));
+    }
+    mcq_ctx::Scratch *sc = nullptr;
+    int rc = scratch_for(c, s, 0, capturing, &sc);
+    if (rc) return rc;
+    uint32_t *d_done = reinterpret_cast<uint32_t *>(static_cast<char *>(c->d_done_dev.p) + 64 * (sc - c->scratch));
+    /* about 16 waves per CU in all, at most eight per query (a sixteenth wave steps over fifteen iterations' words) */
+    uint32_t lg = 0;
+    while (lg < 3u && ((uint64_t)n << (lg + 1u)) <= 16ull * (uint64_t)c->n_cu) lg++;
+    if (c->split_max < lg) lg = c->split_max;
+    const uint64_t waves = (uint64_t)n << lg, blocks = (waves + 15u) / 16u;
+    const uint32_t grid = (uint32_t)(blocks < (uint64_t)c->n_cu ? blocks : (uint64_t)c->n_cu);
+    const uint32_t rounds = (uint32_t)((blocks + grid - 1u) / grid);
+    const uint32_t mode = c->law == MCQ_LAW_UNIFORM ? MCQ_INTERNAL_MODE_UNIFORM : MCQ_MODE_PHILOX;
+    const bool timed = c->timing && !capturing;
+    const int slot = (int)(c->n_timed % mcq_ctx::kRing);
+    c->last_ms = 0.f;
+    HIP_TRY(mcq_launch_eval_direct((int)mode, d_queries, nullptr, rounds, lg ? 1u : 0u, (mcq_result *)d_results, seed, first_query_id,
+                                   c->d_luts, grid, d_done, d_done + 8 /* nobody polls: the stream orders the call */, 1u, s,
+                                   timed ? c->ev0[slot] : nullptr, timed ? c->ev1[slot] : nullptr, nullptr, (uint32_t)n, lg));
+    if (timed) c->n_timed++;
+    if (!capturing && sc != &c->scratch[0]) {
+        HIP_TRY(hipEventRecord(sc->done, s));
+        sc->done_recorded = true;
+    }
+    return MCQ_OK;
+    ABI_GUARD_END("mcq_eval_batch_device_small")
 }
 
 /* The completion flag of the kernels that hand their rows over in pinned memory (mcq_eval_direct_kernel,
@@ -589,6 +644,32 @@ static int eval_host_philox(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t s
          * about 16 waves per CU in all, every query a power-of-two number of them in proportion to its cost (so all
          * waves carry about the same work), the waves of a query side by side in one block. */
         const uint32_t mode = c->law == MCQ_LAW_UNIFORM ? MCQ_INTERNAL_MODE_UNIFORM : MCQ_MODE_PHILOX;
+        if (n >= c->direct_uniform_min && max_tasks <= 8u) {
+            /* Many small queries: the kernel lays its own work out (its device mode, as mcq_eval_batch_device_small:
+             * 2^lg waves per query from the query count alone) and reads the caller's records -- copied into this pinned
+             * buffer, nothing else -- across PCIe: the host neither prices nor places a thousand queries (12 us), and a
+             * uniform cut turned out no slower on the GPU than the cost-proportional one. */
+            uint32_t lg = 0;
+            while (lg < 3u && ((uint64_t)n << (lg + 1u)) <= 16ull * (uint64_t)c->n_cu) lg++;
+            if (c->split_max < lg) lg = c->split_max;
+            const uint64_t blocks = (((uint64_t)n << lg) + 15u) / 16u;
+            const uint32_t grid = (uint32_t)(blocks < (uint64_t)c->n_cu ? blocks : (uint64_t)c->n_cu);
+            const uint32_t rounds = (uint32_t)((blocks + grid - 1u) / grid);
+            rc = flag_ready(c);
+            if (rc) return rc;
+            const uint32_t ticket = next_ticket(c);
+            const int slot = (int)(c->n_timed % mcq_ctx::kRing);
+            c->last_ms = 0.f;
+            HIP_TRY(mcq_launch_eval_direct((int)mode, c->h_q.dev, nullptr, rounds, lg ? 1u : 0u, (mcq_result *)c->h_res.dev, seed,
+                                           first_query_id, c->d_luts, grid, (uint32_t *)c->d_done.p, (uint32_t *)c->h_flag.dev,
+                                           ticket, c->stream, c->timing ? c->ev0[slot] : nullptr,
+                                           c->timing ? c->ev1[slot] : nullptr, nullptr, (uint32_t)n, lg));
+            if (c->timing) c->n_timed++;
+            rc = wait_ticket(c, ticket, nullptr);
+            if (rc) return rc;
+            memcpy(out, c->h_res.p, r_bytes);
+            return MCQ_OK;
+        }
         std::vector<uint64_t> &qcost = c->direct_cost;
         qcost.resize(n);
         for (size_t i = 0; i < n; i++) qcost[i] = (i + 1 < n ? prefix[i + 1] : cost) - prefix[i];

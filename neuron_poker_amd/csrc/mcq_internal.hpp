@@ -67,4 +67,6 @@ struct McqDirectKarg {
 hipError_t mcq_launch_eval_direct(int mode, const void *work_rec, const uint32_t *work_qi, uint32_t rounds, uint32_t merge,
                                   mcq_result *res, uint64_t seed, uint64_t first_qid, const McqTables *d_luts, uint32_t grid,
                                   uint32_t *d_done, uint32_t *done_flag, uint32_t ticket, hipStream_t s, hipEvent_t t0,
-                                  hipEvent_t t1, const McqDirectKarg *karg /* or null: read work_rec / work_qi */);
+                                  hipEvent_t t1, const McqDirectKarg *karg /* or null: read work_rec / work_qi */,
+                                  uint32_t dev_n = 0 /* != 0: work_rec is the caller's mcq_query[dev_n] in HBM, work_qi null: */,
+                                  uint32_t dev_lg = 0 /* every query 2^dev_lg waves; validated on the device */);

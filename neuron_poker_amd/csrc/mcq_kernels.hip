@@ -540,6 +540,32 @@ extern "C" __attribute__((visibility("default"))) int mcq_debug_read_stamps(unsi
 #else
 #define MCQ_STAMP(k)
 #endif
+// Queries resident in HBM (mcq_eval_batch_device_small; use_karg == 2): nobody has laid the work out -- slot `at` IS the
+// wave number: every query gets 2^lg waves (the host picks lg from the query COUNT alone), slot at -> query at >> lg, cut
+// at & (2^lg - 1); work_rec points at the caller's mcq_query array.  The queries are validated here: one that is invalid
+// or has more than MCQ_DIRECT_DEV_TASKS tasks gets runs = 0, passes = UINT64_MAX and no work, one without iterations a
+// row of zeros (the slot of its first wave writes it).
+#define MCQ_DIRECT_DEV_TASKS 8u
+__device__ __forceinline__ void mcq_direct_fetch_dev(const uint4 *__restrict__ queries, size_t at, uint32_t n, uint32_t lg,
+                                                     mcq_result *__restrict__ res, uint32_t &qi, uint4 &rec) {
+    const uint32_t q = (uint32_t)(at >> lg), sub = (uint32_t)at & ((1u << lg) - 1u);
+    qi = MCQ_DIRECT_IDLE;
+    if (q >= n) return;
+    rec = queries[q];
+    const McqQueryWords w = {rec.x, rec.y, rec.z, rec.w};
+    const bool ok = mcq_query_valid(w) && mcq_task_count(w) <= MCQ_DIRECT_DEV_TASKS;
+    if (ok && w.runs() != 0u) {
+        qi = q;
+        rec.z |= (lg << 8) | (sub << 16); /* reserved[0], reserved[1]: as the host's layout writes them */
+    } else if (sub == 0u) {
+        unsigned long long *r = reinterpret_cast<unsigned long long *>(res + q);
+        r[0] = 0ull;
+        r[1] = ok ? 0ull : ~0ull;
+#pragma unroll
+        for (int k = 2; k < 13; k++) r[k] = 0ull;
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(kMaxBlock) void mcq_eval_direct_kernel(const uint4 *__restrict__ work_rec,
                                                                     const uint32_t *__restrict__ work_qi, uint32_t rounds,
@@ -568,7 +594,7 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_direct_kernel(const uint4 
      * across PCIe costs more than it hides.) */
     uint32_t qi0 = MCQ_DIRECT_IDLE;
     uint4 raw0 = {0u, 0u, 0u, 0u};
-    if (use_karg) {
+    if (use_karg == 1u) {
         const size_t at0 = (size_t)blockIdx.x * kWaves + __builtin_amdgcn_readfirstlane(wib);
         qi0 = karg.qi[at0];
         raw0 = make_uint4(karg.rec[at0][0], karg.rec[at0][1], karg.rec[at0][2], karg.rec[at0][3]);
@@ -577,9 +603,11 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_direct_kernel(const uint4 
     uint32_t pre_qi = MCQ_DIRECT_IDLE;
     if (threadIdx.x < kStage && threadIdx.x / kWaves < rounds) {
         const size_t at = ((size_t)(threadIdx.x / kWaves) * gridDim.x + blockIdx.x) * kWaves + threadIdx.x % kWaves;
-        if (use_karg) {
+        if (use_karg == 1u) {
             pre_qi = karg.qi[at];
             pre_rec = make_uint4(karg.rec[at][0], karg.rec[at][1], karg.rec[at][2], karg.rec[at][3]);
+        } else if (use_karg == 2u) {
+            mcq_direct_fetch_dev(work_rec, at, karg.qi[0], karg.qi[1], res, pre_qi, pre_rec);
         } else {
             pre_qi = work_qi[at];
             pre_rec = work_rec[at];
@@ -633,8 +661,12 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_direct_kernel(const uint4 
                 pre_qi = MCQ_DIRECT_IDLE;
                 if (r < rounds) {
                     const size_t at = ((size_t)r * gridDim.x + blockIdx.x) * kWaves + threadIdx.x % kWaves;
-                    pre_qi = work_qi[at];
-                    pre_rec = work_rec[at];
+                    if (use_karg == 2u) {
+                        mcq_direct_fetch_dev(work_rec, at, karg.qi[0], karg.qi[1], res, pre_qi, pre_rec);
+                    } else {
+                        pre_qi = work_qi[at];
+                        pre_rec = work_rec[at];
+                    }
                 }
             }
             s_qi[threadIdx.x] = pre_qi;
@@ -673,7 +705,7 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_direct_kernel(const uint4 
                     const uint64_t it0 = (uint64_t)stream * MCQ_STREAM_ITERS + sub * chunk;
                     if (it0 < qc.runs) {
                         Draws dr;
-                        if (use_karg && round == 0u && task == 0u) {
+                        if (use_karg == 1u && round == 0u && task == 0u) {
                             dr = dr0; /* prepared while the table image was on its way */
                         } else {
                             dr.start(seed, first_qid + qi, stream);
@@ -1195,14 +1227,18 @@ hipError_t mcq_launch_eval(int mode, const mcq_query *d_q, uint32_t n, const uin
 hipError_t mcq_launch_eval_direct(int mode, const void *work_rec, const uint32_t *work_qi, uint32_t rounds, uint32_t merge,
                                   mcq_result *res, uint64_t seed, uint64_t first_qid, const McqTables *d_luts, uint32_t grid,
                                   uint32_t *d_done, uint32_t *done_flag, uint32_t ticket, hipStream_t s, hipEvent_t t0,
-                                  hipEvent_t t1, const McqDirectKarg *karg) {
+                                  hipEvent_t t1, const McqDirectKarg *karg, uint32_t dev_n, uint32_t dev_lg) {
     if (grid == 0 || rounds == 0) return hipErrorInvalidValue;
     if (karg && (uint64_t)grid * rounds * (kMaxBlock / 64) > MCQ_DIRECT_KARG_SLOTS) return hipErrorInvalidValue;
     if (karg && rounds > MCQ_DIRECT_STAGE_ROUNDS) return hipErrorInvalidValue; /* the kernel reads them in its first stage only */
+    if (dev_n && (karg || work_qi || dev_lg > 4u)) return hipErrorInvalidValue;
     const uint4 *rec = static_cast<const uint4 *>(work_rec);
     static const McqDirectKarg none = {};
-    const uint32_t use = karg ? 1u : 0u;
-    const McqDirectKarg &ka = karg ? *karg : none;
+    McqDirectKarg dev = {}; /* queries in HBM: their number and the cut travel in the argument block */
+    dev.qi[0] = dev_n;
+    dev.qi[1] = dev_lg;
+    const uint32_t use = dev_n ? 2u : karg ? 1u : 0u;
+    const McqDirectKarg &ka = dev_n ? dev : karg ? *karg : none;
     if (mode == MCQ_INTERNAL_MODE_UNIFORM)
         MCQ_LAUNCH_TIMED((mcq_eval_direct_kernel<MCQ_INTERNAL_MODE_UNIFORM>), grid, kMaxBlock, rec,
                               work_qi, rounds, merge, res, seed, first_qid, d_luts, d_done, done_flag, ticket, use, ka);

@@ -927,6 +927,68 @@ def test_multi_gpu_entry_partitions_equal_single_context(eng):
             me.close()
 
 
+def test_device_entry_for_small_queries_is_one_launch_and_equals_the_host_entry(eng):
+    """mcq_eval_batch_device_small: queries of at most 8192 iterations resident in HBM, ONE kernel launch (the one-launch
+    kernel lays its own work out: 2^lg waves per query from the query count alone, validation on the device).  Tallies
+    == the host entry's for every batch size regime (one query ... more than one round per block); an invalid query, one
+    without iterations and one that is too long get their marked rows; two streams at once; replay inside a HIP graph."""
+    import torch
+    dev = torch.device("cuda", 0)
+    g = np.random.default_rng(99)
+    for B in (1, 7, 300, 1024, 5000):
+        hole, board, npl = [], [], []
+        for i in range(B):
+            nb = [0, 3, 4, 5][i % 4]
+            c = g.permutation(52)[:2 + nb]
+            hole.append(c[:2])
+            board.append(list(c[2:]) + [255] * (5 - nb))
+            npl.append(1 + i % 10)
+        runs = g.choice([1, 63, 1000, 1024, 1025, 5000, 8192], B)
+        q = npa.pack_queries(hole, board, npl, runs)
+        want = u64(eng.eval_batch(q, seed=21, first_query_id=77))
+        bad = q.copy()
+        if B >= 7:
+            bad["hole"][2] = (9, 9)        # invalid: runs = 0, passes = 2^64 - 1
+            bad["runs"][3] = 0             # nothing to do: a row of zeros
+            bad["runs"][4] = 8193          # too long for this entry: marked like an invalid query
+            want = want.copy()
+            want[2] = 0; want[2, 1] = 2 ** 64 - 1
+            want[3] = 0
+            want[4] = 0; want[4, 1] = 2 ** 64 - 1
+        d_q = torch.from_numpy(bad.view(np.uint8).reshape(-1, 16).copy()).to(dev)
+        out = torch.full((B, 13), -7, dtype=torch.int64, device=dev)
+        eng.eval_batch_device_small(d_q.data_ptr(), B, 21, out.data_ptr(), first_query_id=77,
+                                    stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), want), B
+    # two streams at once, then a graph replay
+    qa = npa.pack_queries([g.permutation(52)[:2] for _ in range(700)], np.full((700, 5), 255, np.uint8), 6, 1000)
+    qb = npa.pack_queries([g.permutation(52)[:2] for _ in range(90)], np.full((90, 5), 255, np.uint8), 2, 3000)
+    wa, wb = u64(eng.eval_batch(qa, 1)), u64(eng.eval_batch(qb, 2))
+    da = torch.from_numpy(qa.view(np.uint8).reshape(-1, 16).copy()).to(dev)
+    db = torch.from_numpy(qb.view(np.uint8).reshape(-1, 16).copy()).to(dev)
+    oa = torch.zeros((700, 13), dtype=torch.int64, device=dev)
+    ob = torch.zeros((90, 13), dtype=torch.int64, device=dev)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        eng.eval_batch_device_small(da.data_ptr(), 700, 1, oa.data_ptr(), stream=s1.cuda_stream)
+        eng.eval_batch_device_small(db.data_ptr(), 90, 2, ob.data_ptr(), stream=s2.cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(oa.cpu().numpy().view(np.uint64), wa) and np.array_equal(ob.cpu().numpy().view(np.uint64), wb)
+    s = torch.cuda.Stream()
+    eng.eval_batch_device_small(da.data_ptr(), 700, 1, oa.data_ptr(), stream=s.cuda_stream)   # the stream's slot exists now
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        eng.eval_batch_device_small(da.data_ptr(), 700, 1, oa.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    for _ in range(3):
+        oa.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(oa.cpu().numpy().view(np.uint64), wa)
+
+
 def test_device_entry_on_two_streams_at_once(eng):
     """Two asynchronous device-entry calls in flight on different streams of one context: each stream has its own
     scheduling scratch, so neither disturbs the other (and a host-entry call in between uses the context's own)."""

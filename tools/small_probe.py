@@ -85,6 +85,17 @@ def main():
             eng.set_kernel_timing(False)
             dt, _ = timeit(devf, 200)
             print("%-26s device entry: call+sync %7.1f us  kernel %7.1f us" % ("%d x 1000 runs (mix)" % n, dt * 1e6, k * 1e3))
+
+            def devs(i):
+                eng.eval_batch_device_small(d_q.data_ptr(), n, i, out.data_ptr(), stream=s.cuda_stream)
+                torch.cuda.synchronize()
+                kt = eng.kernel_times(1)
+                return float(kt[0]) if len(kt) else 0.0
+            eng.set_kernel_timing(True)
+            _, k = timeit(devs, 200)
+            eng.set_kernel_timing(False)
+            dt, _ = timeit(devs, 200)
+            print("%-26s device entry, one launch (small): call+sync %7.1f us  kernel %7.1f us" % ("%d x 1000 runs (mix)" % n, dt * 1e6, k * 1e3))
     except ImportError:
         pass
     seats = [("equity", .5, -.5), ("equity", .8, -.8), ("equity", .7, -.7), ("equity", .2, -.3), ("random",), ("random",)]
