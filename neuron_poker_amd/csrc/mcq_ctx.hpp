@@ -137,6 +137,7 @@ struct mcq_ctx {
     McqDirectKarg direct_karg; /* one-launch path: the work of a small launch, passed by value */
     size_t publish_max_rows = 8192; /* host-buffer calls of at most this many rows get them through mcq_publish_kernel + flag (MCQ_PUBLISH_MAX_ROWS, 0 = never) */
     bool timing = false; /* mcq_set_kernel_timing: launches carry timestamp events */
+    bool ext_small = true; /* a few extended queries of the production mode in one launch (MCQ_EXT_SMALL=0: always the general path) */
     size_t direct_uniform_min = 128; /* one-launch path: from this many queries on the kernel lays its own work out (MCQ_DIRECT_UNIFORM_MIN; measured: 512 queries 39 -> 33 us per call, 1024: 48 -> 42, 4096: 137 -> 113) */
     bool direct_poll = true;      /* pick the rows up at the flag instead of synchronising the stream (MCQ_DIRECT_POLL) */
     McqDirectLayout direct_layout;      /* the one-launch path's layout of the current call */

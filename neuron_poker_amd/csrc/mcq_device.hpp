@@ -920,6 +920,25 @@ MCQ_HD uint32_t mcq_ext_n_lists(const McqQueryWords &q, const McqExtRec &e) {
     return n;
 }
 
+/* Streams of the production mode (MCQ-CTR v5x): a query that draws from candidate lists and has at most
+ * MCQ_EXT_SHORT_RUNS iterations cuts them into streams of MCQ_EXT_SHORT_STREAM iterations instead of MCQ_STREAM_ITERS --
+ * a trial loop consumes a number of words nobody knows beforehand, so a stream cannot be entered half way as the plain
+ * path's can, and a 1000-run query would otherwise be 63 lanes of ONE wave, sixteen iterations each, one behind the
+ * other (34 us); so it is 500 lanes of eight waves, two iterations each.  Long queries keep the long streams (one
+ * Philox block per sixteen iterations), and so does a query without lists: it deals exactly as the plain path. */
+#define MCQ_EXT_SHORT_STREAM 2u
+#define MCQ_EXT_SHORT_RUNS 8192u
+MCQ_HD uint32_t mcq_ext_stream_iters(const McqQueryWords &q, const McqExtRec &e) {
+    return q.runs() <= MCQ_EXT_SHORT_RUNS && mcq_ext_n_lists(q, e) != 0u ? MCQ_EXT_SHORT_STREAM : MCQ_STREAM_ITERS;
+}
+/* wave tasks (64 streams) of a query whose streams hold s_iters iterations, and what one costs (the unit of the cost
+ * axis the kernels cut: three per weight and two iterations of a stream) */
+MCQ_HD uint32_t mcq_ext_task_count(const McqQueryWords &q, uint32_t s_iters) {
+    const uint32_t per = s_iters * MCQ_WAVE;
+    return q.runs() / per + (q.runs() % per != 0u ? 1u : 0u);
+}
+MCQ_HD uint32_t mcq_ext_task_weight(const McqQueryWords &q, uint32_t s_iters) { return 3u * mcq_task_weight(q) * (s_iters >> 1); }
+
 MCQ_HD uint64_t mcq_ext_base_deck(const McqQueryWords &q, const McqExtRec &e) { /* 52 cards minus ghost and table */
     uint64_t deck = (1ull << 52) - 1;
     for (uint32_t i = 0; i < q.n_board(); i++) deck &= ~(1ull << q.card(2u + i));
@@ -1173,14 +1192,16 @@ MCQ_HD bool mcq_iteration_ext(const McqExtCtx &qc, const McqExtWaveCtx &wc, Draw
 // (unrolled over the opponent number, as in mcq_iteration) instead of travelling through LDS as card ids, the deck's
 // length is known without counting (every lane deals two cards per opponent), hero's hand is part of the query context.
 // 6-max at the top quarter of the classes: ~1650 -> ~900 VALU instructions per wave-iteration.
-template <class Draws>
+// (PIN: keep the opponent count in a scalar register of its own, see mcq_opaque_uniform; the one-launch kernel, whose
+// query context comes out of LDS, cannot: the backend refuses the copy.)
+template <class Draws, bool PIN = true>
 MCQ_HD bool mcq_iteration_ext_fast(const McqExtCtx &qc, const McqExtWaveCtx &wc, Draws &dr, const McqCard *cards,
                                    const uint32_t *sel8, const uint32_t *tf, const uint32_t *tops, const uint32_t *sd,
                                    McqLaneAcc &acc) {
     uint64_t deck = ((uint64_t)qc.fdeck_hi << 32) | qc.fdeck_lo;
     const uint32_t n = wc.cnt[0];
     const uint16_t *list = wc.list[0];
-    const uint32_t n_opp = mcq_opaque_uniform(qc.n_players - 1u);
+    const uint32_t n_opp = PIN ? mcq_opaque_uniform(qc.n_players - 1u) : qc.n_players - 1u;
     McqHole opp[MCQ_MAX_OPP];
     bool dealt = true;
 #define MCQ_XOPP(P)                                                                                                 \
@@ -1216,7 +1237,7 @@ MCQ_HD bool mcq_iteration_ext_fast(const McqExtCtx &qc, const McqExtWaveCtx &wc,
     fs.from_board(b);
     const uint32_t hk = mcq_eval_key(b, fs, qc.hero, tf, tops, sd);
     uint32_t best = 0;
-    const uint32_t n_opp_e = mcq_opaque_uniform(qc.n_players - 1u);
+    const uint32_t n_opp_e = PIN ? mcq_opaque_uniform(qc.n_players - 1u) : qc.n_players - 1u;
 #define MCQ_XEVAL(P)                                                  \
     if (P < n_opp_e) {                                                \
         const uint32_t k = mcq_eval_key(b, fs, opp[P], tf, tops, sd); \

@@ -335,6 +335,7 @@ mcq_ctx *mcq_ctx_clone(const mcq_ctx *c) {
         d->direct_max_tasks = c->direct_max_tasks;
         d->direct_poll = c->direct_poll;
         d->direct_uniform_min = c->direct_uniform_min;
+        d->ext_small = c->ext_small;
         d->publish_max_rows = c->publish_max_rows;
         d->timing = c->timing;
         d->replay_device_bytes = c->replay_device_bytes;
@@ -421,6 +422,7 @@ mcq_ctx *mcq_create(int device, int flags) {
         c->direct_max_tasks = (uint32_t)(v < 0 ? 0 : v > (int)MCQ_DIRECT_TASKS_LIMIT ? (int)MCQ_DIRECT_TASKS_LIMIT : v);
     }
     if (const char *e = getenv("MCQ_DIRECT_POLL")) c->direct_poll = atoi(e) != 0;
+    if (const char *e = getenv("MCQ_EXT_SMALL")) c->ext_small = atoi(e) != 0; /* see mcq_eval_batch_ext */
     if (const char *e = getenv("MCQ_DIRECT_UNIFORM_MIN")) { /* tuning knob, see eval_host_philox */
         const long v = atol(e);
         c->direct_uniform_min = (size_t)(v < 0 ? 0 : v);
@@ -806,6 +808,7 @@ int mcq_eval_batch_ext(mcq_ctx *c, const mcq_query *q, const mcq_query_ext *ext,
     if (n > 0x7fffffffu) return mcq_fail(MCQ_EINVAL, "mcq_eval_batch_ext: n too large");
     uint64_t total_tasks = 0;
     uint32_t lists_stride = 1; /* candidate lists per query of the production mode: the batch's maximum */
+    uint32_t most_tasks = 0;
     for (size_t i = 0; i < n; i++) {
         const McqExtRec er = {reinterpret_cast<const uint32_t *>(&ext[i])};
         const McqQueryWords qw = mcq_query_words(q[i]);
@@ -817,13 +820,69 @@ int mcq_eval_batch_ext(mcq_ctx *c, const mcq_query *q, const mcq_query_ext *ext,
         }
         const uint32_t nl = mcq_ext_n_lists(qw, er);
         if (nl > lists_stride) lists_stride = nl;
-        total_tasks += tasks_of(q[i]);
+        const uint32_t t = mcq_ext_task_count(qw, mode == MCQ_MODE_PHILOX ? mcq_ext_stream_iters(qw, er) : MCQ_STREAM_ITERS);
+        total_tasks += t;
+        if (t > most_tasks) most_tasks = t;
     }
     if (total_tasks > 0xfffffff0ull) return mcq_fail(MCQ_EINVAL, "mcq_eval_batch_ext: too many iterations in one call");
     McqDeviceScope dev_(c->device);
     HIP_TRY(dev_.err);
-    HIP_TRY(c->h_q.reserve(n * (sizeof(mcq_query) + sizeof(mcq_query_ext))));
     HIP_TRY(c->h_res.reserve(n * sizeof(mcq_result)));
+    if (mode == MCQ_MODE_PHILOX && c->ext_small && n <= MCQ_EXT_SMALL_Q && lists_stride <= MCQ_EXT_SMALL_LISTS &&
+        most_tasks <= MCQ_EXT_SMALL_TASKS && !stream_capturing(c->stream)) {
+        /* what a decision of the reference's agents asks for -- one ranged query of a thousand iterations -- in ONE
+         * launch: the records in the kernel arguments, a block per query (lists laid out in its LDS), the rows into
+         * pinned memory, the flag: 140 -> ~25 us per call */
+        static_assert(sizeof(mcq_query_ext) == sizeof(((McqExtSmallKarg *)0)->ext[0]), "extension record in the kernel arguments");
+        McqExtSmallKarg karg;
+        uint32_t n_blocks = 0, first_block[MCQ_EXT_SMALL_Q + 1], tasks[MCQ_EXT_SMALL_Q];
+        for (size_t i = 0; i < n; i++) {
+            memcpy(karg.q[i], &q[i], sizeof(mcq_query));
+            memcpy(karg.ext[i], &ext[i], sizeof(mcq_query_ext));
+            const McqExtRec er = {reinterpret_cast<const uint32_t *>(&ext[i])};
+            const McqQueryWords qw = mcq_query_words(q[i]);
+            tasks[i] = mcq_ext_task_count(qw, mcq_ext_stream_iters(qw, er));
+        }
+        uint32_t wpb = 4; /* working waves per block: the fewest with which the launch's blocks suffice */
+        for (; wpb < 16u; wpb <<= 1) {
+            uint32_t need = 0;
+            for (size_t i = 0; i < n; i++) need += tasks[i] > wpb ? (tasks[i] + wpb - 1u) / wpb : 1u;
+            if (need <= MCQ_EXT_SMALL_BLOCKS) break;
+        }
+        for (size_t i = 0; i < n; i++) {
+            const uint32_t parts = tasks[i] > wpb ? (tasks[i] + wpb - 1u) / wpb : 1u;
+            first_block[i] = n_blocks;
+            for (uint32_t p = 0; p < parts; p++) karg.blk[n_blocks++] = (uint32_t)i | (p << 8) | (parts << 16) | (wpb << 24);
+        }
+        first_block[n] = n_blocks;
+        HIP_TRY(c->h_res.reserve(MCQ_EXT_SMALL_BLOCKS * sizeof(mcq_result)));
+        int rc = flag_ready(c);
+        if (rc) return rc;
+        const uint32_t ticket = next_ticket(c);
+        const int slot = (int)(c->n_timed % mcq_ctx::kRing);
+        const bool timed = c->timing;
+        c->last_ms = 0.f;
+        HIP_TRY(mcq_launch_eval_ext_small(&karg, n_blocks, (mcq_result *)c->h_res.dev, seed, first_query_id, c->d_luts,
+                                          (uint32_t *)c->d_done.p, (uint32_t *)c->h_flag.dev, ticket, c->stream,
+                                          timed ? c->ev0[slot] : nullptr, timed ? c->ev1[slot] : nullptr));
+        if (timed) c->n_timed++;
+        rc = wait_ticket(c, ticket, nullptr);
+        if (rc) return rc;
+        if (timed && mcq_kernel_times(c, &c->last_ms, 1) != 1) c->last_ms = 0.f;
+        const uint64_t *hr = (const uint64_t *)c->h_res.p; /* one 13-word row per block */
+        static_assert(sizeof(mcq_result) == 13 * sizeof(uint64_t), "result row");
+        for (size_t i = 0; i < n; i++) {
+            uint64_t row[13] = {q[i].runs};
+            for (uint32_t b = first_block[i]; b < first_block[i + 1]; b++) {
+                if (hr[13u * b] != q[i].runs)
+                    return mcq_fail(MCQ_EINVAL, "mcq_eval_batch_ext: a range cannot be dealt from the remaining cards");
+                for (int k = 1; k < 13; k++) row[k] += hr[13u * b + k];
+            }
+            memcpy(&out[i], row, sizeof row);
+        }
+        return MCQ_OK;
+    }
+    HIP_TRY(c->h_q.reserve(n * (sizeof(mcq_query) + sizeof(mcq_query_ext))));
     HIP_TRY(c->d_q.reserve(n * sizeof(mcq_query)));
     HIP_TRY(c->d_ext.reserve(n * sizeof(mcq_query_ext)));
     HIP_TRY(c->d_res.reserve(n * sizeof(mcq_result)));
@@ -852,7 +911,7 @@ int mcq_eval_batch_ext(mcq_ctx *c, const mcq_query *q, const mcq_query_ext *ext,
         HIP_TRY(c->d_off.reserve(n * sizeof(uint64_t)));
         HIP_TRY(hipMemcpyAsync(c->d_off.p, off, n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     }
-    HIP_TRY(mcq_launch_prep_ext((const mcq_query *)c->d_q.p, (const mcq_query_ext *)c->d_ext.p, (uint32_t)n,
+    HIP_TRY(mcq_launch_prep_ext((const mcq_query *)c->d_q.p, (const mcq_query_ext *)c->d_ext.p, (uint32_t)n, mode,
                                 (mcq_result *)c->d_res.p, (uint64_t *)c->scratch[0].prefix.p, c->stream));
     const int slot = (int)(c->n_timed % mcq_ctx::kRing);
     hipEvent_t t0 = c->timing ? c->ev0[slot] : nullptr; /* parity mode: the timed region starts in front of the stream walk */

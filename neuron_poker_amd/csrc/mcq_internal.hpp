@@ -30,7 +30,21 @@ hipError_t mcq_launch_exact(const McqExactJob *d_jobs, uint32_t n_jobs, uint32_t
 hipError_t mcq_launch_showdown(const uint8_t *hands, uint32_t n_tables, uint32_t n_players, const McqTables *d_luts,
                                uint8_t *winner, uint8_t *wtype, uint32_t *keys, uint32_t *bad, uint32_t *d_done,
                                uint32_t *done_flag, uint32_t ticket, uint32_t n_cu, hipStream_t s);
-hipError_t mcq_launch_prep_ext(const mcq_query *d_q, const mcq_query_ext *d_ext, uint32_t n, mcq_result *d_res,
+/* a few extended queries in one launch (mcq_eval_ext_small_kernel): the queries and their extension records travel in
+ * the kernel arguments */
+#define MCQ_EXT_SMALL_Q 8u      /* queries per launch (8 x 320 B of kernel arguments) */
+#define MCQ_EXT_SMALL_LISTS 6u  /* candidate lists per query that fit the block's LDS (6 x 2704 x 2 B) */
+#define MCQ_EXT_SMALL_TASKS 64u /* wave tasks per query */
+#define MCQ_EXT_SMALL_BLOCKS 32u /* blocks per launch: a query is cut into parts of 4, 8 or 16 wave tasks, whatever fits */
+struct McqExtSmallKarg {
+    uint32_t q[MCQ_EXT_SMALL_Q][4];
+    uint32_t ext[MCQ_EXT_SMALL_Q][76];
+    uint32_t blk[MCQ_EXT_SMALL_BLOCKS]; /* block b: query | part << 8 | parts << 16 | waves that take tasks << 24; its row goes to row b of the result buffer */
+};
+hipError_t mcq_launch_eval_ext_small(const McqExtSmallKarg *karg, uint32_t n_blocks, mcq_result *h_res_dev, uint64_t seed,
+                                     uint64_t first_qid, const McqTables *d_luts, uint32_t *d_done, uint32_t *done_flag,
+                                     uint32_t ticket, hipStream_t s, hipEvent_t t0, hipEvent_t t1);
+hipError_t mcq_launch_prep_ext(const mcq_query *d_q, const mcq_query_ext *d_ext, uint32_t n, int mode, mcq_result *d_res,
                                uint64_t *d_prefix, hipStream_t s);
 /* production mode of the extended queries: lays out the candidate lists (lists_stride per query, MCQ_EXT_LIST_STRIDE
  * uint16 entries each) and their lengths */

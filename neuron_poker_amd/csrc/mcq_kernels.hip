@@ -187,6 +187,7 @@ struct McqMtProducer {
     uint32_t mt[MCQ_MT_N + 64u];
 };
 __device__ __forceinline__ uint32_t mcq_mt_word_yb(const McqMtPairWave &w, uint32_t i) { return w.yb[w.cur][i]; }
+__device__ __forceinline__ void mcq_mt_emit_lane(McqMtPairWave &, bool, uint32_t, uint32_t, uint32_t, uint32_t) {}
 __device__ __forceinline__ void mcq_mt_next_block(McqMtPairWave &w) {
     __syncthreads(); /* the producer has filled the other buffer; it may now overwrite the one just parsed */
     if ((threadIdx.x & 63u) == 0u) {
@@ -770,7 +771,7 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_direct_kernel(const uint4 
 // mcq_ext_lists_kernel lays out once per query (mcq_device.hpp).  A range that could not be dealt zeroes the row's
 // `runs`.
 __global__ __launch_bounds__(1024) void mcq_prep_ext_kernel(const mcq_query *__restrict__ q,
-                                                            const mcq_query_ext *__restrict__ ext, uint32_t n,
+                                                            const mcq_query_ext *__restrict__ ext, uint32_t n, int mode,
                                                             mcq_result *__restrict__ res, uint64_t *__restrict__ prefix) {
     __shared__ uint64_t wave_tot[16];
     uint64_t carry = 0;
@@ -783,7 +784,8 @@ __global__ __launch_bounds__(1024) void mcq_prep_ext_kernel(const mcq_query *__r
             const McqQueryWords qq = {raw.x, raw.y, raw.z, raw.w};
             const McqExtRec er = {reinterpret_cast<const uint32_t *>(ext + i)};
             bool ok = mcq_query_ext_valid(qq, er);
-            cost = ok ? (uint64_t)mcq_task_count(qq) * (3u * mcq_task_weight(qq)) : 0ull;
+            const uint32_t s_iters = ok && mode == MCQ_MODE_PHILOX ? mcq_ext_stream_iters(qq, er) : MCQ_STREAM_ITERS;
+            cost = ok ? (uint64_t)mcq_ext_task_count(qq, s_iters) * mcq_ext_task_weight(qq, s_iters) : 0ull;
             uint64_t *r = reinterpret_cast<uint64_t *>(res + i);
             r[0] = ok ? qq.runs() : 0ull;
             r[1] = ok ? 0ull : ~0ull;
@@ -942,7 +944,7 @@ __global__ __launch_bounds__(kExtBlock) void mcq_eval_ext_kernel(const mcq_query
         if (prefix[mid] <= lo) a = mid; else b = mid;
     }
     uint32_t qi = __builtin_amdgcn_readfirstlane(a);
-    uint32_t task = 0, n_tasks = 0, weight = 1;
+    uint32_t task = 0, n_tasks = 0, weight = 1, s_iters = MCQ_STREAM_ITERS;
     uint64_t pfx = 0;
     McqExtCtx qc;
     WaveTally tally;
@@ -955,12 +957,13 @@ __global__ __launch_bounds__(kExtBlock) void mcq_eval_ext_kernel(const mcq_query
             const McqQueryWords q = {raw.x, raw.y, raw.z, raw.w};
             pfx = prefix[qi];
             bool ok = prefix[qi + 1] > pfx;
-            weight = 3u * mcq_task_weight(q);
+            const McqExtRec er = {reinterpret_cast<const uint32_t *>(ext + qi)};
+            s_iters = ok && MODE == MCQ_MODE_PHILOX ? mcq_ext_stream_iters(q, er) : MCQ_STREAM_ITERS;
+            weight = mcq_ext_task_weight(q, s_iters);
             task = 0;
             if (pfx < lo) task = (uint32_t)((lo - pfx + weight - 1) / weight);
             fresh = false;
             if (ok) {
-                const McqExtRec er = {reinterpret_cast<const uint32_t *>(ext + qi)};
                 mcq_ext_ctx(q, er, qc);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 if (lane < 10u) wc.hand[lane] = lane < qc.n_hands ? mcq_ext_hand(q, er, lane) : 0u;
@@ -983,7 +986,7 @@ __global__ __launch_bounds__(kExtBlock) void mcq_eval_ext_kernel(const mcq_query
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
-            n_tasks = ok ? mcq_task_count(q) : 0u;
+            n_tasks = ok ? mcq_ext_task_count(q, s_iters) : 0u;
         }
         if (task >= n_tasks) {
             if (__any(failed)) {
@@ -1000,11 +1003,11 @@ __global__ __launch_bounds__(kExtBlock) void mcq_eval_ext_kernel(const mcq_query
         McqLaneAcc acc = {0, 0, 0};
         if (MODE == MCQ_MODE_PHILOX) {
             const uint32_t stream = task * MCQ_WAVE + lane;
-            const uint64_t it0 = (uint64_t)stream * MCQ_STREAM_ITERS;
+            const uint64_t it0 = (uint64_t)stream * s_iters;
             if (it0 < qc.runs) {
                 McqExtCtrDraws dr;
                 dr.start(seed, first_qid + qi, stream);
-                const uint32_t cnt = (uint32_t)min((uint64_t)MCQ_STREAM_ITERS, (uint64_t)qc.runs - it0);
+                const uint32_t cnt = (uint32_t)min((uint64_t)s_iters, (uint64_t)qc.runs - it0);
                 if (qc.fast) /* (wave-uniform) */
                     for (uint32_t j = 0; j < cnt && !failed; j++)
                         failed = !mcq_iteration_ext_fast(qc, wc, dr, cards, tab.sel8, g_tab->tf, tab.tops, tab.sd, acc);
@@ -1030,6 +1033,147 @@ __global__ __launch_bounds__(kExtBlock) void mcq_eval_ext_kernel(const mcq_query
     if (qi < n) {
         if (__any(failed) && lane == 0) atomicExch(reinterpret_cast<unsigned long long *>(res + qi), 0ull);
         tally.flush(res + qi, lane);
+    }
+}
+
+// A FEW extended queries in ONE launch (production mode; what a decision of the reference's agents asks for: ONE ranged
+// query of a thousand iterations, agent_*.py -> get_equity -> run_montecarlo).  The general path above is six stream
+// operations (two copies, prep, lists, evaluation, copy back: 140 us for such a query); here the queries travel in the
+// kernel arguments, a block takes ONE query, or one part of one -- a wave task per wave and as few working waves per
+// block as the launch's 32 blocks allow (4, 8 or 16: waves that share a SIMD take turns at its vector unit, one wave
+// per SIMD runs two iterations in 5 us, four in 9; all sixteen waves help with the tables and the lists): validates it, lays its candidate lists
+// out in its own LDS (what mcq_ext_lists_kernel does into HBM), runs its wave tasks, adds the waves' rows up in LDS and
+// stores the row into the host's pinned result buffer, one row per BLOCK (the host adds the parts of a query); the last
+// block to finish raises the completion flag (as mcq_eval_direct_kernel does).  The host sends queries here whose lists fit (at most MCQ_EXT_SMALL_LISTS) and
+// that have at most MCQ_EXT_SMALL_TASKS wave tasks.  Same streams, same draws, same tallies as the general path.
+__global__ __launch_bounds__(kExtBlock) void mcq_eval_ext_small_kernel(McqExtSmallKarg karg, mcq_result *__restrict__ res,
+                                                                       uint64_t seed, uint64_t first_qid,
+                                                                       const McqTables *__restrict__ g_tab,
+                                                                       uint32_t *__restrict__ done, volatile uint32_t *done_flag,
+                                                                       uint32_t ticket) {
+    constexpr uint32_t kWaves = kExtBlock / 64;
+    constexpr uint32_t kStageEntries = MCQ_EXT_SMALL_LISTS * MCQ_EXT_LIST_STRIDE;
+    __shared__ __attribute__((aligned(16))) LdsTablesEval tab;
+    __shared__ McqCard cards[64];
+    __shared__ McqExtWaveCtx wave_ctx; /* one query per block: one context */
+    __shared__ uint16_t ids[(MCQ_MAX_OPP + 1) * kExtBlock];
+    __shared__ __attribute__((aligned(16))) uint16_t s_lists[kStageEntries];
+    __shared__ uint32_t s_rec[4 + MCQ_EXT_WORDS];
+    __shared__ uint32_t wave_tot[kWaves];
+    __shared__ unsigned long long partial[kWaves][12];
+    __shared__ uint32_t s_failed;
+    const uint32_t blk = karg.blk[blockIdx.x], qi = blk & 0xFFu, part = (blk >> 8) & 0xFFu, parts = (blk >> 16) & 0xFFu, wpb = blk >> 24;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    if (tid < 64) cards[tid] = mcq_card(tid < 52 ? tid : 0u);
+    if (tid >= 4u && tid < 4u + MCQ_EXT_WORDS) s_rec[tid] = karg.ext[qi][tid - 4u];
+    if (tid == 0) s_failed = 0;
+    load_tables(tab, g_tab); /* (ends with a barrier) */
+    /* (the query words by scalar loads from the kernel arguments: the iteration wants n_players in an SGPR) */
+    const McqQueryWords q = {karg.q[qi][0], karg.q[qi][1], karg.q[qi][2], karg.q[qi][3]};
+    const McqExtRec er = {s_rec + 4};
+    const bool valid = __builtin_amdgcn_readfirstlane(mcq_query_ext_valid(q, er) ? 1 : 0) != 0;
+    const uint32_t n_lists = __builtin_amdgcn_readfirstlane(valid ? mcq_ext_n_lists(q, er) : 0u);
+    bool ok = valid && n_lists <= MCQ_EXT_SMALL_LISTS;
+    /* the candidate lists, in the order of 52 * a + b: every thread looks at three consecutive candidates, a block scan
+     * of the counts puts the survivors in order */
+    uint32_t list_at = 0;
+    for (uint32_t li = 0; li < n_lists && ok; li++) { /* (block-uniform) */
+        uint64_t U;
+        uint32_t set_off;
+        mcq_ext_list_plan(q, er, li, U, set_off);
+        constexpr uint32_t kPer = (2704u + kExtBlock - 1) / kExtBlock; /* 3 */
+        uint32_t mask = 0;
+        for (uint32_t k = 0; k < kPer; k++)
+            if (mcq_ext_candidate(U, er.w + set_off, tid * kPer + k)) mask |= 1u << k;
+        const uint32_t mine = (uint32_t)__popc(mask);
+        uint32_t inc = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(inc, off, 64);
+            if (lane >= (uint32_t)off) inc += o;
+        }
+        __syncthreads(); /* wave_tot of the previous list has been read */
+        if (lane == 63u) wave_tot[wv] = inc;
+        __syncthreads();
+        uint32_t at = inc - mine, total = 0;
+        for (uint32_t k = 0; k < kWaves; k++) {
+            at += k < wv ? wave_tot[k] : 0u;
+            total += wave_tot[k];
+        }
+        total = __builtin_amdgcn_readfirstlane(total);
+        uint16_t *dst = s_lists + list_at;
+        for (uint32_t k = 0; k < kPer; k++)
+            if ((mask >> k) & 1u) {
+                const uint32_t c = tid * kPer + k, a = c / 52u;
+                dst[at++] = (uint16_t)(a | ((c - 52u * a) << 8));
+            }
+        if (tid == 0) {
+            wave_ctx.cnt[li] = total;
+            wave_ctx.list[li] = s_lists + list_at;
+        }
+        if (total == 0u) ok = false; /* a range no pair of cards can satisfy: nothing to deal from */
+        list_at += total;
+    }
+    McqExtCtx qc;
+    mcq_ext_ctx(q, er, qc);
+    /* (what came out of the record in LDS is wave-uniform: say so) */
+    qc.deck_lo = __builtin_amdgcn_readfirstlane(qc.deck_lo);
+    qc.deck_hi = __builtin_amdgcn_readfirstlane(qc.deck_hi);
+    qc.fdeck_lo = __builtin_amdgcn_readfirstlane(qc.fdeck_lo);
+    qc.fdeck_hi = __builtin_amdgcn_readfirstlane(qc.fdeck_hi);
+    qc.n_hands = __builtin_amdgcn_readfirstlane(qc.n_hands);
+    qc.opp_all = __builtin_amdgcn_readfirstlane(qc.opp_all ? 1 : 0) != 0;
+    qc.fast = __builtin_amdgcn_readfirstlane(qc.fast ? 1 : 0) != 0;
+    if (tid < 10u) wave_ctx.hand[tid] = tid < qc.n_hands ? mcq_ext_hand(q, er, tid) : 0u;
+    if (tid >= 64u && tid < 64u + MCQ_EXT_MAX_LISTS && tid - 64u >= n_lists) { /* never read; defined all the same */
+        wave_ctx.cnt[tid - 64u] = 1u;
+        wave_ctx.list[tid - 64u] = s_lists;
+    }
+    __syncthreads();
+    const uint32_t s_iters = __builtin_amdgcn_readfirstlane(valid ? mcq_ext_stream_iters(q, er) : MCQ_STREAM_ITERS);
+    const uint32_t n_tasks = __builtin_amdgcn_readfirstlane(ok ? mcq_ext_task_count(q, s_iters) : 0u);
+    WaveTally tally;
+    tally.clear();
+    bool failed = false;
+    for (uint32_t task = part * wpb + __builtin_amdgcn_readfirstlane(wv); wv < wpb && task < n_tasks; task += parts * wpb) {
+        McqLaneAcc acc = {0, 0, 0};
+        const uint32_t stream = task * MCQ_WAVE + lane;
+        const uint64_t it0 = (uint64_t)stream * s_iters;
+        if (it0 < qc.runs) {
+            McqExtCtrDraws dr;
+            dr.start(seed, first_qid + qi, stream);
+            const uint32_t cnt = (uint32_t)min((uint64_t)s_iters, (uint64_t)qc.runs - it0);
+            if (qc.fast) /* (block-uniform) */
+                for (uint32_t j = 0; j < cnt && !failed; j++)
+                    failed = !mcq_iteration_ext_fast<McqExtCtrDraws, false>(qc, wave_ctx, dr, cards, tab.sel8, g_tab->tf, tab.tops, tab.sd, acc);
+            else
+                for (uint32_t j = 0; j < cnt && !failed; j++)
+                    failed = !mcq_iteration_ext(qc, wave_ctx, dr, cards, tab.sel8, ids + tid, kExtBlock, g_tab->tf, tab.tops, tab.sd, acc);
+        }
+        tally.add(acc);
+    }
+    if (__any(failed) && lane == 0) atomicOr(&s_failed, 1u);
+    const unsigned long long mine = tally.row_words(lane);
+    if (lane < 12u) partial[wv][lane] = mine;
+    __syncthreads();
+    if (tid < 13u) { /* word tid of the row */
+        unsigned long long v = 0;
+        if (tid > 0u)
+            for (uint32_t k = 0; k < kWaves; k++) v += partial[k][tid - 1u];
+        const bool bad = !ok || s_failed != 0u;
+        if (tid == 0u) v = bad ? 0ull : (unsigned long long)qc.runs;
+        else if (bad) v = tid == 1u && !valid ? ~0ull : 0ull; /* invalid: passes = UINT64_MAX, as mcq_prep_ext_kernel marks it */
+        reinterpret_cast<unsigned long long *>(res + blockIdx.x)[tid] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence_system(); /* this block's row has reached the host's memory */
+        bool last = true;
+        if (gridDim.x > 1u) {
+            last = atomicAdd(done, 1u) + 1u == gridDim.x;
+            if (last) *done = 0; /* ready for the next launch on this stream */
+        }
+        if (last) *done_flag = ticket;
     }
 }
 
@@ -1289,9 +1433,9 @@ hipError_t mcq_launch_add_u64(uint64_t *d_dst, const uint64_t *d_src, uint64_t n
     return hipGetLastError();
 }
 
-hipError_t mcq_launch_prep_ext(const mcq_query *d_q, const mcq_query_ext *d_ext, uint32_t n, mcq_result *d_res,
+hipError_t mcq_launch_prep_ext(const mcq_query *d_q, const mcq_query_ext *d_ext, uint32_t n, int mode, mcq_result *d_res,
                                uint64_t *d_prefix, hipStream_t s) {
-    hipLaunchKernelGGL(mcq_prep_ext_kernel, dim3(1), dim3(1024), 0, s, d_q, d_ext, n, d_res, d_prefix);
+    hipLaunchKernelGGL(mcq_prep_ext_kernel, dim3(1), dim3(1024), 0, s, d_q, d_ext, n, mode, d_res, d_prefix);
     return hipGetLastError();
 }
 
@@ -1313,6 +1457,14 @@ hipError_t mcq_launch_eval_ext(int mode, const mcq_query *d_q, const mcq_query_e
     else
         MCQ_LAUNCH_TIMED(mcq_eval_ext_kernel<MCQ_MODE_REPLAY_MT19937>, grid, block, d_q, d_ext,
                               n, d_prefix, d_res, seed, first_qid, d_luts, d_draws, d_draw_off, d_lists, d_cnts, lists_stride);
+    return hipGetLastError();
+}
+
+hipError_t mcq_launch_eval_ext_small(const McqExtSmallKarg *karg, uint32_t n, /* blocks */ mcq_result *h_res_dev, uint64_t seed,
+                                     uint64_t first_qid, const McqTables *d_luts, uint32_t *d_done, uint32_t *done_flag,
+                                     uint32_t ticket, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
+    if (n == 0 || n > MCQ_EXT_SMALL_BLOCKS) return hipErrorInvalidValue;
+    MCQ_LAUNCH_TIMED(mcq_eval_ext_small_kernel, n, kExtBlock, *karg, h_res_dev, seed, first_qid, d_luts, d_done, done_flag, ticket);
     return hipGetLastError();
 }
 

@@ -215,6 +215,7 @@ MCQ_HD void mcq_mt_regenerate(W &w) {
 // bytes, the parsing wave only reads bytes.
 MCQ_HD uint32_t mcq_mt_word_yb(const McqMtWave &w, uint32_t i) { return (mcq_mt_temper(w.mt[i]) & 63u) | 0x80u; }
 MCQ_HD void mcq_mt_next_block(McqMtWave &w) { mcq_mt_regenerate(w); }
+MCQ_HD void mcq_mt_emit_lane(McqMtWave &, bool, uint32_t, uint32_t, uint32_t, uint32_t) {}
 
 struct McqMtState { /* wave-uniform */
     uint32_t pos;     /* next unread state word, 624 = regenerate first */
@@ -334,6 +335,13 @@ MCQ_HD void mcq_mt_batch(W &w, McqMtState &st, const McqMtPlan &pl) {
         p_end = st.d0 + mcq_mt_popc64(M) - 2u;
     }
     MCQ_MT_STAMP(4);
+    /* walks that parse a query's blocks side by side (mcq_mt_blocks.hpp) send the FINAL draws of the batch straight to
+     * the draw buffer: a pair by its r2 (with the r1 it has just read), a table card by itself; a pair that is drawn
+     * again sends nothing.  (One wave per query: nothing to do, the ring is flushed in rows.) */
+    {
+        const uint64_t Mf = R ? M & ~((uint64_t)1 << mcq_mt_low64(R)) : M;
+        MCQ_FOR_LANES(l) { mcq_mt_emit_lane(w, MCQ_LANE_OF(Mf, l), MCQ_L(t), MCQ_L(v), MCQ_L(pv), st.it_done); }
+    }
     st.passes += n_r2; /* one accepted r2 per attempt (l.168) */
     const uint32_t it_add = (p_end * pl.magic) >> 16;
     st.d0 = p_end - it_add * pl.D;

@@ -69,6 +69,7 @@ def configure(mode=None, couple_numpy=None, dealing=None):
 
 
 _CLASS_ORDER = None
+_TOP_BITS = {}   # take -> bit set of the last `take` classes of the equity order
 
 
 def _class_order():
@@ -89,8 +90,41 @@ def _opponent_range_bits(opponent_range):
         take = int(169 * opponent_range)
         if take <= 0 or take >= 169:
             return None
-        return _lib.range_bits(_class_order()[-take:])
+        bits = _TOP_BITS.get(take)
+        if bits is None:
+            bits = _TOP_BITS[take] = _lib.range_bits(_class_order()[-take:])
+        return bits
     return _lib.range_bits(opponent_range)
+
+
+_EXT_CACHE = {}   # (opponent_range, ghost_cards, hero range, further known hands) -> mcq_query_ext record (1-element array)
+
+
+def _ext_record(hero, hero_is_range, known_hands, ghost_cards, opponent_range, opp_bits):
+    """The extension record of a run_montecarlo call.  An agent asks with the same ranges decision after decision (what
+    changes is its cards and the table), and building the record -- class strings to bit sets, a numpy structured
+    array -- costs more than the GPU call (60 of 86 us): the records of the last few distinct settings are kept."""
+    def freeze(h):
+        return frozenset(h) if isinstance(h, (set, frozenset)) else tuple(h)
+    try:
+        key = (opponent_range if type(opponent_range) in (float, int) else frozenset(opponent_range),
+               ghost_cards if isinstance(ghost_cards, str) or ghost_cards is None else tuple(ghost_cards),
+               frozenset(hero) if hero_is_range else None, tuple(freeze(h) for h in known_hands))
+        ext = _EXT_CACHE.get(key)
+    except TypeError:  # something unhashable inside: build it afresh
+        key, ext = None, None
+    if ext is None:
+        ghost = None
+        if ghost_cards != '' and ghost_cards is not None:
+            ghost = [card_id(ghost_cards[0]), card_id(ghost_cards[1])]
+        known = [_lib.range_bits(h) if isinstance(h, (set, frozenset)) else [card_id(c) for c in h] for h in known_hands]
+        ext = _lib.pack_query_ext(1, ghost=ghost, known=known,
+                                  hero_range=_lib.range_bits(hero) if hero_is_range else None, opp_range=opp_bits)
+        if key is not None:
+            if len(_EXT_CACHE) >= 64:
+                _EXT_CACHE.clear()
+            _EXT_CACHE[key] = ext
+    return ext
 
 
 def _take_ids(n):
@@ -147,14 +181,15 @@ class MonteCarlo(object):
         else:
             if hero_is_range:
                 q["hole"] = 0
-            ghost = None
-            if ghost_cards != '' and ghost_cards is not None:
-                ghost = [card_id(ghost_cards[0]), card_id(ghost_cards[1])]
-            known = [_lib.range_bits(h) if isinstance(h, (set, frozenset)) else [card_id(c) for c in h] for h in players[1:]]
-            ext = _lib.pack_query_ext(1, ghost=ghost, known=known,
-                                      hero_range=_lib.range_bits(hero) if hero_is_range else None, opp_range=opp_bits)
+            ext = _ext_record(hero, hero_is_range, players[1:], ghost_cards, opponent_range, opp_bits)
             s, first = _take_ids(1) if seed is None else (int(seed), 0)
-            res = eng.eval_batch_ext(q, ext, s, first_query_id=first, mode=m)[0]
+            # (straight to the C ABI: Engine.eval_batch_ext's conversions of arrays that are already right cost 8 us)
+            out = np.zeros(1, _lib.RESULT_DTYPE)
+            rc = eng._lib.mcq_eval_batch_ext(eng._ctx, q.ctypes.data, ext.ctypes.data, 1, s & 0xFFFFFFFFFFFFFFFF,
+                                             first & 0xFFFFFFFFFFFFFFFF, m, out.ctypes.data)
+            if rc:
+                _lib._raise(rc)
+            res = out[0]
         runs = int(res["runs"])
         wins = int(res["win"]) + int(res["tie"])
         self.result = res

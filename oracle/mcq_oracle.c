@@ -590,6 +590,8 @@ static int in_range(const uint32_t *bits, uint8_t a, uint8_t b) {
  * index exactly as the plain mode deals them (one word per pair, never re-drawn), so a query that restricts nothing
  * gives the plain mode's tallies.  65536 failed trials in a row = the range cannot be dealt: -2. */
 #define EX_MAX_TRIALS 65536u
+#define EX_SHORT_STREAM 2u
+#define EX_SHORT_RUNS 8192u
 int mcqo_run_ex2(int mode, int n_known, const uint8_t *known_cards, const uint32_t *known_ranges, const uint8_t *ghost,
                  const uint8_t *board, int nb, int n_players, uint32_t runs, uint64_t seed, uint64_t qid,
                  const uint32_t *opp_range, uint64_t *out, uint64_t *total_words) {
@@ -620,6 +622,10 @@ int mcqo_run_ex2(int mode, int n_known, const uint8_t *known_cards, const uint32
     /* production mode: the candidate lists (index n_known = the opponents') */
     static __thread uint16_t plist[11][2704];
     uint32_t pcount[11];
+    /* streams: STREAM_ITERS iterations each, but EX_SHORT_STREAM for a query of at most EX_SHORT_RUNS iterations that
+     * draws from at least one candidate list (a trial loop takes an unknown number of words, so such a stream cannot be
+     * entered half way: short streams are what lets a small query spread over many lanes) */
+    uint32_t stream_iters = STREAM_ITERS;
     if (mode == 1) {
         uint64_t u = (1ull << 52) - 1;
         if (ghost) u &= ~((1ull << ghost[0]) | (1ull << ghost[1]));
@@ -634,12 +640,13 @@ int mcqo_run_ex2(int mode, int n_known, const uint8_t *known_cards, const uint32
                         if (a != b && (u >> a) & 1 && (u >> b) & 1 && in_range(set, (uint8_t)a, (uint8_t)b))
                             plist[h][pcount[h]++] = (uint16_t)(a | (b << 8));
             if (wanted && pcount[h] == 0) return -2;
+            if (wanted && runs <= EX_SHORT_RUNS) stream_iters = EX_SHORT_STREAM;
             if (h < n_known && known_cards[2 * h] != 0xFF)
                 u &= ~((1ull << known_cards[2 * h]) | (1ull << known_cards[2 * h + 1]));
         }
     }
     for (uint32_t it = 0; it < runs; it++) {
-        if (mode == 1 && it % STREAM_ITERS == 0) js_seed(&xo, seed, qid, it / STREAM_ITERS);
+        if (mode == 1 && it % stream_iters == 0) js_seed(&xo, seed, qid, it / stream_iters);
         deck_t d = original;
         uint8_t table[5], hole[10][2], hands[70];
         int w = 0; /* table draws of this iteration (CTR: two per word) */

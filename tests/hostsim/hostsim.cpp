@@ -218,13 +218,14 @@ extern "C" int hs_run_ext(int replay, const mcq_query *q, const mcq_query_ext *e
         }
         return MCQ_OK;
     }
-    uint32_t n_streams = (q->runs + MCQ_STREAM_ITERS - 1) / MCQ_STREAM_ITERS;
+    const uint32_t s_iters = mcq_ext_stream_iters(qw, er);
+    uint32_t n_streams = (q->runs + s_iters - 1) / s_iters;
     for (uint32_t s = 0; s < n_streams; s++) {
         McqExtCtrDraws dr;
         dr.start(seed, qid, s);
         McqLaneAcc acc = {0, 0, 0};
-        for (uint32_t j = 0; j < MCQ_STREAM_ITERS; j++) {
-            if ((uint64_t)s * MCQ_STREAM_ITERS + j >= q->runs) break;
+        for (uint32_t j = 0; j < s_iters; j++) {
+            if ((uint64_t)s * s_iters + j >= q->runs) break;
             if (!(qc.fast ? mcq_iteration_ext_fast(qc, wc, dr, cards, t.sel8, t.tf, t.tops, t.sd, acc)   /* as the kernel picks */
                           : mcq_iteration_ext(qc, wc, dr, cards, t.sel8, ids, 1, t.tf, t.tops, t.sd, acc)))
                 return MCQ_EINVAL;

@@ -387,6 +387,53 @@ def test_ranges_ghost_cards_known_hands(eng):
                                           ghost_cards="", opponent_range={"AA"}, seed=3)
 
 
+def test_extended_queries_one_launch_path(eng):
+    """A few extended queries per call (what a decision of the reference's agents asks: one ranged query, agent_*.py ->
+    get_equity) take ONE launch (mcq_eval_ext_small_kernel: lists laid out in the block's LDS, row into pinned
+    memory); more than eight take the general path (prep, lists, evaluation kernels).  Same streams -- two iterations
+    each for a query of at most 8192 iterations that draws from a list, MCQ-CTR v5x -- so the same tallies, and both
+    equal the oracle's."""
+    from neuron_poker_amd import _lib
+    ranks = "23456789TJQKA"
+    classes = [a + a for a in ranks] + [ranks[i] + ranks[j] + t for i in range(13) for j in range(i) for t in "SO"]  # 169
+    g = np.random.default_rng(77)
+    n = 14
+    q = np.zeros(n, npa.QUERY_DTYPE)
+    e = np.zeros(n, npa.QUERY_EXT_DTYPE)
+    spec = []
+    for i in range(n):
+        nb = int(g.choice([0, 3, 4, 5]))
+        c = [int(x) for x in g.permutation(52)[:14 + nb]]
+        pick = lambda lo, hi: sorted(g.choice(classes, size=int(g.integers(lo, hi)), replace=False))
+        hero_range = pick(25, 90) if i % 5 == 4 else None
+        opp = pick(20, 160) if i % 7 != 6 else None
+        ghost = c[2:4] if i % 3 == 0 else None
+        known = [pick(30, 100) if (i + k) % 3 == 0 else c[4 + 2 * k:6 + 2 * k] for k in range(i % 4)]
+        npl = int(g.integers(max(2, 1 + len(known)), 8))
+        runs = [1, 127, 128, 129, 1000, 2047, 4500, 8192, 8193, 0, 1000, 300, 64, 6000][i]
+        q[i] = _lib.pack_queries([[0, 1] if hero_range else c[:2]], [c[14:] + [255] * (5 - nb)], npl, runs)[0]
+        if hero_range:
+            q["hole"][i] = 0
+        e[i] = _lib.pack_query_ext(1, ghost=ghost, known=[h if isinstance(h[0], int) else _lib.range_bits(h) for h in known],
+                                   hero_range=_lib.range_bits(hero_range) if hero_range else None,
+                                   opp_range=_lib.range_bits(opp) if opp else None)[0]
+        spec.append((hero_range if hero_range else c[:2], c[14:], npl, runs, known, ghost, opp))
+    whole = u64(eng.eval_batch_ext(q, e, 5, first_query_id=100))  # 14 queries: the general path
+    for lo, hi in ((0, 8), (8, 14), (3, 4), (8, 9)):  # at most eight: one launch
+        assert np.array_equal(u64(eng.eval_batch_ext(q[lo:hi], e[lo:hi], 5, first_query_id=100 + lo)), whole[lo:hi]), (lo, hi)
+    for i, (hero, board, npl, runs, known, ghost, opp) in enumerate(spec):
+        want = O.run_ex(O.MODE_CTR, hero, board, npl, runs, 5, qid=100 + i, known=known, ghost=ghost, opp_range=opp)["tallies"]
+        assert np.array_equal(whole[i], want), (i, spec[i])
+    # a range that cannot be dealt, and an invalid record, on the one-launch path
+    with pytest.raises(ValueError):
+        mh.MonteCarlo(eng).run_montecarlo([["AS", "AH"]], ["AD", "AC", "2C"], 2, 1, maxRuns=100, timeout=0,
+                                          ghost_cards="", opponent_range={"AA"}, seed=3)
+    bad = e[:1].copy()
+    bad["ghost"] = q["hole"][0]  # the ghost cards are hero's
+    with pytest.raises(ValueError):
+        eng.eval_batch_ext(q[:1], bad, 1)
+
+
 def test_table_driver_reproduces_reference_episodes_on_gpu(eng):
     """seeded episodes of the reference's own table (tests/golden/env_traces.json) replayed by
     neuron_poker_amd/table_driver.py with the GPU doing every equity query (parity mode on numpy's global
