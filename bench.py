@@ -484,6 +484,45 @@ def main():
                 dt = time.perf_counter() - t1
                 extras["ext_opponents_top25pct_256x6x20k_replay"] = {"call_ms_host_buffers": 1e3 * dt,
                                                                      "hand_evals_per_s": 256 * 6 * 20000 / dt}
+                # ... and as 16 384 queries of 2 500 iterations: the stream walk is serial per query (one wave each), so
+                # its throughput is a matter of how many queries are in flight -- this is where it levels off
+                g16 = np.random.default_rng(16384)
+                c16 = g16.random((16384, 52)).argsort(axis=1)[:, :2].astype(np.uint8)
+                q16 = npa.pack_queries(c16, np.full((16384, 5), 255, np.uint8), 6, 2500)
+                e16 = npa.pack_query_ext(16384, opp_range=npa.range_bits(order[-int(169 * 0.25):]))
+                eng.eval_batch_ext(q16[:256], e16[:256], 1, mode=npa.MODE_REPLAY_MT19937)
+                t1 = time.perf_counter()
+                eng.eval_batch_ext(q16, e16, 2, mode=npa.MODE_REPLAY_MT19937)
+                dt = time.perf_counter() - t1
+                extras["ext_opponents_top25pct_16384x6x2500_replay"] = {"call_ms_host_buffers": 1e3 * dt,
+                                                                        "hand_evals_per_s": 16384 * 6 * 2500 / dt}
+                # what a decision of the reference's agents asks for: ONE ranged query of 1000 iterations per call
+                # (agent_*.py -> get_equity / run_montecarlo with opponent_range): the one-launch path of
+                # mcq_eval_batch_ext, and the whole Python shim around it
+                q1, e1 = npa.pack_queries(hole[:1], board[:1], 4, 1000), npa.pack_query_ext(1, opp_range=npa.range_bits(order[-42:]))
+                eng.eval_batch_ext(q1, e1, 0)
+                kms = eng.last_kernel_ms
+                eng.set_kernel_timing(False)  # (timestamped launches cost a small call 6 us)
+                for i in range(20):
+                    eng.eval_batch_ext(q1, e1, i)
+                t1 = time.perf_counter()
+                for i in range(200):
+                    eng.eval_batch_ext(q1, e1, i)
+                dt = (time.perf_counter() - t1) / 200
+                from neuron_poker_amd import montecarlo_hip as mh
+                sim = mh.MonteCarlo(eng)
+                for i in range(20):
+                    sim.run_montecarlo([["AH", "KH"]], ["2C", "7D", "JS"], 4, 1, maxRuns=1000, timeout=0, ghost_cards="",
+                                       opponent_range=0.25, seed=i)
+                t1 = time.perf_counter()
+                for i in range(200):
+                    sim.run_montecarlo([["AH", "KH"]], ["2C", "7D", "JS"], 4, 1, maxRuns=1000, timeout=0, ghost_cards="",
+                                       opponent_range=0.25, seed=i)
+                dts = (time.perf_counter() - t1) / 200
+                eng.set_kernel_timing(True)
+                extras["ext_single_ranged_query_4x1000"] = {"call_us_host_buffers": 1e6 * dt, "kernel_ms": kms,
+                                                            "run_montecarlo_call_us": 1e6 * dts,
+                                                            "hand_evals_per_s": 4 * 1000 / dt}
             # BASELINE configs[3] (the 8-GPU config) on this one GPU: 65 536 states, flop / turn tables alternating, 6 players,
             # 20k iterations, host buffers; one rank of 8 would take an eighth of the queries
             g3 = np.random.default_rng(65536)

@@ -132,7 +132,10 @@ MCQ_API int mcq_eval_one(mcq_ctx *ctx, const mcq_query *q, uint64_t seed, int mo
  * MCQ_MODE_PHILOX deals the reference's law without its re-draw loops: per range, a list of the ordered card pairs
  * the range allows is laid out once per query, a trial picks one of them with one random word and is accepted iff
  * both cards are still in the deck (and the second is not the deck's highest card, which the reference's index
- * range excludes) -- `passes` counts these trials, not the reference's. */
+ * range excludes) -- `passes` counts these trials, not the reference's.  Streams (MCQ-CTR v5x): as mcq_eval_batch,
+ * sixteen iterations each, but two for a query that draws from a list and has at most 8192 iterations.
+ * Up to eight queries of at most 8192 iterations (six candidate lists) per call take ONE kernel launch: the call
+ * pattern of the reference's agents, one ranged query per decision -- 25 us per call. */
 MCQ_API int mcq_eval_batch_ext(mcq_ctx *ctx, const mcq_query *q, const mcq_query_ext *ext, size_t n, uint64_t seed,
                        uint64_t first_query_id, int mode, mcq_result *out);
 

@@ -588,7 +588,9 @@ static int in_range(const uint32_t *bits, uint8_t a, uint8_t b) {
  * deck.pop(r1); deck.pop(r2) deal, B if B lies below A, else the card that follows B in the deck.  Table cards as
  * in the plain mode (two per word, never the highest card).  Opponents to whom every class is allowed are dealt by
  * index exactly as the plain mode deals them (one word per pair, never re-drawn), so a query that restricts nothing
- * gives the plain mode's tallies.  65536 failed trials in a row = the range cannot be dealt: -2. */
+ * gives the plain mode's tallies.  65536 failed trials in a row = the range cannot be dealt: -2.  Streams: sixteen
+ * iterations each as in the plain mode, but EX_SHORT_STREAM for a query of at most EX_SHORT_RUNS iterations that draws
+ * from at least one candidate list (see below). */
 #define EX_MAX_TRIALS 65536u
 #define EX_SHORT_STREAM 2u
 #define EX_SHORT_RUNS 8192u
