@@ -137,6 +137,7 @@ struct mcq_ctx {
     McqDirectKarg direct_karg; /* one-launch path: the work of a small launch, passed by value */
     size_t publish_max_rows = 8192; /* host-buffer calls of at most this many rows get them through mcq_publish_kernel + flag (MCQ_PUBLISH_MAX_ROWS, 0 = never) */
     bool timing = false; /* mcq_set_kernel_timing: launches carry timestamp events */
+    bool mt_blocks = true; /* parity mode, few long queries: the state blocks of a query parsed side by side (MCQ_MT_BLOCKS=0: always the serial walk) */
     bool ext_small = true; /* a few extended queries of the production mode in one launch (MCQ_EXT_SMALL=0: always the general path) */
     size_t direct_uniform_min = 128; /* one-launch path: from this many queries on the kernel lays its own work out (MCQ_DIRECT_UNIFORM_MIN; measured: 512 queries 39 -> 33 us per call, 1024: 48 -> 42, 4096: 137 -> 113) */
     bool direct_poll = true;      /* pick the rows up at the flag instead of synchronising the stream (MCQ_DIRECT_POLL) */
@@ -151,7 +152,17 @@ int mcq_validate_queries(const mcq_query *q, size_t n);
  * (queries never seen by the host).  mt_seed32 (parity mode): the draws are not in d_draws yet -- the device parses
  * np.random.seed(*mt_seed32 + i)'s stream of query i into it first (mcq_mt.hpp).  d_prefix_ready: the cost prefix
  * has been computed by the host and the result rows are zero already -- no prep kernel (host entries). */
+/* parity mode by state blocks (mcq_mt_blocks.hpp): where the chunk's arrays lie (device pointers) */
+struct McqMtbLaunch {
+    const uint32_t *d_blk_off;
+    uint32_t max_blocks;
+    uint8_t *d_yb;
+    uint32_t *d_exits;
+    void *d_entries;
+    uint32_t *d_ovf;
+};
 int mcq_run_slice(mcq_ctx *c, int mode, const mcq_query *d_q, uint32_t n, mcq_result *d_res, uint64_t seed,
                   uint64_t first_qid, uint64_t total_tasks, const uint8_t *d_draws, const uint64_t *d_off, hipStream_t s,
                   bool timed, uint64_t max_tasks = 0, uint32_t part = 0, uint32_t n_parts = 1,
-                  const uint32_t *mt_seed32 = nullptr, const uint64_t *d_prefix_ready = nullptr);
+                  const uint32_t *mt_seed32 = nullptr, const uint64_t *d_prefix_ready = nullptr,
+                  const struct McqMtbLaunch *mtb = nullptr);

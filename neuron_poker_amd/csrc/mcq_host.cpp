@@ -19,6 +19,7 @@
 #include "mcq_ctx.hpp"
 #include "mcq_device.hpp"
 #include "mcq_internal.hpp"
+#include "mcq_mt_blocks.hpp"
 #include "mcq_replay.hpp"
 
 hipError_t mcq_eval_occupancy(int mode, int block, int *blocks_per_cu); /* mcq_kernels.hip */
@@ -126,7 +127,7 @@ int scratch_for(mcq_ctx *c, hipStream_t s, size_t bytes, bool capturing, mcq_ctx
 int mcq_run_slice(mcq_ctx *c, int mode, const mcq_query *d_q, uint32_t n, mcq_result *d_res, uint64_t seed,
                   uint64_t first_qid, uint64_t total_tasks, const uint8_t *d_draws, const uint64_t *d_off, hipStream_t s,
                   bool timed, uint64_t max_tasks, uint32_t part, uint32_t n_parts, const uint32_t *mt_seed32,
-                  const uint64_t *d_prefix_ready) {
+                  const uint64_t *d_prefix_ready, const McqMtbLaunch *mtb) {
     if (mode == MCQ_MODE_PHILOX && c->law == MCQ_LAW_UNIFORM) mode = MCQ_INTERNAL_MODE_UNIFORM;
     const bool capturing = stream_capturing(s);
     if (capturing || !c->timing) timed = false; /* events recorded inside a capture cannot be read back */
@@ -151,9 +152,13 @@ int mcq_run_slice(mcq_ctx *c, int mode, const mcq_query *d_q, uint32_t n, mcq_re
     if (mt_seed32) {
         if (timed) HIP_TRY(hipEventRecord(t0, s));
         t0 = nullptr;
-        HIP_TRY(mcq_launch_mt_parse(d_q, n, *mt_seed32, const_cast<uint8_t *>(d_draws), d_off, d_res,
-                                    const_cast<uint32_t *>(reinterpret_cast<const uint32_t *>(d_prefix + n + 2)),
-                                    (uint32_t)c->n_cu, s));
+        if (mtb)
+            HIP_TRY(mcq_launch_mt_blocks(d_q, n, *mt_seed32, mtb->d_blk_off, mtb->max_blocks, mtb->d_yb, mtb->d_exits, mtb->d_entries,
+                                         mtb->d_ovf, const_cast<uint8_t *>(d_draws), d_off, d_res, s));
+        else
+            HIP_TRY(mcq_launch_mt_parse(d_q, n, *mt_seed32, const_cast<uint8_t *>(d_draws), d_off, d_res,
+                                        const_cast<uint32_t *>(reinterpret_cast<const uint32_t *>(d_prefix + n + 2)),
+                                        (uint32_t)c->n_cu, s));
     }
     HIP_TRY(mcq_launch_eval(mode, d_q, n, d_prefix, d_res, seed, first_qid, c->d_luts, d_draws, d_off, grid, block, split,
                             part, n_parts, s, t0, t1, work_wpb));
@@ -193,7 +198,14 @@ namespace {
 /* parity mode, independent streams: query i replays np.random.seed((seed + first_qid + i) mod 2^32).  The stream walk
  * runs on the DEVICE (mcq_mt_parse_kernel, one wave per query) and fills the draw buffer the evaluation kernel
  * reads; the host only lays the buffer out.  Chunks of queries whose draws fit c->replay_device_bytes. */
-int replay_batch_device(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed, uint64_t first_query_id, mcq_result *out) {
+/* Few long queries (at most kMtbQueries in a chunk, at least kMtbMinBlocks state blocks among them) are parsed with
+ * their state blocks side by side (mcq_mt_blocks.hpp): one 100 000-run query 6.5 -> 1.x ms.  The blocks a query needs are
+ * an estimate with a margin; a query whose stream runs past them comes back with passes = UINT64_MAX and the call is
+ * repeated with the serial walk. */
+constexpr size_t kMtbQueries = 64;
+constexpr uint64_t kMtbMinBlocks = 64, kMtbMaxBlocks = 1u << 20;
+int replay_batch_device(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed, uint64_t first_query_id, mcq_result *out,
+                        bool allow_blocks = true) {
     HIP_TRY(c->h_off.reserve(n * sizeof(uint64_t)));
     HIP_TRY(c->d_off.reserve(n * sizeof(uint64_t)));
     uint64_t *off = (uint64_t *)c->h_off.p;
@@ -221,16 +233,54 @@ int replay_batch_device(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed,
     HIP_TRY(c->d_draws.reserve(largest + 64));
     HIP_TRY(hipMemcpyAsync(c->d_off.p, off, n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     const uint64_t timed0 = c->n_timed;
+    bool by_blocks = false;
     for (const Chunk &ch : chunks) { /* stream order keeps a chunk's parse behind the previous chunk's evaluation */
         const uint32_t seed32 = (uint32_t)(seed + first_query_id + ch.a);
-        int rc = mcq_run_slice(c, MCQ_MODE_REPLAY_MT19937, (const mcq_query *)c->d_q.p + ch.a, (uint32_t)(ch.b - ch.a),
+        const size_t m = ch.b - ch.a;
+        McqMtbLaunch mtb = {nullptr, 0, nullptr, nullptr, nullptr, nullptr};
+        if (allow_blocks && c->mt_blocks && m <= kMtbQueries && chunks.size() == 1) {
+            HIP_TRY(c->h_misc.reserve((m + 1) * sizeof(uint32_t)));
+            uint32_t *blk = (uint32_t *)c->h_misc.p;
+            uint64_t total = 0;
+            for (size_t i = 0; i < m; i++) {
+                const mcq_query &qq = q[ch.a + i];
+                blk[i] = (uint32_t)total;
+                const uint32_t n_opp = qq.n_players - 1u, n_deal = 5u - qq.n_board;
+                if (qq.n_players >= 1 && qq.n_players <= 10 && qq.n_board <= 5 && 2u * n_opp + n_deal != 0u && qq.runs != 0u) {
+                    const uint32_t nb = mcq_mtb_blocks_needed(50u - qq.n_board, n_opp, n_deal, qq.runs);
+                    total += nb;
+                    if (nb > mtb.max_blocks) mtb.max_blocks = nb;
+                }
+            }
+            blk[m] = (uint32_t)total;
+            if (total >= kMtbMinBlocks && total <= kMtbMaxBlocks) {
+                const auto pad16 = [](uint64_t x) { return (x + 15u) & ~15ull; };
+                const uint64_t o_ovf = pad16((m + 1) * 4), o_ent = o_ovf + pad16(m * 4), o_ex = o_ent + pad16(total * sizeof(McqMtbEntry)),
+                               o_yb = o_ex + total * MCQ_MTB_LANES * 4u, bytes = o_yb + total * MCQ_MT_N + 64u;
+                HIP_TRY(c->d_mt.reserve(bytes));
+                char *base = (char *)c->d_mt.p;
+                HIP_TRY(hipMemcpyAsync(base, blk, (m + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+                mtb.d_blk_off = (const uint32_t *)base;
+                mtb.d_ovf = (uint32_t *)(base + o_ovf);
+                mtb.d_entries = base + o_ent;
+                mtb.d_exits = (uint32_t *)(base + o_ex);
+                mtb.d_yb = (uint8_t *)(base + o_yb);
+                by_blocks = true;
+            }
+        }
+        int rc = mcq_run_slice(c, MCQ_MODE_REPLAY_MT19937, (const mcq_query *)c->d_q.p + ch.a, (uint32_t)m,
                                (mcq_result *)c->d_res.p + ch.a, seed, first_query_id + ch.a, ch.tasks ? ch.tasks : 1,
                                (const uint8_t *)c->d_draws.p, (const uint64_t *)c->d_off.p + ch.a, c->stream, true,
-                               ch.max_tasks, 0, 1, &seed32);
+                               ch.max_tasks, 0, 1, &seed32, nullptr, mtb.d_blk_off ? &mtb : nullptr);
         if (rc) return rc;
     }
     HIP_TRY(hipMemcpyAsync(c->h_res.p, c->d_res.p, n * sizeof(mcq_result), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (by_blocks) { /* a stream that ran past its estimated blocks (never seen; the margin is eight blocks): the serial walk */
+        const mcq_result *hr = (const mcq_result *)c->h_res.p;
+        for (size_t i = 0; i < n; i++)
+            if (hr[i].passes == ~0ull) return replay_batch_device(c, q, n, seed, first_query_id, out, false);
+    }
     memcpy(out, c->h_res.p, n * sizeof(mcq_result));
     float total = 0.f;
     const int launched = (int)(c->n_timed - timed0);
@@ -336,6 +386,7 @@ mcq_ctx *mcq_ctx_clone(const mcq_ctx *c) {
         d->direct_poll = c->direct_poll;
         d->direct_uniform_min = c->direct_uniform_min;
         d->ext_small = c->ext_small;
+        d->mt_blocks = c->mt_blocks;
         d->publish_max_rows = c->publish_max_rows;
         d->timing = c->timing;
         d->replay_device_bytes = c->replay_device_bytes;
@@ -423,6 +474,7 @@ mcq_ctx *mcq_create(int device, int flags) {
     }
     if (const char *e = getenv("MCQ_DIRECT_POLL")) c->direct_poll = atoi(e) != 0;
     if (const char *e = getenv("MCQ_EXT_SMALL")) c->ext_small = atoi(e) != 0; /* see mcq_eval_batch_ext */
+    if (const char *e = getenv("MCQ_MT_BLOCKS")) c->mt_blocks = atoi(e) != 0;  /* see replay_batch_device */
     if (const char *e = getenv("MCQ_DIRECT_UNIFORM_MIN")) { /* tuning knob, see eval_host_philox */
         const long v = atol(e);
         c->direct_uniform_min = (size_t)(v < 0 ? 0 : v);

@@ -19,6 +19,7 @@
 #include "mcq_internal.hpp"
 #include "mcq_mt.hpp"
 #include "mcq_mt_ext.hpp"
+#include "mcq_mt_blocks.hpp"
 
 namespace {
 
@@ -278,6 +279,153 @@ __global__ __launch_bounds__(kMtExtBlock) void mcq_mt_parse_ext_kernel(const mcq
             reinterpret_cast<unsigned long long *>(res + qi)[1] = ok ? st.passes : ~0ull;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------- few long queries
+// mcq_mt_blocks.hpp: the stream of a query parsed with its state blocks side by side -- four kernels behind one another
+// on the stream.  blk_off[q] .. blk_off[q + 1]: the query's blocks in the shared arrays (none: the query draws nothing
+// or is invalid); gridDim.y = queries where the grid is two-dimensional.
+//
+// 1. generate.  The MT19937 recurrence is the one serial thing left: x[k] of the next state needs x[k], x[k + 1] and
+// x[k + 397] -- three sweeps of at most 227 independent words, each waiting for the one before.  A work-group of four
+// waves per query does a sweep in ONE step (two state buffers: a sweep reads the old state and the finished part of the
+// new one, never what it writes), three barriers per block; the new state leaves as bytes (y & 63) | 0x80, four per lane.
+constexpr int kMtbGenBlock = 256;
+__global__ __launch_bounds__(kMtbGenBlock) void mcq_mtb_generate_kernel(const uint32_t *__restrict__ blk_off, uint32_t seed32,
+                                                                       uint8_t *__restrict__ yb) {
+    __shared__ __attribute__((aligned(16))) uint32_t mt[2][MCQ_MT_N + 8u];
+    const uint32_t qi = blockIdx.x, tid = threadIdx.x, first = blk_off[qi], nb = blk_off[qi + 1u] - first;
+    if (nb == 0u) return; /* (block-uniform) */
+    if (tid == 0) { /* np.random.seed: init_genrand, a serial recurrence */
+        uint32_t x = seed32 + qi;
+        mt[0][0] = x;
+        for (uint32_t i = 1; i < MCQ_MT_N; i++) {
+            x = 1812433253u * (x ^ (x >> 30)) + i;
+            mt[0][i] = x;
+        }
+    }
+    __syncthreads();
+    uint8_t *dst = yb + (uint64_t)first * MCQ_MT_N;
+    for (uint32_t b = 0; b < nb; b++) {
+        const uint32_t *old = mt[b & 1u];
+        uint32_t *nw = mt[(b + 1u) & 1u];
+        if (tid < 227u) nw[tid] = old[tid + MCQ_MT_M] ^ mcq_mt_twist(old[tid], old[tid + 1u]);
+        __syncthreads();
+        if (tid < 227u) nw[227u + tid] = nw[tid] ^ mcq_mt_twist(old[227u + tid], old[228u + tid]);
+        __syncthreads();
+        if (tid < 170u) {
+            const uint32_t k = 454u + tid;
+            nw[k] = nw[k - 227u] ^ mcq_mt_twist(old[k], k == MCQ_MT_N - 1u ? nw[0] : old[k + 1u]);
+        }
+        __syncthreads();
+        if (tid < MCQ_MT_N / 4u) {
+            const uint4 y = *reinterpret_cast<const uint4 *>(nw + 4u * tid);
+            const uint32_t out = ((mcq_mt_temper(y.x) & 63u) | ((mcq_mt_temper(y.y) & 63u) << 8) | ((mcq_mt_temper(y.z) & 63u) << 16) |
+                                  ((mcq_mt_temper(y.w) & 63u) << 24)) | 0x80808080u;
+            *reinterpret_cast<uint32_t *>(dst + (uint64_t)b * MCQ_MT_N + 4u * tid) = out;
+        }
+        /* (the next block's first sweep writes the buffer this block's sweeps have read: behind the barrier above) */
+    }
+}
+
+// 2. scan: one wave per (query, block); lane = entry state (mcq_mtb_automaton), the block's bytes through LDS.
+constexpr int kMtbBlock = 256;
+__device__ __forceinline__ McqMtbPlan mcq_mtb_plan_of(const mcq_query *__restrict__ queries, uint32_t qi) {
+    const uint4 raw = reinterpret_cast<const uint4 *>(queries)[qi];
+    const McqQueryWords q = {(uint32_t)__builtin_amdgcn_readfirstlane(raw.x), (uint32_t)__builtin_amdgcn_readfirstlane(raw.y),
+                             (uint32_t)__builtin_amdgcn_readfirstlane(raw.z), (uint32_t)__builtin_amdgcn_readfirstlane(raw.w)};
+    return mcq_mtb_plan(50u - q.n_board(), q.n_players() - 1u, 5u - q.n_board(), q.runs());
+}
+__global__ __launch_bounds__(kMtbBlock) void mcq_mtb_scan_kernel(const mcq_query *__restrict__ queries,
+                                                                const uint32_t *__restrict__ blk_off,
+                                                                const uint8_t *__restrict__ yb, uint32_t *__restrict__ exits) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_yb[kMtbBlock / 64][MCQ_MT_N + 16u];
+    const uint32_t qi = blockIdx.y, lane = threadIdx.x & 63u, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t first = blk_off[qi], nb = blk_off[qi + 1u] - first, b = blockIdx.x * (kMtbBlock / 64) + wv;
+    if (b >= nb) return; /* (wave-uniform; no block barrier below) */
+    const McqMtbPlan pl = mcq_mtb_plan_of(queries, qi);
+    const uint8_t *src = yb + (uint64_t)(first + b) * MCQ_MT_N;
+    if (lane < MCQ_MT_N / 16u) reinterpret_cast<uint4 *>(s_yb[wv])[lane] = reinterpret_cast<const uint4 *>(src)[lane];
+    MCQ_WAVE_SYNC();
+    const uint32_t x = mcq_mtb_automaton(s_yb[wv], pl, lane);
+    if (lane < MCQ_MTB_LANES) exits[(uint64_t)(first + b) * MCQ_MTB_LANES + lane] = x;
+}
+
+// 3. stitch: one wave per query follows the exits through the blocks, 256 blocks' exit words in LDS at a time; every
+// lane carries the same state (the LDS reads are broadcasts), lane 0 notes the entries.  ovf[q] = 1: the stream has not
+// ended within the query's blocks -- its row gets passes = UINT64_MAX and the host falls back to the serial walk.
+constexpr uint32_t kMtbChunk = 256;
+__global__ __launch_bounds__(64) void mcq_mtb_stitch_kernel(const mcq_query *__restrict__ queries,
+                                                            const uint32_t *__restrict__ blk_off,
+                                                            const uint32_t *__restrict__ exits, McqMtbEntry *__restrict__ entries,
+                                                            uint32_t *__restrict__ ovf, mcq_result *__restrict__ res) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_ex[kMtbChunk * MCQ_MTB_LANES];
+    __shared__ McqMtbEntry s_en[kMtbChunk];
+    const uint32_t qi = blockIdx.x, lane = threadIdx.x;
+    const uint32_t first = blk_off[qi], nb = blk_off[qi + 1u] - first;
+    if (nb == 0u) {
+        if (lane == 0) ovf[qi] = 0u;
+        return;
+    }
+    const McqMtbPlan pl = mcq_mtb_plan_of(queries, qi);
+    uint32_t d = 0, pend = 0, it = 0;
+    for (uint32_t b0 = 0; b0 < nb; b0 += kMtbChunk) {
+        const uint32_t cnt = nb - b0 < kMtbChunk ? nb - b0 : kMtbChunk;
+        const uint4 *src = reinterpret_cast<const uint4 *>(exits + (uint64_t)(first + b0) * MCQ_MTB_LANES);
+        for (uint32_t k = lane; k < cnt * (MCQ_MTB_LANES / 4u); k += 64u) reinterpret_cast<uint4 *>(s_ex)[k] = src[k];
+        MCQ_WAVE_SYNC();
+        for (uint32_t k = 0; k < cnt; k++) {
+            if (lane == 0) {
+                s_en[k].it0 = it;
+                s_en[k].dp = d | (pend << 8) | (it < pl.runs ? 0x80000000u : 0u);
+            }
+            mcq_mtb_stitch_step(s_ex + k * MCQ_MTB_LANES, pl, d, pend, it);
+        }
+        MCQ_WAVE_SYNC();
+        for (uint32_t k = lane; k < cnt; k += 64u) entries[first + b0 + k] = s_en[k];
+        MCQ_WAVE_SYNC();
+    }
+    if (lane == 0) {
+        ovf[qi] = it < pl.runs ? 1u : 0u;
+        if (it < pl.runs) reinterpret_cast<unsigned long long *>(res + qi)[1] = ~0ull;
+    }
+}
+
+// 4. parse: one wave per (query, block) from the block's true entry (mcq_mtb_parse_block: the batch code of the serial
+// walk), draws straight to the draw buffer, the attempts added to the row's `passes`.
+__global__ __launch_bounds__(kMtbBlock) void mcq_mtb_parse_kernel(const mcq_query *__restrict__ queries,
+                                                                 const uint32_t *__restrict__ blk_off,
+                                                                 const uint8_t *__restrict__ yb,
+                                                                 const McqMtbEntry *__restrict__ entries,
+                                                                 const uint32_t *__restrict__ ovf, uint8_t *__restrict__ draws,
+                                                                 const uint64_t *__restrict__ draw_off, mcq_result *__restrict__ res) {
+    __shared__ __attribute__((aligned(16))) McqMtBlockWave ws[kMtbBlock / 64];
+    const uint32_t qi = blockIdx.y, lane = threadIdx.x & 63u, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t first = blk_off[qi], nb = blk_off[qi + 1u] - first, b = blockIdx.x * (kMtbBlock / 64) + wv;
+    if (b >= nb || ovf[qi] != 0u) return; /* (wave-uniform; no block barrier below) */
+    /* (into scalar registers by hand: the compiler knows that a load at a uniform address is uniform, drops a
+     * readfirstlane of it -- and then cannot pin the walk's state in SGPRs where mcq_mt_batch asks for that) */
+    const McqMtbEntry en0 = entries[first + b];
+    McqMtbEntry en;
+    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(en.it0) : "v"(en0.it0));
+    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(en.dp) : "v"(en0.dp));
+    if (!(en.dp >> 31)) return; /* the stream ended in an earlier block */
+    McqMtBlockWave &w = ws[wv];
+    const uint4 raw = reinterpret_cast<const uint4 *>(queries)[qi];
+    const McqQueryWords q = {(uint32_t)__builtin_amdgcn_readfirstlane(raw.x), (uint32_t)__builtin_amdgcn_readfirstlane(raw.y),
+                             (uint32_t)__builtin_amdgcn_readfirstlane(raw.z), (uint32_t)__builtin_amdgcn_readfirstlane(raw.w)};
+    const uint32_t L0 = 50u - q.n_board(), n_opp = q.n_players() - 1u, n_deal = 5u - q.n_board(), runs = q.runs();
+    const uint8_t *src = yb + (uint64_t)(first + b) * MCQ_MT_N;
+    if (lane < MCQ_MT_N / 16u) reinterpret_cast<uint4 *>(w.yb)[lane] = reinterpret_cast<const uint4 *>(src)[lane];
+    else if (lane < MCQ_MT_N / 16u + 4u) reinterpret_cast<uint4 *>(w.yb)[lane] = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+    if (lane == 0) {
+        w.draws = draws + draw_off[qi];
+        w.stride = ((uint64_t)runs + 63u) & ~63ull;
+        w.two_opp = 2u * n_opp;
+    }
+    mcq_mt_fill_ptab(w, L0, n_opp, 2u * n_opp + n_deal); /* (ends with a wave barrier) */
+    const uint64_t passes = mcq_mtb_parse_block(w, L0, n_opp, n_deal, runs, en);
+    if (lane == 0 && passes) atomicAdd(reinterpret_cast<unsigned long long *>(res + qi) + 1, (unsigned long long)passes);
 }
 
 // ---------------------------------------------------------------------------------------------- multi-GPU helper
@@ -1399,6 +1547,20 @@ hipError_t mcq_launch_mt_parse(const mcq_query *d_q, uint32_t n, uint32_t seed32
     if (blocks > 16u * n_cu) blocks = 16u * n_cu; /* what a CU holds at once: 16 work-groups */
     hipLaunchKernelGGL(mcq_mt_parse_kernel, dim3(blocks), dim3(kMtBlock), 0, s, d_q, n, seed32, d_draws, d_draw_off, d_res,
                        d_counter);
+    return hipGetLastError();
+}
+
+hipError_t mcq_launch_mt_blocks(const mcq_query *d_q, uint32_t n, uint32_t seed32, const uint32_t *d_blk_off, uint32_t max_blocks,
+                                uint8_t *d_yb, uint32_t *d_exits, void *d_entries, uint32_t *d_ovf, uint8_t *d_draws,
+                                const uint64_t *d_draw_off, mcq_result *d_res, hipStream_t s) {
+    if (n == 0 || max_blocks == 0) return hipSuccess;
+    const dim3 per_block((max_blocks + kMtbBlock / 64 - 1) / (kMtbBlock / 64), n);
+    hipLaunchKernelGGL(mcq_mtb_generate_kernel, dim3(n), dim3(kMtbGenBlock), 0, s, d_blk_off, seed32, d_yb);
+    hipLaunchKernelGGL(mcq_mtb_scan_kernel, per_block, dim3(kMtbBlock), 0, s, d_q, d_blk_off, d_yb, d_exits);
+    hipLaunchKernelGGL(mcq_mtb_stitch_kernel, dim3(n), dim3(64), 0, s, d_q, d_blk_off, d_exits,
+                       reinterpret_cast<McqMtbEntry *>(d_entries), d_ovf, d_res);
+    hipLaunchKernelGGL(mcq_mtb_parse_kernel, per_block, dim3(kMtbBlock), 0, s, d_q, d_blk_off, d_yb,
+                       reinterpret_cast<const McqMtbEntry *>(d_entries), d_ovf, d_draws, d_draw_off, d_res);
     return hipGetLastError();
 }
 

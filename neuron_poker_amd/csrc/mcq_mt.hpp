@@ -216,6 +216,10 @@ MCQ_HD void mcq_mt_regenerate(W &w) {
 MCQ_HD uint32_t mcq_mt_word_yb(const McqMtWave &w, uint32_t i) { return (mcq_mt_temper(w.mt[i]) & 63u) | 0x80u; }
 MCQ_HD void mcq_mt_next_block(McqMtWave &w) { mcq_mt_regenerate(w); }
 MCQ_HD void mcq_mt_emit_lane(McqMtWave &, bool, uint32_t, uint32_t, uint32_t, uint32_t) {}
+/* a wave-uniform count the batch wants computed where it stands (mcq_opaque_uniform: pinned in a scalar register);
+ * waves whose state comes out of memory overload this with the identity -- the backend cannot pin those */
+template <class W>
+MCQ_HD uint32_t mcq_mt_pin(const W &, uint32_t x) { return mcq_opaque_uniform(x); }
 
 struct McqMtState { /* wave-uniform */
     uint32_t pos;     /* next unread state word, 624 = regenerate first */
@@ -325,7 +329,7 @@ MCQ_HD void mcq_mt_batch(W &w, McqMtState &st, const McqMtPlan &pl) {
     MCQ_FOR_LANES(l) { MCQ_L(pv) = w.ring[MCQ_L(at)]; }
     const uint64_t R2 = MCQ_BALLOT_OF(l, (int32_t)MCQ_L(t) < 0) & M;
     uint32_t used = rem < 64u ? rem : 64u;
-    uint32_t n_r2 = mcq_opaque_uniform(mcq_mt_popc64(R2)), p_end = mcq_opaque_uniform(st.d0 + mcq_mt_popc64(M)); /* (here, not behind the wait) */
+    uint32_t n_r2 = mcq_mt_pin(w, mcq_mt_popc64(R2)), p_end = mcq_mt_pin(w, st.d0 + mcq_mt_popc64(M)); /* (here, not behind the wait) */
     const uint64_t R = MCQ_BALLOT_OF(l, MCQ_L(pv) == MCQ_L(v)) & R2;
     if (R) { /* one batch in five */
         const uint32_t j = mcq_mt_low64(R);

@@ -134,6 +134,26 @@ def mt_parse(query16, seed32, reference=False):
     return draws[:D, :runs], int(passes)
 
 
+def mt_parse_blocks(query16, seed32, n_blocks=0):
+    """The same stream parsed block by block (mcq_mt_blocks.hpp) -> (draws, passes); passes = None when the stream does
+    not end within n_blocks state blocks (0: the host's estimate)."""
+    q = np.ascontiguousarray(query16, np.uint8)
+    runs = int(q[12:16].view(np.uint32)[0])
+    D = 2 * (int(q[8]) - 1) + 5 - int(q[7])
+    stride = max((runs + 63) & ~63, 64)
+    draws = np.zeros((max(D, 1), stride), np.uint8)
+    f = lib().hs_mt_parse_blocks
+    f.restype = C.c_uint64
+    passes = int(f(_p(q, C.c_uint8), C.c_uint32(seed32), _p(draws, C.c_uint8), C.c_uint64(stride), C.c_uint32(n_blocks)))
+    return draws[:D, :runs], (None if passes == 2 ** 64 - 1 else passes)
+
+
+def mtb_blocks_needed(query16):
+    q = np.ascontiguousarray(query16, np.uint8)
+    lib().hs_mtb_blocks_needed.restype = C.c_uint32
+    return int(lib().hs_mtb_blocks_needed(_p(q, C.c_uint8)))
+
+
 def mt_parse_ext(query16, ext, seed32, reference=False):
     """The same for an extended query (mcq_mt_ext.hpp against mcq_replay_parse_ext) -> (draws [rows, runs], passes);
     passes = None when a range cannot be dealt."""

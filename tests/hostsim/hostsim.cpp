@@ -14,6 +14,7 @@
 #include "../../neuron_poker_amd/csrc/mcq_layout.hpp"
 #include "../../neuron_poker_amd/csrc/mcq_mt.hpp"
 #include "../../neuron_poker_amd/csrc/mcq_mt_ext.hpp"
+#include "../../neuron_poker_amd/csrc/mcq_mt_blocks.hpp"
 #include "../../neuron_poker_amd/csrc/mcq_replay.hpp"
 
 namespace {
@@ -292,6 +293,53 @@ extern "C" uint64_t hs_mt_parse(const mcq_query *q, uint32_t seed32, uint8_t *dr
     McqMtState st = {MCQ_MT_N, 0, 0, 0, 0};
     mcq_mt_parse_query(w, st, 50u - q->n_board, n_opp, n_deal, q->runs, draws, stride);
     return st.passes;
+}
+// ... the same stream parsed block by block (mcq_mt_blocks.hpp: generate, scan every entry state, stitch, parse each block
+// from its true entry) as the four kernels of the device do it; n_blocks = 0: as many as the host would estimate.
+// UINT64_MAX: the stream did not end within the blocks (the device then falls back to the serial walk)
+extern "C" uint32_t hs_mtb_blocks_needed(const mcq_query *q) {
+    return mcq_mtb_blocks_needed(50u - q->n_board, q->n_players - 1u, 5u - q->n_board, q->runs);
+}
+extern "C" uint64_t hs_mt_parse_blocks(const mcq_query *q, uint32_t seed32, uint8_t *draws, uint64_t stride, uint32_t n_blocks) {
+    static thread_local McqMtWave gen;
+    static thread_local McqMtBlockWave w;
+    const uint32_t n_opp = q->n_players - 1u, n_deal = 5u - q->n_board, L0 = 50u - q->n_board, D = 2u * n_opp + n_deal;
+    if (D == 0u || q->runs == 0u) return 0;
+    if (!n_blocks) n_blocks = hs_mtb_blocks_needed(q);
+    /* 1. generate */
+    std::vector<uint8_t> yb((size_t)n_blocks * MCQ_MT_N);
+    mcq_mt_seed(gen, seed32);
+    for (uint32_t b = 0; b < n_blocks; b++) {
+        mcq_mt_regenerate(gen);
+        for (uint32_t k = 0; k < MCQ_MT_N; k++) yb[(size_t)b * MCQ_MT_N + k] = (uint8_t)mcq_mt_word_yb(gen, k);
+    }
+    /* 2. scan */
+    const McqMtbPlan pl = mcq_mtb_plan(L0, n_opp, n_deal, q->runs);
+    std::vector<uint32_t> exits((size_t)n_blocks * MCQ_MTB_LANES);
+    for (uint32_t b = 0; b < n_blocks; b++)
+        for (uint32_t l = 0; l < MCQ_MTB_LANES; l++) exits[(size_t)b * MCQ_MTB_LANES + l] = mcq_mtb_automaton(&yb[(size_t)b * MCQ_MT_N], pl, l);
+    /* 3. stitch */
+    std::vector<McqMtbEntry> entry(n_blocks);
+    uint32_t d = 0, pend = 0, it = 0;
+    for (uint32_t b = 0; b < n_blocks; b++) {
+        entry[b].it0 = it;
+        entry[b].dp = d | (pend << 8) | (it < q->runs ? 0x80000000u : 0u);
+        mcq_mtb_stitch_step(&exits[(size_t)b * MCQ_MTB_LANES], pl, d, pend, it);
+    }
+    if (it < q->runs) return ~0ull;
+    /* 4. parse */
+    uint64_t passes = 0;
+    w.draws = draws;
+    w.stride = stride;
+    w.two_opp = 2u * n_opp;
+    mcq_mt_fill_ptab(w, L0, n_opp, D);
+    for (uint32_t b = 0; b < n_blocks; b++) {
+        if (!(entry[b].dp >> 31)) continue;
+        memcpy(w.yb, &yb[(size_t)b * MCQ_MT_N], MCQ_MT_N);
+        memset(w.yb + MCQ_MT_N, 0x80, 64);
+        passes += mcq_mtb_parse_block(w, L0, n_opp, n_deal, q->runs, entry[b]);
+    }
+    return passes;
 }
 // ... and the same for extended queries (mcq_mt_ext.hpp) against mcq_replay_parse_ext; UINT64_MAX: cannot be dealt
 extern "C" uint64_t hs_mt_parse_ext(const mcq_query *q, const mcq_query_ext *e, uint32_t seed32, uint8_t *draws, uint64_t stride) {

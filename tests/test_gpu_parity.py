@@ -138,6 +138,40 @@ def test_replay_stream_walk_runs_on_the_device(eng, monkeypatch):
         e2.close()
 
 
+def test_replay_few_long_queries_by_state_blocks(eng, monkeypatch):
+    """Few long queries in parity mode are parsed with their 624-word state blocks side by side (mcq_mt_blocks.hpp:
+    generate / scan every entry state / stitch / parse each block from its true entry): every number of players (zone
+    31 with eight and nine opponents), boards of every length, queries that draw nothing and a short one among them;
+    equal to the oracle's literal walk, to the serial walk on the device (MCQ_MT_BLOCKS=0), and seeds wrap 2^32."""
+    g = np.random.default_rng(78)
+    B = 24
+    hole = np.zeros((B, 2), np.uint8)
+    board = np.full((B, 5), 255, np.uint8)
+    npl = np.zeros(B, np.uint8)
+    for i in range(B):
+        nb = [0, 3, 4, 5][i % 4]
+        c = g.permutation(52)[:2 + nb]
+        hole[i] = c[:2]
+        board[i, :nb] = c[2:]
+        npl[i] = 1 + i % 10
+    runs = g.choice([2000, 5000, 12000, 20000], B)
+    runs[3] = 1
+    runs[7] = 0
+    q = npa.pack_queries(hole, board, npl, runs)
+    first = 2 ** 32 - 10
+    exp = O.run_batch(O.MODE_MT, q.view(np.uint8).reshape(-1, 16), 7, first, threads=8)
+    got = u64(eng.eval_batch(q, seed=7, first_query_id=first, mode=npa.MODE_REPLAY_MT19937))
+    assert np.array_equal(got, exp)
+    one = u64(eng.eval_batch(q[9:10], seed=7, first_query_id=first + 9, mode=npa.MODE_REPLAY_MT19937))   # ten players, alone
+    assert np.array_equal(one, exp[9:10])
+    monkeypatch.setenv("MCQ_MT_BLOCKS", "0")
+    e2 = npa.Engine(0)
+    try:
+        assert np.array_equal(u64(e2.eval_batch(q, seed=7, first_query_id=first, mode=npa.MODE_REPLAY_MT19937)), exp)
+    finally:
+        e2.close()
+
+
 # ------------------------------------------------------------------------------------------ production mode
 def test_philox_equals_oracle_ctr_bit_exact(eng):
     g = np.random.default_rng(5)

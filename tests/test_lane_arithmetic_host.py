@@ -260,6 +260,35 @@ def test_wave_cooperative_mt19937_parse_equals_the_sequential_walk():
         assert p1 == p2 and np.array_equal(d1, d2), (nb, npl, runs, seed)
 
 
+def test_block_parallel_mt19937_walk_equals_the_sequential_walk():
+    """mcq_mt_blocks.hpp -- the stream of ONE query parsed with its 624-word state blocks side by side (every block
+    scanned from every entry position by a sequential automaton, the exits stitched, every block then parsed from its
+    true entry with the wave-cooperative batch code, draws stored by the second index of a pair): draws and `passes`
+    must equal the sequential walk byte for byte, for every number of players (zone 31 with eight and nine opponents),
+    also with exactly as many blocks as the stream touches; too few blocks are reported, not mis-parsed; the host's
+    estimate of the blocks suffices."""
+    g = np.random.default_rng(20261005)
+    for t in range(120):
+        nb = int(g.choice([0, 3, 4, 5]))
+        npl = int(g.integers(1, 11)) if t >= 20 else 1 + t % 10
+        runs = int(g.choice([1, 40, 129, 700, 3000, 9000]))
+        if npl == 1 and nb == 5:
+            nb = 3   # (a query that draws nothing has no stream)
+        c = g.permutation(52)[:2 + nb]
+        q = O.pack_queries([c[:2]], [list(c[2:]) + [255] * (5 - nb)], npl, runs)[0]
+        seed = int(g.integers(0, 2 ** 32))
+        d2, p2 = H.mt_parse(q, seed, reference=True)
+        d1, p1 = H.mt_parse_blocks(q, seed)
+        assert p1 == p2 and np.array_equal(d1, d2), (nb, npl, runs, seed)
+        # the words the stream consumes -> the blocks it touches: exactly those suffice, one fewer does not
+        lo = H.mtb_blocks_needed(q)   # (the estimate sufficed above; it carries a margin of eight blocks)
+        while lo > 1 and H.mt_parse_blocks(q, seed, lo - 1)[1] is not None:
+            lo -= 1
+        d3, p3 = H.mt_parse_blocks(q, seed, lo)
+        assert p3 == p2 and np.array_equal(d3, d2), (nb, npl, runs, seed, lo)
+        assert lo == 1 or H.mt_parse_blocks(q, seed, lo - 1)[1] is None
+
+
 def test_wave_cooperative_walk_of_extended_queries_equals_the_sequential_walk():
     """mcq_mt_ext.hpp -- the device's walk of numpy's stream through the reference's loops over ranges, ghost cards
     and known hands (stage by stage: every attempt of a batch of 64 words tested at once, first success ends the stage,

@@ -32,3 +32,8 @@ q1 = npa.pack_queries([[npa.card_id("AH"), npa.card_id("KH")]], [[255] * 5], 2, 
 r = eng.eval_batch(q1, seed=0, mode=npa.MODE_REPLAY_MT19937)
 print("AhKh heads-up 100k seed 0: wins %d passes %d (reference: 65807 / 102091)" % (int(r["win"][0] + r["tie"][0]), int(r["passes"][0])))
 timed(q1, 5, "configs[1] ONE query x 2 players x 100k", 2e5)
+# few long queries: the state blocks of a query side by side (mcq_mt_blocks.hpp); MCQ_MT_BLOCKS=0 in the environment
+# gives the serial walk's times for the same lines
+for npl, runs, nq in ((6, 100000, 1), (10, 100000, 1), (6, 100000, 8), (6, 20000, 64), (2, 1000000, 1)):
+    timed(npa.pack_queries(hole[:nq], board[:nq], npl, runs), 3, "%d query x %d players x %d%s" %
+          (nq, npl, runs, "" if os.environ.get("MCQ_MT_BLOCKS", "1") != "0" else " (serial walk)"), nq * npl * runs)
