@@ -154,11 +154,13 @@ int mcq_validate_queries(const mcq_query *q, size_t n);
  * has been computed by the host and the result rows are zero already -- no prep kernel (host entries). */
 /* parity mode by state blocks (mcq_mt_blocks.hpp): where the chunk's arrays lie (device pointers) */
 struct McqMtbLaunch {
-    const uint32_t *d_blk_off;
+    const uint32_t *d_blk_off, *d_grp_off;
     uint32_t max_blocks;
-    uint8_t *d_yb;
+    uint32_t *d_raw;
     uint32_t *d_exits;
     void *d_entries;
+    uint32_t *d_gword, *d_gits;
+    void *d_gentry;
     uint32_t *d_ovf;
 };
 int mcq_run_slice(mcq_ctx *c, int mode, const mcq_query *d_q, uint32_t n, mcq_result *d_res, uint64_t seed,

@@ -153,8 +153,9 @@ int mcq_run_slice(mcq_ctx *c, int mode, const mcq_query *d_q, uint32_t n, mcq_re
         if (timed) HIP_TRY(hipEventRecord(t0, s));
         t0 = nullptr;
         if (mtb)
-            HIP_TRY(mcq_launch_mt_blocks(d_q, n, *mt_seed32, mtb->d_blk_off, mtb->max_blocks, mtb->d_yb, mtb->d_exits, mtb->d_entries,
-                                         mtb->d_ovf, const_cast<uint8_t *>(d_draws), d_off, d_res, s));
+            HIP_TRY(mcq_launch_mt_blocks(d_q, n, *mt_seed32, mtb->d_blk_off, mtb->d_grp_off, mtb->max_blocks, mtb->d_raw, mtb->d_exits,
+                                         mtb->d_entries, mtb->d_gword, mtb->d_gits, mtb->d_gentry, mtb->d_ovf,
+                                         const_cast<uint8_t *>(d_draws), d_off, d_res, s));
         else
             HIP_TRY(mcq_launch_mt_parse(d_q, n, *mt_seed32, const_cast<uint8_t *>(d_draws), d_off, d_res,
                                         const_cast<uint32_t *>(reinterpret_cast<const uint32_t *>(d_prefix + n + 2)),
@@ -203,7 +204,7 @@ namespace {
  * an estimate with a margin; a query whose stream runs past them comes back with passes = UINT64_MAX and the call is
  * repeated with the serial walk. */
 constexpr size_t kMtbQueries = 64;
-constexpr uint64_t kMtbMinBlocks = 64, kMtbMaxBlocks = 1u << 20;
+constexpr uint64_t kMtbMinBlocks = 64, kMtbMaxBlocks = 1u << 18; /* (2.7 KB of scratch per block) */
 int replay_batch_device(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed, uint64_t first_query_id, mcq_result *out,
                         bool allow_blocks = true) {
     HIP_TRY(c->h_off.reserve(n * sizeof(uint64_t)));
@@ -237,34 +238,43 @@ int replay_batch_device(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed,
     for (const Chunk &ch : chunks) { /* stream order keeps a chunk's parse behind the previous chunk's evaluation */
         const uint32_t seed32 = (uint32_t)(seed + first_query_id + ch.a);
         const size_t m = ch.b - ch.a;
-        McqMtbLaunch mtb = {nullptr, 0, nullptr, nullptr, nullptr, nullptr};
+        McqMtbLaunch mtb = {};
         if (allow_blocks && c->mt_blocks && m <= kMtbQueries && chunks.size() == 1) {
-            HIP_TRY(c->h_misc.reserve((m + 1) * sizeof(uint32_t)));
-            uint32_t *blk = (uint32_t *)c->h_misc.p;
-            uint64_t total = 0;
+            HIP_TRY(c->h_misc.reserve(2 * (m + 1) * sizeof(uint32_t)));
+            uint32_t *blk = (uint32_t *)c->h_misc.p, *grp = blk + m + 1; /* block / group offsets of the queries */
+            uint64_t total = 0, groups = 0;
             for (size_t i = 0; i < m; i++) {
                 const mcq_query &qq = q[ch.a + i];
                 blk[i] = (uint32_t)total;
+                grp[i] = (uint32_t)groups;
                 const uint32_t n_opp = qq.n_players - 1u, n_deal = 5u - qq.n_board;
                 if (qq.n_players >= 1 && qq.n_players <= 10 && qq.n_board <= 5 && 2u * n_opp + n_deal != 0u && qq.runs != 0u) {
                     const uint32_t nb = mcq_mtb_blocks_needed(50u - qq.n_board, n_opp, n_deal, qq.runs);
                     total += nb;
+                    groups += (nb + MCQ_MTB_GROUP - 1u) / MCQ_MTB_GROUP;
                     if (nb > mtb.max_blocks) mtb.max_blocks = nb;
                 }
             }
             blk[m] = (uint32_t)total;
+            grp[m] = (uint32_t)groups;
             if (total >= kMtbMinBlocks && total <= kMtbMaxBlocks) {
                 const auto pad16 = [](uint64_t x) { return (x + 15u) & ~15ull; };
-                const uint64_t o_ovf = pad16((m + 1) * 4), o_ent = o_ovf + pad16(m * 4), o_ex = o_ent + pad16(total * sizeof(McqMtbEntry)),
-                               o_yb = o_ex + total * MCQ_MTB_LANES * 4u, bytes = o_yb + total * MCQ_MT_N + 64u;
+                const uint64_t o_ovf = pad16(2 * (m + 1) * 4), o_ent = o_ovf + pad16(m * 4),
+                               o_gen = o_ent + pad16(total * sizeof(McqMtbEntry)), o_gw = o_gen + pad16(groups * sizeof(McqMtbEntry)),
+                               o_gi = o_gw + groups * MCQ_MTB_LANES * 4u, o_ex = o_gi + groups * MCQ_MTB_LANES * 4u,
+                               o_raw = o_ex + total * MCQ_MTB_LANES * 4u, bytes = o_raw + total * MCQ_MT_N * 4u + 64u;
                 HIP_TRY(c->d_mt.reserve(bytes));
                 char *base = (char *)c->d_mt.p;
-                HIP_TRY(hipMemcpyAsync(base, blk, (m + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(hipMemcpyAsync(base, blk, 2 * (m + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
                 mtb.d_blk_off = (const uint32_t *)base;
+                mtb.d_grp_off = mtb.d_blk_off + m + 1;
                 mtb.d_ovf = (uint32_t *)(base + o_ovf);
                 mtb.d_entries = base + o_ent;
+                mtb.d_gentry = base + o_gen;
+                mtb.d_gword = (uint32_t *)(base + o_gw);
+                mtb.d_gits = (uint32_t *)(base + o_gi);
                 mtb.d_exits = (uint32_t *)(base + o_ex);
-                mtb.d_yb = (uint8_t *)(base + o_yb);
+                mtb.d_raw = (uint32_t *)(base + o_raw);
                 by_blocks = true;
             }
         }

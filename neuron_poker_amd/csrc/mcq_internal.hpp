@@ -66,11 +66,13 @@ hipError_t mcq_launch_add_u64(uint64_t *d_dst, const uint64_t *d_src, uint64_t n
 hipError_t mcq_launch_mt_parse(const mcq_query *d_q, uint32_t n, uint32_t seed32, uint8_t *d_draws, const uint64_t *d_draw_off,
                                mcq_result *d_res, uint32_t *d_counter, uint32_t n_cu, hipStream_t s);
 /* ... for few long queries (mcq_mt_blocks.hpp): the state blocks of a query side by side.  d_blk_off[q] .. d_blk_off[q + 1]:
- * the query's blocks in d_yb (624 B each), d_exits (MCQ_MTB_LANES words each), d_entries (8 B each); max_blocks = the most
- * blocks of one query; d_ovf[n].  A query whose stream does not end within its blocks gets passes = UINT64_MAX.  The
+ * the query's blocks in d_raw (624 state words each), d_exits (MCQ_MTB_LANES words each), d_entries (8 B each); max_blocks = the most
+ * blocks of one query; d_grp_off likewise for the query's groups of MCQ_MTB_GROUP blocks in d_gword / d_gits (MCQ_MTB_LANES
+ * words each) and d_gentry (8 B each); d_ovf[n].  A query whose stream does not end within its blocks gets passes = UINT64_MAX.  The
  * rows' passes must be zero (the prep kernel). */
-hipError_t mcq_launch_mt_blocks(const mcq_query *d_q, uint32_t n, uint32_t seed32, const uint32_t *d_blk_off, uint32_t max_blocks,
-                                uint8_t *d_yb, uint32_t *d_exits, void *d_entries, uint32_t *d_ovf, uint8_t *d_draws,
+hipError_t mcq_launch_mt_blocks(const mcq_query *d_q, uint32_t n, uint32_t seed32, const uint32_t *d_blk_off,
+                                const uint32_t *d_grp_off, uint32_t max_blocks, uint32_t *d_raw, uint32_t *d_exits, void *d_entries,
+                                uint32_t *d_gword, uint32_t *d_gits, void *d_gentry, uint32_t *d_ovf, uint8_t *d_draws,
                                 const uint64_t *d_draw_off, mcq_result *d_res, hipStream_t s);
 /* ... and for extended queries (mcq_mt_ext.hpp); d_counter zero (mcq_prep_ext_kernel leaves one behind its prefix); a
  * query whose range cannot be dealt gets passes = UINT64_MAX */

@@ -287,12 +287,16 @@ __global__ __launch_bounds__(kMtExtBlock) void mcq_mt_parse_ext_kernel(const mcq
 // or is invalid); gridDim.y = queries where the grid is two-dimensional.
 //
 // 1. generate.  The MT19937 recurrence is the one serial thing left: x[k] of the next state needs x[k], x[k + 1] and
-// x[k + 397] -- three sweeps of at most 227 independent words, each waiting for the one before.  A work-group of four
-// waves per query does a sweep in ONE step (two state buffers: a sweep reads the old state and the finished part of the
-// new one, never what it writes), three barriers per block; the new state leaves as bytes (y & 63) | 0x80, four per lane.
-constexpr int kMtbGenBlock = 256;
+// x[k + 397] of this one, or -- from k = 227 on -- x[k - 227] of the NEXT: three sweeps of at most 227 words, each
+// waiting for the one before.  But the word a sweep waits for is the one the SAME thread has just made (k - 227 is
+// thread t's word of the sweep before), so thread t makes x[t], x[227 + t] and x[454 + t] out of registers, from seven
+// words of the finished state that it reads at once -- one LDS round trip and one barrier per block instead of three
+// (1.73 -> 0.6 ms for the 3 900 blocks of a 6-max 100 000-run query).  (x[623] needs the new x[0]: its thread makes that
+// one a second time.)  Two state buffers; three more waves copy the state the first four are reading to HBM as it is --
+// 2 496 B per block; the waves that read it temper it (mcq_mtb_load_block): off the chain, and side by side.
+constexpr int kMtbGenBlock = 512;
 __global__ __launch_bounds__(kMtbGenBlock) void mcq_mtb_generate_kernel(const uint32_t *__restrict__ blk_off, uint32_t seed32,
-                                                                       uint8_t *__restrict__ yb) {
+                                                                       uint32_t *__restrict__ raw) {
     __shared__ __attribute__((aligned(16))) uint32_t mt[2][MCQ_MT_N + 8u];
     const uint32_t qi = blockIdx.x, tid = threadIdx.x, first = blk_off[qi], nb = blk_off[qi + 1u] - first;
     if (nb == 0u) return; /* (block-uniform) */
@@ -305,31 +309,47 @@ __global__ __launch_bounds__(kMtbGenBlock) void mcq_mtb_generate_kernel(const ui
         }
     }
     __syncthreads();
-    uint8_t *dst = yb + (uint64_t)first * MCQ_MT_N;
-    for (uint32_t b = 0; b < nb; b++) {
-        const uint32_t *old = mt[b & 1u];
-        uint32_t *nw = mt[(b + 1u) & 1u];
-        if (tid < 227u) nw[tid] = old[tid + MCQ_MT_M] ^ mcq_mt_twist(old[tid], old[tid + 1u]);
-        __syncthreads();
-        if (tid < 227u) nw[227u + tid] = nw[tid] ^ mcq_mt_twist(old[227u + tid], old[228u + tid]);
-        __syncthreads();
-        if (tid < 170u) {
-            const uint32_t k = 454u + tid;
-            nw[k] = nw[k - 227u] ^ mcq_mt_twist(old[k], k == MCQ_MT_N - 1u ? nw[0] : old[k + 1u]);
+    uint32_t *dst = raw + (uint64_t)first * MCQ_MT_N;
+    const bool producer = tid < 256u; /* (wave-uniform) */
+    for (uint32_t b = 0; b <= nb; b++) { /* state b -> state b + 1; the query's block b - 1 = state b, tempered */
+        const uint32_t *S = mt[b & 1u];
+        uint32_t *N = mt[(b + 1u) & 1u];
+        if (producer) {
+            if (b < nb && tid < 227u) {
+                /* every read up front, none behind a condition on the thread (indices clamped instead): ONE round trip to
+                 * LDS per block */
+                const uint32_t t = tid, tc = t < 169u ? t : 169u;
+                const uint32_t a0 = S[t], a1 = S[t + 1u], f = S[t + MCQ_MT_M], b0 = S[227u + t], b1 = S[228u + t];
+                const uint32_t c0 = S[454u + tc], c1o = S[455u + tc] /* (tc = 169: the padding behind the state) */;
+                const uint32_t z0 = S[0], z1 = S[1], zf = S[MCQ_MT_M];
+                const uint32_t c1 = t == 169u ? zf ^ mcq_mt_twist(z0, z1) /* the new x[0] */ : c1o;
+                const uint32_t nA = f ^ mcq_mt_twist(a0, a1);
+                const uint32_t nB = nA ^ mcq_mt_twist(b0, b1);
+                N[t] = nA;
+                N[227u + t] = nB;
+                if (t < 170u) N[454u + t] = nB ^ mcq_mt_twist(c0, c1);
+            }
+        } else if (b >= 1u && tid - 256u < MCQ_MT_N / 4u) {
+            const uint32_t t = tid - 256u;
+            reinterpret_cast<uint4 *>(dst + (uint64_t)(b - 1u) * MCQ_MT_N)[t] = *reinterpret_cast<const uint4 *>(S + 4u * t);
         }
-        __syncthreads();
-        if (tid < MCQ_MT_N / 4u) {
-            const uint4 y = *reinterpret_cast<const uint4 *>(nw + 4u * tid);
-            const uint32_t out = ((mcq_mt_temper(y.x) & 63u) | ((mcq_mt_temper(y.y) & 63u) << 8) | ((mcq_mt_temper(y.z) & 63u) << 16) |
-                                  ((mcq_mt_temper(y.w) & 63u) << 24)) | 0x80808080u;
-            *reinterpret_cast<uint32_t *>(dst + (uint64_t)b * MCQ_MT_N + 4u * tid) = out;
-        }
-        /* (the next block's first sweep writes the buffer this block's sweeps have read: behind the barrier above) */
+        __syncthreads(); /* state b + 1 is complete; state b has been read for the last time */
     }
 }
 
 // 2. scan: one wave per (query, block); lane = entry state (mcq_mtb_automaton), the block's bytes through LDS.
 constexpr int kMtbBlock = 256;
+/* a block's state words -> its bytes (y & 63) | 0x80 in LDS (dst: MCQ_MT_N + 64 bytes, the last 64 padding) */
+__device__ __forceinline__ void mcq_mtb_load_block(const uint32_t *__restrict__ src, uint8_t *dst, uint32_t lane) {
+    uint32_t y[10];
+#pragma unroll
+    for (uint32_t k = 0; k < 10u; k++) y[k] = src[64u * k + lane < MCQ_MT_N ? 64u * k + lane : MCQ_MT_N - 1u];
+#pragma unroll
+    for (uint32_t k = 0; k < 10u; k++)
+        if (64u * k + lane < MCQ_MT_N) dst[64u * k + lane] = (uint8_t)((mcq_mt_temper(y[k]) & 63u) | 0x80u);
+    dst[MCQ_MT_N + lane] = 0x80u;
+    MCQ_WAVE_SYNC();
+}
 __device__ __forceinline__ McqMtbPlan mcq_mtb_plan_of(const mcq_query *__restrict__ queries, uint32_t qi) {
     const uint4 raw = reinterpret_cast<const uint4 *>(queries)[qi];
     const McqQueryWords q = {(uint32_t)__builtin_amdgcn_readfirstlane(raw.x), (uint32_t)__builtin_amdgcn_readfirstlane(raw.y),
@@ -338,51 +358,81 @@ __device__ __forceinline__ McqMtbPlan mcq_mtb_plan_of(const mcq_query *__restric
 }
 __global__ __launch_bounds__(kMtbBlock) void mcq_mtb_scan_kernel(const mcq_query *__restrict__ queries,
                                                                 const uint32_t *__restrict__ blk_off,
-                                                                const uint8_t *__restrict__ yb, uint32_t *__restrict__ exits) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_yb[kMtbBlock / 64][MCQ_MT_N + 16u];
+                                                                const uint32_t *__restrict__ raw, uint32_t *__restrict__ exits) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_yb[kMtbBlock / 64][MCQ_MT_N + 64u];
+    __shared__ uint32_t s_pos[kMtbBlock / 64][MCQ_MTB_POS];
     const uint32_t qi = blockIdx.y, lane = threadIdx.x & 63u, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t first = blk_off[qi], nb = blk_off[qi + 1u] - first, b = blockIdx.x * (kMtbBlock / 64) + wv;
     if (b >= nb) return; /* (wave-uniform; no block barrier below) */
     const McqMtbPlan pl = mcq_mtb_plan_of(queries, qi);
-    const uint8_t *src = yb + (uint64_t)(first + b) * MCQ_MT_N;
-    if (lane < MCQ_MT_N / 16u) reinterpret_cast<uint4 *>(s_yb[wv])[lane] = reinterpret_cast<const uint4 *>(src)[lane];
-    MCQ_WAVE_SYNC();
-    const uint32_t x = mcq_mtb_automaton(s_yb[wv], pl, lane);
+    if (lane < MCQ_MTB_POS) s_pos[wv][lane] = mcq_mtb_pos_word(pl, lane < pl.D ? lane : 0u);
+    mcq_mtb_load_block(raw + (uint64_t)(first + b) * MCQ_MT_N, s_yb[wv], lane); /* (ends with a wave barrier) */
+    const uint32_t x = mcq_mtb_automaton(s_yb[wv], s_pos[wv], pl, lane);
     if (lane < MCQ_MTB_LANES) exits[(uint64_t)(first + b) * MCQ_MTB_LANES + lane] = x;
 }
 
-// 3. stitch: one wave per query follows the exits through the blocks, 256 blocks' exit words in LDS at a time; every
-// lane carries the same state (the LDS reads are broadcasts), lane 0 notes the entries.  ovf[q] = 1: the stream has not
-// ended within the query's blocks -- its row gets passes = UINT64_MAX and the host falls back to the serial walk.
-constexpr uint32_t kMtbChunk = 256;
+// 3. stitch, in two levels (mcq_mt_blocks.hpp).  grp_off[q] .. grp_off[q + 1]: the query's groups of MCQ_MTB_GROUP blocks.
+// 3a. compose: one wave per (query, group); the group's exit words through LDS, lane = entry state of the group.
+__global__ __launch_bounds__(kMtbBlock) void mcq_mtb_compose_kernel(const mcq_query *__restrict__ queries,
+                                                                   const uint32_t *__restrict__ blk_off,
+                                                                   const uint32_t *__restrict__ grp_off,
+                                                                   const uint32_t *__restrict__ exits,
+                                                                   uint32_t *__restrict__ gword, uint32_t *__restrict__ gits) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_ex[kMtbBlock / 64][MCQ_MTB_GROUP * MCQ_MTB_LANES];
+    const uint32_t qi = blockIdx.y, lane = threadIdx.x & 63u, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t first = blk_off[qi], nb = blk_off[qi + 1u] - first, g = blockIdx.x * (kMtbBlock / 64) + wv;
+    if (g * MCQ_MTB_GROUP >= nb) return; /* (wave-uniform; no block barrier below) */
+    const McqMtbPlan pl = mcq_mtb_plan_of(queries, qi);
+    const uint32_t b0 = g * MCQ_MTB_GROUP, cnt = nb - b0 < MCQ_MTB_GROUP ? nb - b0 : MCQ_MTB_GROUP;
+    const uint4 *src = reinterpret_cast<const uint4 *>(exits + (uint64_t)(first + b0) * MCQ_MTB_LANES);
+    for (uint32_t k = lane; k < cnt * (MCQ_MTB_LANES / 4u); k += 64u) reinterpret_cast<uint4 *>(s_ex[wv])[k] = src[k];
+    MCQ_WAVE_SYNC();
+    McqMtbWalk s = mcq_mtb_walk_from(pl, lane);
+    if (lane < pl.D + (pl.two_opp >> 1))
+        for (uint32_t k = 0; k < cnt; k++) mcq_mtb_compose_step(s_ex[wv] + k * MCQ_MTB_LANES, pl, s);
+    if (lane < MCQ_MTB_LANES) {
+        gword[(uint64_t)(grp_off[qi] + g) * MCQ_MTB_LANES + lane] = mcq_mtb_walk_word(s);
+        gits[(uint64_t)(grp_off[qi] + g) * MCQ_MTB_LANES + lane] = s.its;
+    }
+}
+
+// 3b. one wave per query follows the GROUPS' exits, 128 groups' words in LDS at a time; every lane carries the same state
+// (the LDS reads are broadcasts).  gentry[group] = the walk in front of the group.  ovf[q] = 1: the stream has not ended
+// within the query's blocks -- its row gets passes = UINT64_MAX and the host falls back to the serial walk.
+constexpr uint32_t kMtbChunk = 128;
 __global__ __launch_bounds__(64) void mcq_mtb_stitch_kernel(const mcq_query *__restrict__ queries,
                                                             const uint32_t *__restrict__ blk_off,
-                                                            const uint32_t *__restrict__ exits, McqMtbEntry *__restrict__ entries,
-                                                            uint32_t *__restrict__ ovf, mcq_result *__restrict__ res) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_ex[kMtbChunk * MCQ_MTB_LANES];
+                                                            const uint32_t *__restrict__ grp_off,
+                                                            const uint32_t *__restrict__ gword, const uint32_t *__restrict__ gits,
+                                                            McqMtbEntry *__restrict__ gentry, uint32_t *__restrict__ ovf,
+                                                            mcq_result *__restrict__ res) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_w[kMtbChunk * MCQ_MTB_LANES], s_i[kMtbChunk * MCQ_MTB_LANES];
     __shared__ McqMtbEntry s_en[kMtbChunk];
     const uint32_t qi = blockIdx.x, lane = threadIdx.x;
-    const uint32_t first = blk_off[qi], nb = blk_off[qi + 1u] - first;
-    if (nb == 0u) {
+    const uint32_t gfirst = grp_off[qi], ng = grp_off[qi + 1u] - gfirst;
+    if (blk_off[qi + 1u] == blk_off[qi]) {
         if (lane == 0) ovf[qi] = 0u;
         return;
     }
     const McqMtbPlan pl = mcq_mtb_plan_of(queries, qi);
     uint32_t d = 0, pend = 0, it = 0;
-    for (uint32_t b0 = 0; b0 < nb; b0 += kMtbChunk) {
-        const uint32_t cnt = nb - b0 < kMtbChunk ? nb - b0 : kMtbChunk;
-        const uint4 *src = reinterpret_cast<const uint4 *>(exits + (uint64_t)(first + b0) * MCQ_MTB_LANES);
-        for (uint32_t k = lane; k < cnt * (MCQ_MTB_LANES / 4u); k += 64u) reinterpret_cast<uint4 *>(s_ex)[k] = src[k];
-        MCQ_WAVE_SYNC();
-        for (uint32_t k = 0; k < cnt; k++) {
-            if (lane == 0) {
-                s_en[k].it0 = it;
-                s_en[k].dp = d | (pend << 8) | (it < pl.runs ? 0x80000000u : 0u);
-            }
-            mcq_mtb_stitch_step(s_ex + k * MCQ_MTB_LANES, pl, d, pend, it);
+    for (uint32_t g0 = 0; g0 < ng; g0 += kMtbChunk) {
+        const uint32_t cnt = ng - g0 < kMtbChunk ? ng - g0 : kMtbChunk;
+        const uint4 *sw = reinterpret_cast<const uint4 *>(gword + (uint64_t)(gfirst + g0) * MCQ_MTB_LANES);
+        const uint4 *si = reinterpret_cast<const uint4 *>(gits + (uint64_t)(gfirst + g0) * MCQ_MTB_LANES);
+        for (uint32_t k = lane; k < cnt * (MCQ_MTB_LANES / 4u); k += 64u) {
+            reinterpret_cast<uint4 *>(s_w)[k] = sw[k];
+            reinterpret_cast<uint4 *>(s_i)[k] = si[k];
         }
         MCQ_WAVE_SYNC();
-        for (uint32_t k = lane; k < cnt; k += 64u) entries[first + b0 + k] = s_en[k];
+        for (uint32_t k = 0; k < cnt; k++) {
+            /* (every lane stores the same words: no branch on the lane number inside the chain) */
+            s_en[k].it0 = it;
+            s_en[k].dp = d | (pend << 8) | (it < pl.runs ? 0x80000000u : 0u);
+            mcq_mtb_stitch_group(s_w + k * MCQ_MTB_LANES, s_i + k * MCQ_MTB_LANES, pl, d, pend, it);
+        }
+        MCQ_WAVE_SYNC();
+        for (uint32_t k = lane; k < cnt; k += 64u) gentry[gfirst + g0 + k] = s_en[k];
         MCQ_WAVE_SYNC();
     }
     if (lane == 0) {
@@ -391,11 +441,39 @@ __global__ __launch_bounds__(64) void mcq_mtb_stitch_kernel(const mcq_query *__r
     }
 }
 
+// 3c. expand: one wave per (query, group) follows the group's blocks from the group's entry and notes theirs.
+__global__ __launch_bounds__(kMtbBlock) void mcq_mtb_expand_kernel(const mcq_query *__restrict__ queries,
+                                                                  const uint32_t *__restrict__ blk_off,
+                                                                  const uint32_t *__restrict__ grp_off,
+                                                                  const uint32_t *__restrict__ exits,
+                                                                  const McqMtbEntry *__restrict__ gentry,
+                                                                  McqMtbEntry *__restrict__ entries) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_ex[kMtbBlock / 64][MCQ_MTB_GROUP * MCQ_MTB_LANES];
+    __shared__ McqMtbEntry s_en[kMtbBlock / 64][MCQ_MTB_GROUP];
+    const uint32_t qi = blockIdx.y, lane = threadIdx.x & 63u, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t first = blk_off[qi], nb = blk_off[qi + 1u] - first, g = blockIdx.x * (kMtbBlock / 64) + wv;
+    if (g * MCQ_MTB_GROUP >= nb) return; /* (wave-uniform; no block barrier below) */
+    const McqMtbPlan pl = mcq_mtb_plan_of(queries, qi);
+    const uint32_t b0 = g * MCQ_MTB_GROUP, cnt = nb - b0 < MCQ_MTB_GROUP ? nb - b0 : MCQ_MTB_GROUP;
+    const uint4 *src = reinterpret_cast<const uint4 *>(exits + (uint64_t)(first + b0) * MCQ_MTB_LANES);
+    for (uint32_t k = lane; k < cnt * (MCQ_MTB_LANES / 4u); k += 64u) reinterpret_cast<uint4 *>(s_ex[wv])[k] = src[k];
+    const McqMtbEntry ge = gentry[grp_off[qi] + g];
+    uint32_t d = ge.dp & 0xFFu, pend = (ge.dp >> 8) & 0x7Fu, it = ge.it0;
+    MCQ_WAVE_SYNC();
+    for (uint32_t k = 0; k < cnt; k++) {
+        s_en[wv][k].it0 = it;
+        s_en[wv][k].dp = d | (pend << 8) | (it < pl.runs ? 0x80000000u : 0u);
+        mcq_mtb_stitch_step(s_ex[wv] + k * MCQ_MTB_LANES, pl, d, pend, it);
+    }
+    MCQ_WAVE_SYNC();
+    if (lane < cnt) entries[first + b0 + lane] = s_en[wv][lane];
+}
+
 // 4. parse: one wave per (query, block) from the block's true entry (mcq_mtb_parse_block: the batch code of the serial
 // walk), draws straight to the draw buffer, the attempts added to the row's `passes`.
 __global__ __launch_bounds__(kMtbBlock) void mcq_mtb_parse_kernel(const mcq_query *__restrict__ queries,
                                                                  const uint32_t *__restrict__ blk_off,
-                                                                 const uint8_t *__restrict__ yb,
+                                                                 const uint32_t *__restrict__ state,
                                                                  const McqMtbEntry *__restrict__ entries,
                                                                  const uint32_t *__restrict__ ovf, uint8_t *__restrict__ draws,
                                                                  const uint64_t *__restrict__ draw_off, mcq_result *__restrict__ res) {
@@ -415,9 +493,7 @@ __global__ __launch_bounds__(kMtbBlock) void mcq_mtb_parse_kernel(const mcq_quer
     const McqQueryWords q = {(uint32_t)__builtin_amdgcn_readfirstlane(raw.x), (uint32_t)__builtin_amdgcn_readfirstlane(raw.y),
                              (uint32_t)__builtin_amdgcn_readfirstlane(raw.z), (uint32_t)__builtin_amdgcn_readfirstlane(raw.w)};
     const uint32_t L0 = 50u - q.n_board(), n_opp = q.n_players() - 1u, n_deal = 5u - q.n_board(), runs = q.runs();
-    const uint8_t *src = yb + (uint64_t)(first + b) * MCQ_MT_N;
-    if (lane < MCQ_MT_N / 16u) reinterpret_cast<uint4 *>(w.yb)[lane] = reinterpret_cast<const uint4 *>(src)[lane];
-    else if (lane < MCQ_MT_N / 16u + 4u) reinterpret_cast<uint4 *>(w.yb)[lane] = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+    mcq_mtb_load_block(state + (uint64_t)(first + b) * MCQ_MT_N, w.yb, lane);
     if (lane == 0) {
         w.draws = draws + draw_off[qi];
         w.stride = ((uint64_t)runs + 63u) & ~63ull;
@@ -1550,16 +1626,22 @@ hipError_t mcq_launch_mt_parse(const mcq_query *d_q, uint32_t n, uint32_t seed32
     return hipGetLastError();
 }
 
-hipError_t mcq_launch_mt_blocks(const mcq_query *d_q, uint32_t n, uint32_t seed32, const uint32_t *d_blk_off, uint32_t max_blocks,
-                                uint8_t *d_yb, uint32_t *d_exits, void *d_entries, uint32_t *d_ovf, uint8_t *d_draws,
+hipError_t mcq_launch_mt_blocks(const mcq_query *d_q, uint32_t n, uint32_t seed32, const uint32_t *d_blk_off,
+                                const uint32_t *d_grp_off, uint32_t max_blocks, uint32_t *d_raw, uint32_t *d_exits, void *d_entries,
+                                uint32_t *d_gword, uint32_t *d_gits, void *d_gentry, uint32_t *d_ovf, uint8_t *d_draws,
                                 const uint64_t *d_draw_off, mcq_result *d_res, hipStream_t s) {
     if (n == 0 || max_blocks == 0) return hipSuccess;
-    const dim3 per_block((max_blocks + kMtbBlock / 64 - 1) / (kMtbBlock / 64), n);
-    hipLaunchKernelGGL(mcq_mtb_generate_kernel, dim3(n), dim3(kMtbGenBlock), 0, s, d_blk_off, seed32, d_yb);
-    hipLaunchKernelGGL(mcq_mtb_scan_kernel, per_block, dim3(kMtbBlock), 0, s, d_q, d_blk_off, d_yb, d_exits);
-    hipLaunchKernelGGL(mcq_mtb_stitch_kernel, dim3(n), dim3(64), 0, s, d_q, d_blk_off, d_exits,
-                       reinterpret_cast<McqMtbEntry *>(d_entries), d_ovf, d_res);
-    hipLaunchKernelGGL(mcq_mtb_parse_kernel, per_block, dim3(kMtbBlock), 0, s, d_q, d_blk_off, d_yb,
+    constexpr uint32_t kWaves = kMtbBlock / 64;
+    const uint32_t max_groups = (max_blocks + MCQ_MTB_GROUP - 1u) / MCQ_MTB_GROUP;
+    const dim3 per_block((max_blocks + kWaves - 1) / kWaves, n), per_group((max_groups + kWaves - 1) / kWaves, n);
+    hipLaunchKernelGGL(mcq_mtb_generate_kernel, dim3(n), dim3(kMtbGenBlock), 0, s, d_blk_off, seed32, d_raw);
+    hipLaunchKernelGGL(mcq_mtb_scan_kernel, per_block, dim3(kMtbBlock), 0, s, d_q, d_blk_off, d_raw, d_exits);
+    hipLaunchKernelGGL(mcq_mtb_compose_kernel, per_group, dim3(kMtbBlock), 0, s, d_q, d_blk_off, d_grp_off, d_exits, d_gword, d_gits);
+    hipLaunchKernelGGL(mcq_mtb_stitch_kernel, dim3(n), dim3(64), 0, s, d_q, d_blk_off, d_grp_off, d_gword, d_gits,
+                       reinterpret_cast<McqMtbEntry *>(d_gentry), d_ovf, d_res);
+    hipLaunchKernelGGL(mcq_mtb_expand_kernel, per_group, dim3(kMtbBlock), 0, s, d_q, d_blk_off, d_grp_off, d_exits,
+                       reinterpret_cast<const McqMtbEntry *>(d_gentry), reinterpret_cast<McqMtbEntry *>(d_entries));
+    hipLaunchKernelGGL(mcq_mtb_parse_kernel, per_block, dim3(kMtbBlock), 0, s, d_q, d_blk_off, d_raw,
                        reinterpret_cast<const McqMtbEntry *>(d_entries), d_ovf, d_draws, d_draw_off, d_res);
     return hipGetLastError();
 }

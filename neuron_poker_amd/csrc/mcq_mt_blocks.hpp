@@ -51,39 +51,38 @@ MCQ_HD bool mcq_mtb_is_r2(const McqMtbPlan &pl, uint32_t d) { return d < pl.two_
 //   lane < D: position lane, the first accepted word does not complete a pair that is drawn again;
 //   D <= lane < D + n_opp: position 2 (lane - D) + 1 (a second index), the first accepted word DOES (it equals the
 //   pending first index), so the walk steps back to the first index.
-// Every lane of a wave runs this on the same words (device: the bytes sit in LDS, one broadcast read per word).
-MCQ_HD uint32_t mcq_mtb_automaton(const uint8_t *yb, const McqMtbPlan &pl, uint32_t lane) {
+// Every lane of a wave runs this on the same words (device: the bytes sit in LDS, one broadcast read per word), so it is
+// written for instruction count: what a position needs comes out of ONE table word (ptab, MCQ_MTB_POS entries, filled by
+// mcq_mtb_fill_ptab; device: LDS) --
+//   bits 0-5 the mask of randint's loop (63 / 31), bits 8-13 the largest accepted value, bits 16-20 the position behind
+//   an accepted word (0 behind the last one), bit 24 "that completes an iteration", bit 25 first index, bit 26 second index
+#define MCQ_MTB_POS 24u
+MCQ_HD uint32_t mcq_mtb_pos_word(const McqMtbPlan &pl, uint32_t d) {
+    const uint32_t e = d + (d >= pl.two_opp ? 1u : 0u), rng = pl.L0 - 1u - e, last = d + 1u == pl.D ? 1u : 0u;
+    return (e > pl.z_max ? 31u : 63u) | (rng << 8) | ((last ? 0u : d + 1u) << 16) | (last << 24) |
+           ((d < pl.two_opp && !(d & 1u)) ? 1u << 25 : 0u) | (mcq_mtb_is_r2(pl, d) ? 1u << 26 : 0u);
+}
+MCQ_HD uint32_t mcq_mtb_automaton(const uint8_t *yb, const uint32_t *ptab, const McqMtbPlan &pl, uint32_t lane) {
     if (lane >= pl.D + (pl.two_opp >> 1)) return 0u;
-    bool again = lane >= pl.D; /* the next accepted word is a second index equal to its first */
+    /* `same` = the pending first index, or 64 ("no value") while it is unknown: a lane that entered on a second index
+     * without knowing the first takes the pair as final -- its twin lane D + d / 2 takes it as drawn again (`again`: any
+     * value matches, once), the stitch picks the one that is right */
+    uint32_t again = lane >= pl.D ? 1u : 0u;
     uint32_t d = again ? 2u * (lane - pl.D) + 1u : lane;
-    uint32_t pend = 0, pend_ok = 0, first = 0, seen = 0, its = 0;
+    uint32_t pend = 64u, first = 64u, its = 0;
     for (uint32_t i = 0; i < MCQ_MT_N; i++) {
-        const uint32_t y = yb[i];
-        const uint32_t e = d + (d >= pl.two_opp ? 1u : 0u);
-        const uint32_t v = e > pl.z_max ? (y & 31u) : (y & 63u);
-        if (v > pl.L0 - 1u - e) continue; /* rejected by randint's mask loop */
-        if (!seen) first = v;
-        seen = 1u;
-        if (d >= pl.two_opp) {
-            d++; /* a table card */
-        } else if ((d & 1u) == 0u) {
-            pend = v; /* a first index */
-            pend_ok = 1u;
-            d++;
-        } else { /* a second index: equal to the first = the pair is drawn again (l.171-176) */
-            const bool same = again || (pend_ok && v == pend);
-            again = false;
-            if (same) d--;
-            else d++;
-            /* (a lane that entered on a second index without knowing the first takes the pair as final: its twin lane
-             * D + d / 2 takes it as drawn again -- the stitch picks the one that is right) */
-        }
-        if (d == pl.D) {
-            d = 0;
-            its++;
-        }
+        const uint32_t t = ptab[d], v = yb[i] & t & 63u;
+        if (v > ((t >> 8) & 63u)) continue; /* rejected by randint's mask loop */
+        first = first == 64u ? v : first;
+        const bool r2 = (t >> 26) & 1u;
+        const bool back = r2 && ((again | (v == pend ? 1u : 0u)) != 0u); /* equal to the first = drawn again (l.171-176) */
+        again = r2 ? 0u : again;
+        pend = (t >> 25) & 1u ? v : pend;
+        its += back ? 0u : (t >> 24) & 1u;
+        d = back ? d - 1u : (t >> 16) & 31u;
     }
-    return d | (pend << 5) | (pend_ok << 11) | (first << 12) | (seen << 18) | (its << 19);
+    const uint32_t pend_ok = pend != 64u ? 1u : 0u, seen = first != 64u ? 1u : 0u;
+    return d | ((pend & 63u) << 5) | (pend_ok << 11) | ((first & 63u) << 12) | (seen << 18) | (its << 19);
 }
 
 struct McqMtbEntry { /* the walk in front of a block's first word */
@@ -98,6 +97,52 @@ MCQ_HD void mcq_mtb_stitch_step(const uint32_t *exits, const McqMtbPlan &pl, uin
     if (MCQ_MTB_PEND_OK(x)) pend = MCQ_MTB_PEND(x);
     d = MCQ_MTB_D(x);
     it += MCQ_MTB_ITS(x);
+}
+
+// The stitch in two levels (one step per block behind the other would be 3 900 dependent LDS reads for a 6-max
+// 100 000-run query: 0.5 ms): groups of MCQ_MTB_GROUP blocks are COMPOSED first, side by side -- lane = entry state of the
+// group, walking the group's blocks by their exit words --, which gives every group an exit word of the same form (and
+// its iterations in a word of their own); one wave then follows the GROUPS' exits, and every group, now knowing its
+// entry, follows its own blocks once more to note their entries.
+#define MCQ_MTB_GROUP 32u
+struct McqMtbWalk { /* a walk from an entry state across blocks, the first index of the entry's pair unknown */
+    uint32_t d, pend, pend_ok, first, seen, its;
+    bool again; /* entry variant "the first accepted word is a second index equal to its first": until a word is accepted */
+};
+MCQ_HD McqMtbWalk mcq_mtb_walk_from(const McqMtbPlan &pl, uint32_t lane) { /* lane as in mcq_mtb_automaton */
+    const bool again = lane >= pl.D;
+    const McqMtbWalk s = {again ? 2u * (lane - pl.D) + 1u : lane, 0u, 0u, 0u, 0u, 0u, again};
+    return s;
+}
+MCQ_HD void mcq_mtb_compose_step(const uint32_t *exits, const McqMtbPlan &pl, McqMtbWalk &s) {
+    uint32_t x;
+    if (!s.seen) { /* still in the entry state: the lane's own variant */
+        x = exits[s.again ? pl.D + (s.d >> 1) : s.d];
+    } else { /* a second index here has seen its first accepted inside the group */
+        x = exits[s.d];
+        if (mcq_mtb_is_r2(pl, s.d) && MCQ_MTB_SEEN(x) && MCQ_MTB_FIRST(x) == s.pend) x = exits[pl.D + (s.d >> 1)];
+    }
+    if (!s.seen && MCQ_MTB_SEEN(x)) s.first = MCQ_MTB_FIRST(x);
+    s.seen |= MCQ_MTB_SEEN(x);
+    if (MCQ_MTB_PEND_OK(x)) {
+        s.pend = MCQ_MTB_PEND(x);
+        s.pend_ok = 1u;
+    }
+    s.d = MCQ_MTB_D(x);
+    s.its += MCQ_MTB_ITS(x);
+}
+MCQ_HD uint32_t mcq_mtb_walk_word(const McqMtbWalk &s) { /* the exit word of a group (its iterations travel beside it) */
+    return s.d | (s.pend << 5) | (s.pend_ok << 11) | (s.first << 12) | (s.seen << 18);
+}
+/* one step of the walk over GROUPS: as mcq_mtb_stitch_step, the iterations from their own array */
+MCQ_HD void mcq_mtb_stitch_group(const uint32_t *words, const uint32_t *its, const McqMtbPlan &pl, uint32_t &d, uint32_t &pend,
+                                 uint32_t &it) {
+    uint32_t at = d;
+    if (mcq_mtb_is_r2(pl, d) && MCQ_MTB_SEEN(words[d]) && MCQ_MTB_FIRST(words[d]) == pend) at = pl.D + (d >> 1);
+    const uint32_t x = words[at];
+    if (MCQ_MTB_PEND_OK(x)) pend = MCQ_MTB_PEND(x);
+    d = MCQ_MTB_D(x);
+    it += its[at];
 }
 
 // State words a query consumes, as the host estimates them: per draw 1 / P(accept) words, per pair 1 / (1 - 1 / L)

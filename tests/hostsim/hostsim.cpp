@@ -316,15 +316,34 @@ extern "C" uint64_t hs_mt_parse_blocks(const mcq_query *q, uint32_t seed32, uint
     /* 2. scan */
     const McqMtbPlan pl = mcq_mtb_plan(L0, n_opp, n_deal, q->runs);
     std::vector<uint32_t> exits((size_t)n_blocks * MCQ_MTB_LANES);
+    uint32_t pos_tab[MCQ_MTB_POS];
+    for (uint32_t k = 0; k < MCQ_MTB_POS; k++) pos_tab[k] = mcq_mtb_pos_word(pl, k < D ? k : 0u);
     for (uint32_t b = 0; b < n_blocks; b++)
-        for (uint32_t l = 0; l < MCQ_MTB_LANES; l++) exits[(size_t)b * MCQ_MTB_LANES + l] = mcq_mtb_automaton(&yb[(size_t)b * MCQ_MT_N], pl, l);
-    /* 3. stitch */
+        for (uint32_t l = 0; l < MCQ_MTB_LANES; l++)
+            exits[(size_t)b * MCQ_MTB_LANES + l] = mcq_mtb_automaton(&yb[(size_t)b * MCQ_MT_N], pos_tab, pl, l);
+    /* 3. stitch: compose the groups, follow the groups, note every block's entry from its group's */
+    const uint32_t n_groups = (n_blocks + MCQ_MTB_GROUP - 1u) / MCQ_MTB_GROUP;
+    std::vector<uint32_t> gword((size_t)n_groups * MCQ_MTB_LANES), gits((size_t)n_groups * MCQ_MTB_LANES);
+    for (uint32_t g = 0; g < n_groups; g++)
+        for (uint32_t l = 0; l < MCQ_MTB_LANES; l++) {
+            McqMtbWalk s = mcq_mtb_walk_from(pl, l);
+            if (l < pl.D + (pl.two_opp >> 1))
+                for (uint32_t b = g * MCQ_MTB_GROUP; b < n_blocks && b < (g + 1u) * MCQ_MTB_GROUP; b++)
+                    mcq_mtb_compose_step(&exits[(size_t)b * MCQ_MTB_LANES], pl, s);
+            gword[(size_t)g * MCQ_MTB_LANES + l] = mcq_mtb_walk_word(s);
+            gits[(size_t)g * MCQ_MTB_LANES + l] = s.its;
+        }
     std::vector<McqMtbEntry> entry(n_blocks);
     uint32_t d = 0, pend = 0, it = 0;
-    for (uint32_t b = 0; b < n_blocks; b++) {
-        entry[b].it0 = it;
-        entry[b].dp = d | (pend << 8) | (it < q->runs ? 0x80000000u : 0u);
-        mcq_mtb_stitch_step(&exits[(size_t)b * MCQ_MTB_LANES], pl, d, pend, it);
+    for (uint32_t g = 0; g < n_groups; g++) {
+        uint32_t bd = d, bp = pend, bi = it; /* the group's entry: its blocks follow from there */
+        for (uint32_t b = g * MCQ_MTB_GROUP; b < n_blocks && b < (g + 1u) * MCQ_MTB_GROUP; b++) {
+            entry[b].it0 = bi;
+            entry[b].dp = bd | (bp << 8) | (bi < q->runs ? 0x80000000u : 0u);
+            mcq_mtb_stitch_step(&exits[(size_t)b * MCQ_MTB_LANES], pl, bd, bp, bi);
+        }
+        mcq_mtb_stitch_group(&gword[(size_t)g * MCQ_MTB_LANES], &gits[(size_t)g * MCQ_MTB_LANES], pl, d, pend, it);
+        if (bd != d || bi != it || (mcq_mtb_is_r2(pl, d) && bp != pend)) return ~0ull - 1u; /* the two levels disagree: a bug */
     }
     if (it < q->runs) return ~0ull;
     /* 4. parse */
