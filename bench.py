@@ -42,7 +42,7 @@ HBM_PEAK_GBPS = 8000.0
 
 
 KERNEL_SOURCES = ["neuron_poker_amd/csrc/mcq_device.hpp", "neuron_poker_amd/csrc/mcq_kernels.hip", "neuron_poker_amd/csrc/mcq_mt.hpp",
-                  "neuron_poker_amd/csrc/mcq_exact.hpp"]
+                  "neuron_poker_amd/csrc/mcq_exact.hpp", "neuron_poker_amd/csrc/mcq_mt_ext.hpp", "neuron_poker_amd/csrc/mcq_mt_blocks.hpp"]
 
 
 def kernel_source_hash():
@@ -457,6 +457,15 @@ def main():
                 "call_ms_host_buffers": 1e3 * dt, "kernel_ms_parse_plus_eval": eng.last_kernel_ms, "hand_evals_per_s": 2e5 / dt,
                 "wins_seed0": int(r1[0, 2] + r1[0, 3]), "passes_seed0": int(r1[0, 1]),
                 "equals_reference_known_answer": bool(int(r1[0, 2] + r1[0, 3]) == 65807 and int(r1[0, 1]) == 102091)}
+            # ... and a 6-max one (few long queries are parsed with their 624-word state blocks side by side, mcq_mt_blocks.hpp)
+            q6r = npa.pack_queries([[npa.card_id("AH"), npa.card_id("KH")]], [[255] * 5], 6, 100000)
+            eng.eval_batch(q6r, seed=0, mode=npa.MODE_REPLAY_MT19937)
+            t1 = time.perf_counter()
+            for i in range(5):
+                eng.eval_batch(q6r, seed=i, mode=npa.MODE_REPLAY_MT19937)
+            dt = (time.perf_counter() - t1) / 5
+            extras["single_query_6max_100k_replay"] = {"call_ms_host_buffers": 1e3 * dt, "kernel_ms_parse_plus_eval": eng.last_kernel_ms,
+                                                       "hand_evals_per_s": 6e5 / dt}
             # run_montecarlo's other arguments: opponents restricted to the top quarter of the preflop classes
             # (the range the reference's own test uses, tests/test_montecarlo_python.py:215-222), 2048 states x 6 players x
             # 20k iterations through mcq_eval_batch_ext / mcq_eval_ext_kernel (candidate lists instead of the re-draw loop)

@@ -321,7 +321,9 @@ __global__ __launch_bounds__(kMtbGenBlock) void mcq_mtb_generate_kernel(const ui
                 const uint32_t t = tid, tc = t < 169u ? t : 169u;
                 const uint32_t a0 = S[t], a1 = S[t + 1u], f = S[t + MCQ_MT_M], b0 = S[227u + t], b1 = S[228u + t];
                 const uint32_t c0 = S[454u + tc], c1o = S[455u + tc] /* (tc = 169: the padding behind the state) */;
-                const uint32_t z0 = S[0], z1 = S[1], zf = S[MCQ_MT_M];
+                /* (opaque: or the compiler moves these three reads into thread 169's branch, behind the wait for the others) */
+                uint32_t z0 = S[0], z1 = S[1], zf = S[MCQ_MT_M];
+                asm volatile("" : "+v"(z0), "+v"(z1), "+v"(zf));
                 const uint32_t c1 = t == 169u ? zf ^ mcq_mt_twist(z0, z1) /* the new x[0] */ : c1o;
                 const uint32_t nA = f ^ mcq_mt_twist(a0, a1);
                 const uint32_t nB = nA ^ mcq_mt_twist(b0, b1);

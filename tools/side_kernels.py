@@ -7,6 +7,7 @@ the kernels of the library that are not the bulk kernel, each on the batch bench
   mcq_eval_direct_kernel<0>    one lock-step of configs[4]: 1024 queries x 1000 runs, state mix of reference episodes
   mcq_eval_ext_kernel<0>       2048 states x 6 players x 20 000 runs, opponents restricted to the top quarter of the classes
   mcq_eval_ext_kernel<1> / mcq_mt_parse_ext_kernel   256 of those in the bit-exact mode
+  mcq_mtb_generate / scan / parse_kernel              ONE 6-max query of 100 000 runs in the bit-exact mode (state blocks side by side)
 
 Prints one JSON object: per kernel the units one launch processes, so that instruction counts can be put per unit.
 """
@@ -59,6 +60,12 @@ def main():
         eng.eval_batch_ext(qx[:256], npa.pack_query_ext(256, opp_range=top25), i, mode=npa.MODE_REPLAY_MT19937)
     units["mcq_eval_ext_kernel<1>"] = {"iterations": 256 * 20000}
     units["mcq_mt_parse_ext_kernel"] = {"iterations": 256 * 20000}
+    # few long queries of the bit-exact mode: the state blocks of a query side by side (mcq_mt_blocks.hpp)
+    q6 = npa.pack_queries([[npa.card_id("AH"), npa.card_id("KH")]], [[255] * 5], 6, 100000)
+    for i in range(REPS + 1):
+        eng.eval_batch(q6, seed=i, mode=npa.MODE_REPLAY_MT19937)
+    for k in ("mcq_mtb_generate_kernel", "mcq_mtb_scan_kernel", "mcq_mtb_parse_kernel"):
+        units[k] = {"iterations": 100000, "state_blocks_approx": 3900}
     print(json.dumps(units))
 
 
