@@ -137,6 +137,7 @@ struct mcq_ctx {
     McqDirectKarg direct_karg; /* one-launch path: the work of a small launch, passed by value */
     size_t publish_max_rows = 8192; /* host-buffer calls of at most this many rows get them through mcq_publish_kernel + flag (MCQ_PUBLISH_MAX_ROWS, 0 = never) */
     bool timing = false; /* mcq_set_kernel_timing: launches carry timestamp events */
+    int mt_blocks_margin = 8; /* state blocks beyond the estimate (MCQ_MT_BLOCKS_MARGIN; negative: the tests' way to the fall-back) */
     bool mt_blocks = true; /* parity mode, few long queries: the state blocks of a query parsed side by side (MCQ_MT_BLOCKS=0: always the serial walk) */
     bool ext_small = true; /* a few extended queries of the production mode in one launch (MCQ_EXT_SMALL=0: always the general path) */
     size_t direct_uniform_min = 128; /* one-launch path: from this many queries on the kernel lays its own work out (MCQ_DIRECT_UNIFORM_MIN; measured: 512 queries 39 -> 33 us per call, 1024: 48 -> 42, 4096: 137 -> 113) */

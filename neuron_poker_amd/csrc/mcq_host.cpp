@@ -249,7 +249,7 @@ int replay_batch_device(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed,
                 grp[i] = (uint32_t)groups;
                 const uint32_t n_opp = qq.n_players - 1u, n_deal = 5u - qq.n_board;
                 if (qq.n_players >= 1 && qq.n_players <= 10 && qq.n_board <= 5 && 2u * n_opp + n_deal != 0u && qq.runs != 0u) {
-                    const uint32_t nb = mcq_mtb_blocks_needed(50u - qq.n_board, n_opp, n_deal, qq.runs);
+                    const uint32_t nb = mcq_mtb_blocks_needed(50u - qq.n_board, n_opp, n_deal, qq.runs, c->mt_blocks_margin);
                     total += nb;
                     groups += (nb + MCQ_MTB_GROUP - 1u) / MCQ_MTB_GROUP;
                     if (nb > mtb.max_blocks) mtb.max_blocks = nb;
@@ -397,6 +397,7 @@ mcq_ctx *mcq_ctx_clone(const mcq_ctx *c) {
         d->direct_uniform_min = c->direct_uniform_min;
         d->ext_small = c->ext_small;
         d->mt_blocks = c->mt_blocks;
+        d->mt_blocks_margin = c->mt_blocks_margin;
         d->publish_max_rows = c->publish_max_rows;
         d->timing = c->timing;
         d->replay_device_bytes = c->replay_device_bytes;
@@ -485,6 +486,7 @@ mcq_ctx *mcq_create(int device, int flags) {
     if (const char *e = getenv("MCQ_DIRECT_POLL")) c->direct_poll = atoi(e) != 0;
     if (const char *e = getenv("MCQ_EXT_SMALL")) c->ext_small = atoi(e) != 0; /* see mcq_eval_batch_ext */
     if (const char *e = getenv("MCQ_MT_BLOCKS")) c->mt_blocks = atoi(e) != 0;  /* see replay_batch_device */
+    if (const char *e = getenv("MCQ_MT_BLOCKS_MARGIN")) c->mt_blocks_margin = atoi(e);
     if (const char *e = getenv("MCQ_DIRECT_UNIFORM_MIN")) { /* tuning knob, see eval_host_philox */
         const long v = atol(e);
         c->direct_uniform_min = (size_t)(v < 0 ? 0 : v);

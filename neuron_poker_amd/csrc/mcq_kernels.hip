@@ -482,7 +482,18 @@ __global__ __launch_bounds__(kMtbBlock) void mcq_mtb_parse_kernel(const mcq_quer
     __shared__ __attribute__((aligned(16))) McqMtBlockWave ws[kMtbBlock / 64];
     const uint32_t qi = blockIdx.y, lane = threadIdx.x & 63u, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t first = blk_off[qi], nb = blk_off[qi + 1u] - first, b = blockIdx.x * (kMtbBlock / 64) + wv;
-    if (b >= nb || ovf[qi] != 0u) return; /* (wave-uniform; no block barrier below) */
+    if (b >= nb) return; /* (wave-uniform; no block barrier below) */
+    if (ovf[qi] != 0u) {
+        /* the stream ran past the query's blocks: the host repeats the call with the serial walk; the evaluation kernel
+         * behind this one still reads the query's draws -- give it valid ones (index 0), not whatever the buffer held */
+        const uint4 raw = reinterpret_cast<const uint4 *>(queries)[qi];
+        const McqQueryWords q = {raw.x, raw.y, raw.z, raw.w};
+        const uint64_t bytes = (((uint64_t)q.runs() + 63u) & ~63ull) * (2u * (q.n_players() - 1u) + 5u - q.n_board());
+        const uint64_t per = ((bytes + nb - 1u) / nb + 15u) & ~15ull, lo = (uint64_t)b * per, hi = lo + per < bytes ? lo + per : bytes;
+        uint4 *dst = reinterpret_cast<uint4 *>(draws + draw_off[qi]);
+        for (uint64_t k = lo / 16u + lane; k < hi / 16u; k += 64u) dst[k] = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+        return;
+    }
     /* (into scalar registers by hand: the compiler knows that a load at a uniform address is uniform, drops a
      * readfirstlane of it -- and then cannot pin the walk's state in SGPRs where mcq_mt_batch asks for that) */
     const McqMtbEntry en0 = entries[first + b];

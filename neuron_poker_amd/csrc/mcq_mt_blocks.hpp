@@ -148,7 +148,7 @@ MCQ_HD void mcq_mtb_stitch_group(const uint32_t *words, const uint32_t *its, con
 // State words a query consumes, as the host estimates them: per draw 1 / P(accept) words, per pair 1 / (1 - 1 / L)
 // attempts; + a margin (half a percent and eight blocks: the count's standard deviation is about two words per
 // iteration, 632 words at 100 000 iterations).  (a host function: double arithmetic)
-static inline uint32_t mcq_mtb_blocks_needed(uint32_t L0, uint32_t n_opp, uint32_t n_deal, uint32_t runs) {
+static inline uint32_t mcq_mtb_blocks_needed(uint32_t L0, uint32_t n_opp, uint32_t n_deal, uint32_t runs, int margin = 8) {
     double per_it = 0.0;
     const uint32_t D = 2u * n_opp + n_deal;
     for (uint32_t d = 0; d < D; d++) {
@@ -158,7 +158,8 @@ static inline uint32_t mcq_mtb_blocks_needed(uint32_t L0, uint32_t n_opp, uint32
         per_it += w;
     }
     const double words = per_it * (double)runs * 1.005;
-    return (uint32_t)(words / (double)MCQ_MT_N) + 8u;
+    const long blocks = (long)(words / (double)MCQ_MT_N) + margin; /* (a negative margin: tests of the fall-back) */
+    return blocks < 1 ? 1u : (uint32_t)blocks;
 }
 
 // The parsing wave of step 4: what mcq_mt_batch touches (positions, ring, the block's bytes) and where the draws go.

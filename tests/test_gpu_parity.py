@@ -170,6 +170,16 @@ def test_replay_few_long_queries_by_state_blocks(eng, monkeypatch):
         assert np.array_equal(u64(e2.eval_batch(q, seed=7, first_query_id=first, mode=npa.MODE_REPLAY_MT19937)), exp)
     finally:
         e2.close()
+    # too few blocks (the estimate short by three): the streams that run past them are noticed and the call falls
+    # back to the serial walk; exactly enough blocks (the estimate without its margin mostly is): still right
+    monkeypatch.setenv("MCQ_MT_BLOCKS", "1")
+    for margin in ("-3", "0", "1"):
+        monkeypatch.setenv("MCQ_MT_BLOCKS_MARGIN", margin)
+        e3 = npa.Engine(0)
+        try:
+            assert np.array_equal(u64(e3.eval_batch(q, seed=7, first_query_id=first, mode=npa.MODE_REPLAY_MT19937)), exp), margin
+        finally:
+            e3.close()
 
 
 # ------------------------------------------------------------------------------------------ production mode
