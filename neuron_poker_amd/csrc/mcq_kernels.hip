@@ -310,32 +310,39 @@ __global__ __launch_bounds__(kMtbGenBlock) void mcq_mtb_generate_kernel(const ui
     }
     __syncthreads();
     uint32_t *dst = raw + (uint64_t)first * MCQ_MT_N;
-    const bool producer = tid < 256u; /* (wave-uniform) */
-    for (uint32_t b = 0; b <= nb; b++) { /* state b -> state b + 1; the query's block b - 1 = state b, tempered */
-        const uint32_t *S = mt[b & 1u];
-        uint32_t *N = mt[(b + 1u) & 1u];
-        if (producer) {
-            if (b < nb && tid < 227u) {
-                /* every read up front, none behind a condition on the thread (indices clamped instead): ONE round trip to
-                 * LDS per block */
-                const uint32_t t = tid, tc = t < 169u ? t : 169u;
+    /* two loops with the same barriers: the waves that make the state, the waves that copy it out */
+    if (tid < 256u) { /* (wave-uniform) */
+        /* every read up front, none behind a condition on the thread (indices clamped instead): ONE round trip to LDS per
+         * block.  Threads 227 .. 255 repeat thread 226's work and store nothing. */
+        const uint32_t t = tid < 226u ? tid : 226u, tc = t < 169u ? t : 169u;
+        const bool w_ab = tid < 227u, w_c = tid < 170u, is_last = tid == 169u;
+        for (uint32_t b = 0; b <= nb; b++) { /* state b -> state b + 1 */
+            const uint32_t *S = mt[b & 1u];
+            uint32_t *N = mt[(b + 1u) & 1u];
+            if (b < nb) {
                 const uint32_t a0 = S[t], a1 = S[t + 1u], f = S[t + MCQ_MT_M], b0 = S[227u + t], b1 = S[228u + t];
                 const uint32_t c0 = S[454u + tc], c1o = S[455u + tc] /* (tc = 169: the padding behind the state) */;
-                /* (opaque: or the compiler moves these three reads into thread 169's branch, behind the wait for the others) */
+                /* (opaque, or the compiler moves these three reads into thread 169's branch, behind the wait for the others) */
                 uint32_t z0 = S[0], z1 = S[1], zf = S[MCQ_MT_M];
                 asm volatile("" : "+v"(z0), "+v"(z1), "+v"(zf));
-                const uint32_t c1 = t == 169u ? zf ^ mcq_mt_twist(z0, z1) /* the new x[0] */ : c1o;
+                const uint32_t c1 = is_last ? zf ^ mcq_mt_twist(z0, z1) /* the new x[0] */ : c1o;
                 const uint32_t nA = f ^ mcq_mt_twist(a0, a1);
                 const uint32_t nB = nA ^ mcq_mt_twist(b0, b1);
-                N[t] = nA;
-                N[227u + t] = nB;
-                if (t < 170u) N[454u + t] = nB ^ mcq_mt_twist(c0, c1);
+                if (w_ab) {
+                    N[t] = nA;
+                    N[227u + t] = nB;
+                }
+                if (w_c) N[454u + t] = nB ^ mcq_mt_twist(c0, c1);
             }
-        } else if (b >= 1u && tid - 256u < MCQ_MT_N / 4u) {
-            const uint32_t t = tid - 256u;
-            reinterpret_cast<uint4 *>(dst + (uint64_t)(b - 1u) * MCQ_MT_N)[t] = *reinterpret_cast<const uint4 *>(S + 4u * t);
+            __syncthreads(); /* state b + 1 is complete; state b has been read for the last time */
         }
-        __syncthreads(); /* state b + 1 is complete; state b has been read for the last time */
+    } else {
+        const uint32_t t = tid - 256u;
+        for (uint32_t b = 0; b <= nb; b++) { /* the query's block b - 1 = state b */
+            if (b >= 1u && t < MCQ_MT_N / 4u)
+                reinterpret_cast<uint4 *>(dst + (uint64_t)(b - 1u) * MCQ_MT_N)[t] = *reinterpret_cast<const uint4 *>(mt[b & 1u] + 4u * t);
+            __syncthreads();
+        }
     }
 }
 
