@@ -180,22 +180,20 @@ struct McqMtPairWave { /* what mcq_mt_batch touches: the position tables and the
     uint32_t ptab[MCQ_MT_POSITIONS];
     uint8_t ring[(MCQ_MT_MAX_DRAWS + 1u) * MCQ_MT_ROW];
     uint8_t yb[2][MCQ_MT_N + 64u]; /* + 64: a batch reads 64 bytes from its position */
-    uint32_t cur, barriers;        /* the buffer being parsed; barriers the parser has passed */
     volatile uint32_t stop_at;     /* the producer leaves behind its barrier number stop_at (0 = not yet known) */
     uint32_t qi;
 };
 struct McqMtProducer {
     uint32_t mt[MCQ_MT_N + 64u];
 };
-__device__ __forceinline__ uint32_t mcq_mt_word_yb(const McqMtPairWave &w, uint32_t i) { return w.yb[w.cur][i]; }
+/* the buffer being parsed: blocks taken over so far decide (the first hand-over makes it buffer 0) */
+__device__ __forceinline__ uint32_t mcq_mt_word_yb(const McqMtPairWave &w, const McqMtState &st, uint32_t i) {
+    return w.yb[(st.blocks + 1u) & 1u][i];
+}
 __device__ __forceinline__ void mcq_mt_emit_lane(McqMtPairWave &, bool, uint32_t, uint32_t, uint32_t, uint32_t) {}
-__device__ __forceinline__ void mcq_mt_next_block(McqMtPairWave &w) {
+__device__ __forceinline__ void mcq_mt_next_block(McqMtPairWave &, McqMtState &st) {
     __syncthreads(); /* the producer has filled the other buffer; it may now overwrite the one just parsed */
-    if ((threadIdx.x & 63u) == 0u) {
-        w.cur ^= 1u;
-        w.barriers += 1u;
-    }
-    MCQ_WAVE_SYNC();
+    st.blocks += 1u; /* (= barriers the parser has passed) */
 }
 
 __global__ __launch_bounds__(kMtBlock) void mcq_mt_parse_kernel(const mcq_query *__restrict__ queries, uint32_t n,
@@ -209,8 +207,6 @@ __global__ __launch_bounds__(kMtBlock) void mcq_mt_parse_kernel(const mcq_query 
     for (;;) {
         if (threadIdx.x == 0) {
             w.qi = atomicAdd(counter, 1u);
-            w.cur = 1u; /* the first hand-over flips it to buffer 0 */
-            w.barriers = 0u;
             w.stop_at = 0u;
         }
         __syncthreads();
@@ -241,7 +237,7 @@ __global__ __launch_bounds__(kMtBlock) void mcq_mt_parse_kernel(const mcq_query 
                 /* every lane stores the same word: a store under `lane == 0` here would be a divergent branch in front of
                  * the barrier */
                 reinterpret_cast<unsigned long long *>(res + qi)[1] = st.passes;
-                if (lane == 0) w.stop_at = w.barriers + 1u; /* the producer is filling one more block: it leaves behind the next barrier */
+                if (lane == 0) w.stop_at = st.blocks + 1u; /* the producer is filling one more block: it leaves behind the next barrier */
                 __syncthreads();
             }
         }

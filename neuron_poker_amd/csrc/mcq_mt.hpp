@@ -213,8 +213,9 @@ MCQ_HD void mcq_mt_regenerate(W &w) {
 // regenerates its own state block and tempers the words it parses.  Two waves per query (McqMtPairWave in
 // mcq_kernels.hip): a PRODUCER wave regenerates and tempers a block ahead into a double buffer of (y & 63) | 0x80
 // bytes, the parsing wave only reads bytes.
-MCQ_HD uint32_t mcq_mt_word_yb(const McqMtWave &w, uint32_t i) { return (mcq_mt_temper(w.mt[i]) & 63u) | 0x80u; }
-MCQ_HD void mcq_mt_next_block(McqMtWave &w) { mcq_mt_regenerate(w); }
+struct McqMtState;
+MCQ_HD uint32_t mcq_mt_word_yb(const McqMtWave &w, const McqMtState &, uint32_t i) { return (mcq_mt_temper(w.mt[i]) & 63u) | 0x80u; }
+MCQ_HD void mcq_mt_next_block(McqMtWave &w, McqMtState &) { mcq_mt_regenerate(w); }
 MCQ_HD void mcq_mt_emit_lane(McqMtWave &, bool, uint32_t, uint32_t, uint32_t, uint32_t) {}
 /* a wave-uniform count the batch wants computed where it stands (mcq_opaque_uniform: pinned in a scalar register);
  * waves whose state comes out of memory overload this with the identity -- the backend cannot pin those */
@@ -227,6 +228,8 @@ struct McqMtState { /* wave-uniform */
     uint32_t d0;      /* draws of the current iteration already accepted */
     uint32_t flushed; /* iterations already written to the global buffer */
     uint64_t passes;
+    uint32_t blocks;  /* state blocks taken over from a producer wave (two waves per query): which buffer is being parsed
+                       * is a matter of registers, not of a word in LDS that every batch would have to wait for */
 };
 
 // 64 iterations [st.flushed, st.flushed + 64) (or the last `count` < 64) from the ring to draws[d * stride + it]:
@@ -288,7 +291,7 @@ MCQ_HD void mcq_mt_batch(W &w, McqMtState &st, const McqMtPlan &pl) {
     MCQ_PL(uint32_t, pa);  /* the position as the byte address of its ptab word: pos0 + 4 * (accepted words before the lane) */
     MCQ_PL(uint32_t, t);   /* that word */
     MCQ_FOR_LANES(l) {
-        MCQ_L(yb) = mcq_mt_word_yb(w, st.pos + l); /* (padded: lanes behind the block read words nobody uses) */
+        MCQ_L(yb) = mcq_mt_word_yb(w, st, st.pos + l); /* (padded: lanes behind the block read words nobody uses) */
         MCQ_L(E63) = l < rem ? (int32_t)(pl.k_e - MCQ_L(yb)) : -1; /* never accepted */
         if (TWO_ZONE) MCQ_L(E31) = l < rem ? (int32_t)(pl.k_e - (MCQ_L(yb) & 0x9Fu)) : -1; /* (y & 31) | 0x80 */
     }
@@ -370,7 +373,7 @@ MCQ_HD void mcq_mt_parse_loop(W &w, McqMtState &st, const McqMtPlan &pl, uint8_t
 #define MCQ_MT_STEP(TAIL_)                                                                       \
     do {                                                                                         \
         if (st.pos >= MCQ_MT_N) {                                                                \
-            mcq_mt_next_block(w);                                                                \
+            mcq_mt_next_block(w, st);                                                            \
             st.pos = 0;                                                                          \
         }                                                                                        \
         mcq_mt_batch<TWO_ZONE, TAIL_>(w, st, pl);                                                \

@@ -171,8 +171,8 @@ struct McqMtBlockWave {
     uint64_t stride;
     uint32_t two_opp;
 };
-MCQ_HD uint32_t mcq_mt_word_yb(const McqMtBlockWave &w, uint32_t i) { return w.yb[i]; }
-MCQ_HD void mcq_mt_next_block(McqMtBlockWave &) {} /* never: a wave parses one block */
+MCQ_HD uint32_t mcq_mt_word_yb(const McqMtBlockWave &w, const McqMtState &, uint32_t i) { return w.yb[i]; }
+MCQ_HD void mcq_mt_next_block(McqMtBlockWave &, McqMtState &) {} /* never: a wave parses one block */
 MCQ_HD uint32_t mcq_mt_pin(const McqMtBlockWave &, uint32_t x) { return x; }
 MCQ_HD void mcq_mt_emit_lane(McqMtBlockWave &w, bool final_draw, uint32_t t, uint32_t v, uint32_t pv, uint32_t it_done) {
     if (!final_draw) return;

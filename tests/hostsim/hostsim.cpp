@@ -311,7 +311,7 @@ extern "C" uint64_t hs_mt_parse_blocks(const mcq_query *q, uint32_t seed32, uint
     mcq_mt_seed(gen, seed32);
     for (uint32_t b = 0; b < n_blocks; b++) {
         mcq_mt_regenerate(gen);
-        for (uint32_t k = 0; k < MCQ_MT_N; k++) yb[(size_t)b * MCQ_MT_N + k] = (uint8_t)mcq_mt_word_yb(gen, k);
+        for (uint32_t k = 0; k < MCQ_MT_N; k++) yb[(size_t)b * MCQ_MT_N + k] = (uint8_t)mcq_mt_word_yb(gen, McqMtState(), k);
     }
     /* 2. scan */
     const McqMtbPlan pl = mcq_mtb_plan(L0, n_opp, n_deal, q->runs);
