@@ -1116,7 +1116,7 @@ struct McqExtReplayDraws { /* accepted draws from the host, all in list.pop orde
 // hands; cards: the 52-entry card table; wc.list: the query's candidate lists,
 // wc: the known hands and the list sizes.  Returns false when a range could not be dealt within
 // MCQ_EXT_MAX_TRIALS attempts.
-template <class Draws>
+template <class Draws, bool LDS_LIST = false /* the candidate lists lie in LDS: see mcq_iteration_ext_fast */>
 MCQ_HD bool mcq_iteration_ext(const McqExtCtx &qc, const McqExtWaveCtx &wc, Draws &dr, const McqCard *cards,
                               const uint32_t *sel8, uint16_t *ids, uint32_t ids_stride,
                               const uint32_t *tf, const uint32_t *tops, const uint32_t *sd, McqLaneAcc &acc) {
@@ -1144,16 +1144,25 @@ MCQ_HD bool mcq_iteration_ext(const McqExtCtx &qc, const McqExtWaveCtx &wc, Draw
         } else {
             const uint32_t n = wc.cnt[li];
             const uint16_t *list = wc.list[li];
+#if defined(__HIP_DEVICE_COMPILE__)
+            typedef __attribute__((address_space(3))) const uint16_t *LdsList;
+            const LdsList list_l = (LdsList)(uintptr_t)list;
+#define MCQ_XLIST(i) (LDS_LIST ? (uint32_t)list_l[i] : (uint32_t)list[i])
+#else
+#define MCQ_XLIST(i) ((uint32_t)list[i])
+#endif
             const uint32_t top = mcq_deck_top(dlo, dhi);
             bool ok = false;
             c1 = c2 = 0;
-            for (uint32_t trial = 0; trial < MCQ_EXT_MAX_TRIALS && !ok; trial++) {
-                acc.passes++;
-                const uint32_t e = list[dr.pick(n)];
+            uint32_t trial = 0;
+            for (; trial < MCQ_EXT_MAX_TRIALS && !ok; trial++) {
+                const uint32_t e = MCQ_XLIST(dr.pick(n));
                 c1 = e & 0xFFu;
                 c2 = e >> 8;
                 ok = mcq_deck_has(dlo, dhi, c1) && mcq_deck_has(dlo, dhi, c2) && c2 != top;
             }
+#undef MCQ_XLIST
+            acc.passes += trial;
             dealt = dealt && ok;
             if (!known && ok && c2 > c1) c2 = mcq_deck_next(dlo, dhi, c2); /* deck.pop(r2) after deck.pop(r1), l.178-179 */
         }
@@ -1194,13 +1203,24 @@ MCQ_HD bool mcq_iteration_ext(const McqExtCtx &qc, const McqExtWaveCtx &wc, Draw
 // 6-max at the top quarter of the classes: ~1650 -> ~900 VALU instructions per wave-iteration.
 // (PIN: keep the opponent count in a scalar register of its own, see mcq_opaque_uniform; the one-launch kernel, whose
 // query context comes out of LDS, cannot: the backend refuses the copy.)
-template <class Draws, bool PIN = true>
+// (LDS_LIST: the caller knows the candidate list lies in LDS -- staged by the block -- so a trial reads it with a
+// 32-bit LDS address instead of through a generic pointer: a flat load waits for both memory counters and takes
+// several times as long, in a loop where every trial is one dependent chain word -> index -> entry -> test.)
+template <class Draws, bool PIN = true, bool LDS_LIST = false>
 MCQ_HD bool mcq_iteration_ext_fast(const McqExtCtx &qc, const McqExtWaveCtx &wc, Draws &dr, const McqCard *cards,
                                    const uint32_t *sel8, const uint32_t *tf, const uint32_t *tops, const uint32_t *sd,
                                    McqLaneAcc &acc) {
     uint64_t deck = ((uint64_t)qc.fdeck_hi << 32) | qc.fdeck_lo;
     const uint32_t n = wc.cnt[0];
-    const uint16_t *list = wc.list[0];
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) const uint16_t *LdsList;
+    const uint16_t *list_g = wc.list[0];
+    const LdsList list_l = (LdsList)(uintptr_t)list_g; /* (the low half of a generic LDS address is the LDS address) */
+#define MCQ_XLIST(i) (LDS_LIST ? (uint32_t)list_l[i] : (uint32_t)list_g[i])
+#else
+    const uint16_t *list_g = wc.list[0];
+#define MCQ_XLIST(i) ((uint32_t)list_g[i])
+#endif
     const uint32_t n_opp = PIN ? mcq_opaque_uniform(qc.n_players - 1u) : qc.n_players - 1u;
     McqHole opp[MCQ_MAX_OPP];
     bool dealt = true;
@@ -1208,24 +1228,24 @@ MCQ_HD bool mcq_iteration_ext_fast(const McqExtCtx &qc, const McqExtWaveCtx &wc,
     if (P < n_opp) {                                                                                                \
         const uint32_t dhi = (uint32_t)(deck >> 32), dlo = (uint32_t)deck;                                          \
         const uint32_t top = mcq_deck_top(dlo, dhi);                                                                \
-        uint32_t c1 = 0, c2 = 0;                                                                                    \
+        uint32_t c1 = 0, c2 = 0, trial = 0;                                                                         \
         bool ok = false;                                                                                            \
-        for (uint32_t trial = 0; trial < MCQ_EXT_MAX_TRIALS && !ok; trial++) {                                      \
-            acc.passes++;                                                                                           \
-            const uint32_t e = list[dr.pick(n)];                                                                    \
+        for (; trial < MCQ_EXT_MAX_TRIALS && !ok; trial++) {                                                        \
+            const uint32_t e = MCQ_XLIST(dr.pick(n));                                                               \
             c1 = e & 0xFFu;                                                                                         \
             c2 = e >> 8;                                                                                            \
             ok = (((deck >> c1) & (deck >> c2)) & 1u) != 0u && c2 != top; /* both still there, B not the highest */ \
         }                                                                                                           \
+        acc.passes += trial; /* (the lane's own count: lanes leave the loop at different trials) */                 \
         dealt = dealt && ok;                                                                                        \
         if (ok && c2 > c1) c2 = mcq_deck_next(dlo, dhi, c2); /* deck.pop(r2) after deck.pop(r1), l.178-179 */       \
-        c1 = c1 < 52u ? c1 : 0u;                                                                                    \
-        c2 = c2 < 52u ? c2 : 0u;                                                                                    \
+        /* (c1, c2 are entries of the list -- card ids below 52 -- or, with an empty trial budget, zero: no clamp) */ \
         deck &= ~(((uint64_t)1 << c1) | ((uint64_t)1 << c2));                                                       \
         opp[P].set(cards[c1], cards[c2]);                                                                           \
     }
     MCQ_XOPP(0) MCQ_XOPP(1) MCQ_XOPP(2) MCQ_XOPP(3) MCQ_XOPP(4) MCQ_XOPP(5) MCQ_XOPP(6) MCQ_XOPP(7) MCQ_XOPP(8)
 #undef MCQ_XOPP
+#undef MCQ_XLIST
     uint32_t dlo = (uint32_t)deck, dhi = (uint32_t)(deck >> 32);
     uint32_t L = mcq_popc(qc.fdeck_lo) + mcq_popc(qc.fdeck_hi) - 2u * n_opp; /* wave-uniform: no counting per lane */
     McqBoard b = qc.board;

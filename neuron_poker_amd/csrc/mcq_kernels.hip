@@ -1189,7 +1189,7 @@ __global__ __launch_bounds__(kExtBlock) void mcq_eval_ext_kernel(const mcq_query
     McqExtCtx qc;
     WaveTally tally;
     tally.clear();
-    bool failed = false, fresh = true;
+    bool failed = false, fresh = true, list_in_lds = false;
     for (;;) {
         if (fresh) {
             if (qi >= n) break;
@@ -1209,6 +1209,7 @@ __global__ __launch_bounds__(kExtBlock) void mcq_eval_ext_kernel(const mcq_query
                 if (lane < 10u) wc.hand[lane] = lane < qc.n_hands ? mcq_ext_hand(q, er, lane) : 0u;
                 if (MODE == MCQ_MODE_PHILOX) {
                     const uint32_t n_lists = mcq_ext_n_lists(q, er);
+                    list_in_lds = __builtin_amdgcn_readfirstlane(s_stage[2] && qi - s_stage[0] < s_stage[1] ? 1 : 0) != 0;
                     uint32_t c = 1;
                     if (lane < MCQ_EXT_MAX_LISTS) {
                         c = lane < n_lists ? cnts[(size_t)qi * lists_stride + lane] : 1u;
@@ -1248,9 +1249,15 @@ __global__ __launch_bounds__(kExtBlock) void mcq_eval_ext_kernel(const mcq_query
                 McqExtCtrDraws dr;
                 dr.start(seed, first_qid + qi, stream);
                 const uint32_t cnt = (uint32_t)min((uint64_t)s_iters, (uint64_t)qc.runs - it0);
-                if (qc.fast) /* (wave-uniform) */
+                if (qc.fast && list_in_lds) /* (wave-uniform) */
+                    for (uint32_t j = 0; j < cnt && !failed; j++)
+                        failed = !mcq_iteration_ext_fast<McqExtCtrDraws, true, true>(qc, wc, dr, cards, tab.sel8, g_tab->tf, tab.tops, tab.sd, acc);
+                else if (qc.fast)
                     for (uint32_t j = 0; j < cnt && !failed; j++)
                         failed = !mcq_iteration_ext_fast(qc, wc, dr, cards, tab.sel8, g_tab->tf, tab.tops, tab.sd, acc);
+                else if (list_in_lds)
+                    for (uint32_t j = 0; j < cnt && !failed; j++)
+                        failed = !mcq_iteration_ext<McqExtCtrDraws, true>(qc, wc, dr, cards, tab.sel8, my_ids, kExtBlock, g_tab->tf, tab.tops, tab.sd, acc);
                 else
                     for (uint32_t j = 0; j < cnt && !failed; j++)
                         failed = !mcq_iteration_ext(qc, wc, dr, cards, tab.sel8, my_ids, kExtBlock, g_tab->tf, tab.tops, tab.sd, acc);
@@ -1385,10 +1392,10 @@ __global__ __launch_bounds__(kExtBlock) void mcq_eval_ext_small_kernel(McqExtSma
             const uint32_t cnt = (uint32_t)min((uint64_t)s_iters, (uint64_t)qc.runs - it0);
             if (qc.fast) /* (block-uniform) */
                 for (uint32_t j = 0; j < cnt && !failed; j++)
-                    failed = !mcq_iteration_ext_fast<McqExtCtrDraws, false>(qc, wave_ctx, dr, cards, tab.sel8, g_tab->tf, tab.tops, tab.sd, acc);
+                    failed = !mcq_iteration_ext_fast<McqExtCtrDraws, false, true>(qc, wave_ctx, dr, cards, tab.sel8, g_tab->tf, tab.tops, tab.sd, acc);
             else
                 for (uint32_t j = 0; j < cnt && !failed; j++)
-                    failed = !mcq_iteration_ext(qc, wave_ctx, dr, cards, tab.sel8, ids + tid, kExtBlock, g_tab->tf, tab.tops, tab.sd, acc);
+                    failed = !mcq_iteration_ext<McqExtCtrDraws, true>(qc, wave_ctx, dr, cards, tab.sel8, ids + tid, kExtBlock, g_tab->tf, tab.tops, tab.sd, acc);
         }
         tally.add(acc);
     }
