@@ -466,6 +466,12 @@ def main():
             dt = (time.perf_counter() - t1) / 5
             extras["single_query_6max_100k_replay"] = {"call_ms_host_buffers": 1e3 * dt, "kernel_ms_parse_plus_eval": eng.last_kernel_ms,
                                                        "hand_evals_per_s": 6e5 / dt}
+            mtb = {k: side_counters[k].get("kernel_avg_ms_rocprof") for k in
+                   ("mcq_mtb_generate_kernel", "mcq_mtb_scan_kernel", "mcq_mtb_parse_kernel") if k in side_counters}
+            if mtb:   # the kernels of this call as rocprofv3 timed them (profiles/current.json); the first is one work-group
+                extras["single_query_6max_100k_replay"]["kernels_ms_rocprof"] = dict(
+                    mtb, counters_fresh=fresh, bound="the MT19937 recurrence: one dependent LDS round trip per 624-word state "
+                                                     "block in ONE work-group (mcq_mtb_generate_kernel, ~0.19 us per block)")
             # run_montecarlo's other arguments: opponents restricted to the top quarter of the preflop classes
             # (the range the reference's own test uses, tests/test_montecarlo_python.py:215-222), 2048 states x 6 players x
             # 20k iterations through mcq_eval_batch_ext / mcq_eval_ext_kernel (candidate lists instead of the re-draw loop)

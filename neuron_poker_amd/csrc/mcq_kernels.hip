@@ -186,14 +186,17 @@ struct McqMtPairWave { /* what mcq_mt_batch touches: the position tables and the
 struct McqMtProducer {
     uint32_t mt[MCQ_MT_N + 64u];
 };
-/* the buffer being parsed: blocks taken over so far decide (the first hand-over makes it buffer 0) */
+/* the buffer being parsed: st.src, its byte offset (the first hand-over makes it buffer 0: the state starts at buffer 1) */
+constexpr uint32_t kMtYbBytes = MCQ_MT_N + 64u;
 __device__ __forceinline__ uint32_t mcq_mt_word_yb(const McqMtPairWave &w, const McqMtState &st, uint32_t i) {
-    return w.yb[(st.blocks + 1u) & 1u][i];
+    return (&w.yb[0][0])[st.src + i];
 }
 __device__ __forceinline__ void mcq_mt_emit_lane(McqMtPairWave &, bool, uint32_t, uint32_t, uint32_t, uint32_t) {}
+__device__ __forceinline__ constexpr bool mcq_mt_padded(const McqMtPairWave &) { return true; } /* yb[.][624 .. 688) = 0xFF */
 __device__ __forceinline__ void mcq_mt_next_block(McqMtPairWave &, McqMtState &st) {
     __syncthreads(); /* the producer has filled the other buffer; it may now overwrite the one just parsed */
     st.blocks += 1u; /* (= barriers the parser has passed) */
+    st.src = kMtYbBytes - st.src;
 }
 
 __global__ __launch_bounds__(kMtBlock) void mcq_mt_parse_kernel(const mcq_query *__restrict__ queries, uint32_t n,
@@ -204,6 +207,7 @@ __global__ __launch_bounds__(kMtBlock) void mcq_mt_parse_kernel(const mcq_query 
     __shared__ __attribute__((aligned(16))) McqMtProducer prod;
     const uint32_t lane = threadIdx.x & 63u;
     const bool producer = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0u;
+    w.yb[threadIdx.x >> 6][MCQ_MT_N + lane] = 0xFFu; /* behind both buffers' words: accepted nowhere (mcq_mt_padded) */
     for (;;) {
         if (threadIdx.x == 0) {
             w.qi = atomicAdd(counter, 1u);
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(kMtBlock) void mcq_mt_parse_kernel(const mcq_query 
                     if (w.stop_at == b + 1u) break;
                 }
             } else {
-                McqMtState st = {MCQ_MT_N, 0u, 0u, 0u, 0ull};
+                McqMtState st = {MCQ_MT_N, 0u, 0u, 0u, 0ull, 0u, kMtYbBytes};
                 mcq_mt_parse_query(w, st, 50u - q.n_board(), n_opp, n_deal, runs, draws + draw_off[qi],
                                    ((uint64_t)runs + 63u) & ~63ull);
                 /* every lane stores the same word: a store under `lane == 0` here would be a divergent branch in front of
@@ -352,7 +356,7 @@ __device__ __forceinline__ void mcq_mtb_load_block(const uint32_t *__restrict__ 
 #pragma unroll
     for (uint32_t k = 0; k < 10u; k++)
         if (64u * k + lane < MCQ_MT_N) dst[64u * k + lane] = (uint8_t)((mcq_mt_temper(y[k]) & 63u) | 0x80u);
-    dst[MCQ_MT_N + lane] = 0x80u;
+    dst[MCQ_MT_N + lane] = 0xFFu; /* (mcq_mt_padded) */
     MCQ_WAVE_SYNC();
 }
 __device__ __forceinline__ McqMtbPlan mcq_mtb_plan_of(const mcq_query *__restrict__ queries, uint32_t qi) {

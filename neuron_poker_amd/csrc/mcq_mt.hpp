@@ -221,6 +221,10 @@ MCQ_HD void mcq_mt_emit_lane(McqMtWave &, bool, uint32_t, uint32_t, uint32_t, ui
  * waves whose state comes out of memory overload this with the identity -- the backend cannot pin those */
 template <class W>
 MCQ_HD uint32_t mcq_mt_pin(const W &, uint32_t x) { return mcq_opaque_uniform(x); }
+/* does the wave's word source answer 0xFF behind the block's last word?  (E = k_e - 0xFF is negative: such a word is
+ * accepted nowhere in zone 63, and the batch need not mask the lanes behind the block) */
+template <class W>
+MCQ_HD constexpr bool mcq_mt_padded(const W &) { return false; }
 
 struct McqMtState { /* wave-uniform */
     uint32_t pos;     /* next unread state word, 624 = regenerate first */
@@ -230,6 +234,7 @@ struct McqMtState { /* wave-uniform */
     uint64_t passes;
     uint32_t blocks;  /* state blocks taken over from a producer wave (two waves per query): which buffer is being parsed
                        * is a matter of registers, not of a word in LDS that every batch would have to wait for */
+    uint32_t src;     /* ... and that buffer's byte offset */
 };
 
 // 64 iterations [st.flushed, st.flushed + 64) (or the last `count` < 64) from the ring to draws[d * stride + it]:
@@ -292,7 +297,8 @@ MCQ_HD void mcq_mt_batch(W &w, McqMtState &st, const McqMtPlan &pl) {
     MCQ_PL(uint32_t, t);   /* that word */
     MCQ_FOR_LANES(l) {
         MCQ_L(yb) = mcq_mt_word_yb(w, st, st.pos + l); /* (padded: lanes behind the block read words nobody uses) */
-        MCQ_L(E63) = l < rem ? (int32_t)(pl.k_e - MCQ_L(yb)) : -1; /* never accepted */
+        if (!TWO_ZONE && mcq_mt_padded(w)) MCQ_L(E63) = (int32_t)(pl.k_e - MCQ_L(yb)); /* (0xFF behind the block: negative) */
+        else MCQ_L(E63) = l < rem ? (int32_t)(pl.k_e - MCQ_L(yb)) : -1; /* never accepted */
         if (TWO_ZONE) MCQ_L(E31) = l < rem ? (int32_t)(pl.k_e - (MCQ_L(yb) & 0x9Fu)) : -1; /* (y & 31) | 0x80 */
     }
     uint64_t M = MCQ_BALLOT_OF(l, MCQ_L(E63) >= (int32_t)pl.e_mid);
@@ -304,14 +310,18 @@ MCQ_HD void mcq_mt_batch(W &w, McqMtState &st, const McqMtPlan &pl) {
                : (int32_t)(MCQ_L(t) & 0xFFu) <= MCQ_L(E63)) &&                                                     \
      (!TAIL || MCQ_L(P) < p_lim))
 #define MCQ_MT_ACCEPT(P) (MCQ_L(t) = MCQ_PTAB_AT(w, MCQ_L(P)), MCQ_MT_ACCEPT_T(P))
-    for (;;) { /* settled when a round answers with the accept bits it was asked with (a scalar compare) */
-        const uint64_t M1 = MCQ_BALLOT_OF(l, MCQ_MT_ACCEPT(pa));
+    /* settled when a round answers with the accept bits it was asked with (a scalar compare at the loop's foot) */
+    uint64_t M1 = MCQ_BALLOT_OF(l, MCQ_MT_ACCEPT(pa));
+#ifdef MCQ_MT_STATS
+    g_rounds++;
+#endif
+    while (M1 != M) {
+        M = M1;
+        MCQ_FOR_LANES(l) { MCQ_L(pa) = MCQ_POS4_FROM(M, l, pos0); }
+        M1 = MCQ_BALLOT_OF(l, MCQ_MT_ACCEPT(pa));
 #ifdef MCQ_MT_STATS
         g_rounds++;
 #endif
-        if (M1 == M) break;
-        M = M1;
-        MCQ_FOR_LANES(l) { MCQ_L(pa) = MCQ_POS4_FROM(M, l, pos0); }
     }
     MCQ_MT_STAMP(2);
     /* write-out: every lane computes its slot (t is the word of the final position), the accepted ones store; then

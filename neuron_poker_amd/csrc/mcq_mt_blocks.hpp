@@ -174,6 +174,7 @@ struct McqMtBlockWave {
 MCQ_HD uint32_t mcq_mt_word_yb(const McqMtBlockWave &w, const McqMtState &, uint32_t i) { return w.yb[i]; }
 MCQ_HD void mcq_mt_next_block(McqMtBlockWave &, McqMtState &) {} /* never: a wave parses one block */
 MCQ_HD uint32_t mcq_mt_pin(const McqMtBlockWave &, uint32_t x) { return x; }
+MCQ_HD constexpr bool mcq_mt_padded(const McqMtBlockWave &) { return true; } /* yb[624 .. 688) = 0xFF */
 MCQ_HD void mcq_mt_emit_lane(McqMtBlockWave &w, bool final_draw, uint32_t t, uint32_t v, uint32_t pv, uint32_t it_done) {
     if (!final_draw) return;
     const uint32_t d = (((t >> 16) & 0xFFFu) * 497u) >> 16; /* / MCQ_MT_ROW, exact below 24 rows (checked in the tests) */

@@ -355,7 +355,7 @@ extern "C" uint64_t hs_mt_parse_blocks(const mcq_query *q, uint32_t seed32, uint
     for (uint32_t b = 0; b < n_blocks; b++) {
         if (!(entry[b].dp >> 31)) continue;
         memcpy(w.yb, &yb[(size_t)b * MCQ_MT_N], MCQ_MT_N);
-        memset(w.yb + MCQ_MT_N, 0x80, 64);
+        memset(w.yb + MCQ_MT_N, 0xFF, 64);
         passes += mcq_mtb_parse_block(w, L0, n_opp, n_deal, q->runs, entry[b]);
     }
     return passes;
