@@ -52,7 +52,8 @@
 #define MCQ_BALLOT(name) __ballot(name)
 #define MCQ_BALLOT_K(name, k) __ballot(name[k])
 #define MCQ_BALLOT_OF(l, expr) ({ const uint32_t l __attribute__((unused)) = mcq_mt_lane(); __ballot(expr); }) /* ballot of an expression of the lane's values */
-#define MCQ_LANE_OF(m, l) mcq_mt_lane_of(m)    /* is this lane's bit set in the wave mask m? */
+#define MCQ_LANE_OF(m, l) __builtin_amdgcn_inverse_ballot_w64(m) /* is this lane's bit set in the wave mask m?  (a condition on
+                                                                  * it makes m the EXEC mask: no vector instruction at all) */
 /* number of set bits of the wave mask m below this lane */
 #define MCQ_COUNT_BELOW(m, l) __builtin_amdgcn_mbcnt_hi((uint32_t)((m) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(m), 0u))
 #define MCQ_WAVE_SYNC()                                                  \
@@ -333,9 +334,9 @@ MCQ_HD void mcq_mt_batch(W &w, McqMtState &st, const McqMtPlan &pl) {
     MCQ_FOR_LANES(l) {
         MCQ_L(at) = ((MCQ_L(t) >> 16) & 0xFFFu) + ((st.it_done + ((MCQ_L(t) >> 8) & 0xFFu)) & (MCQ_MT_RING - 1u));
         MCQ_L(v) = TWO_ZONE && (MCQ_L(t) & MCQ_MT_ZONE31) ? (MCQ_L(yb) & 0x9Fu) : MCQ_L(yb);
-        /* the accepted lanes (the compare again: cheaper than turning the mask M back into a lane condition; t and pa are
-         * those of the final round) -- lanes behind a re-drawn pair too: see above */
-        if (MCQ_MT_ACCEPT_T(pa)) w.ring[MCQ_L(at) + MCQ_MT_ROW] = (uint8_t)MCQ_L(v);
+        /* the accepted lanes (M is the final round's answer; t and pa are that round's) -- lanes behind a re-drawn pair
+         * too: see above */
+        if (MCQ_LANE_OF(M, l)) w.ring[MCQ_L(at) + MCQ_MT_ROW] = (uint8_t)MCQ_L(v);
     }
     MCQ_WAVE_SYNC();
     MCQ_MT_STAMP(3);
