@@ -191,15 +191,18 @@ MCQ_HD bool mcq_mt_parse_query_ext(W &w, McqMtExtState &st, const McqQueryWords 
             }
             const uint64_t In = MCQ_BALLOT_OF(l, l >= st.start && l < st.cnt);
             const uint64_t A1 = MCQ_BALLOT_OF(l, MCQ_L(v1) <= rng1) & In, A2 = MCQ_BALLOT_OF(l, MCQ_L(v2) <= rng2) & In;
-            uint64_t M = A1;
-            for (;;) { /* phases: settled when a round answers with the accept bits it was asked with */
-                MCQ_FOR_LANES(l) { MCQ_L(g) = phase0 + MCQ_COUNT_BELOW(M, l); }
-                const uint64_t Odd = MCQ_BALLOT_OF(l, (MCQ_L(g) & 1u) != 0u);
-                const uint64_t M1 = (A1 & ~Odd) | (A2 & Odd);
-                if (M1 == M) break;
+            /* phases: settled when a round answers with the accept bits it was asked with (tested at the loop's foot: a
+             * scalar compare and branch per round) */
+            uint64_t M = A1, Odd, M1;
+            MCQ_FOR_LANES(l) { MCQ_L(g) = phase0 + MCQ_COUNT_BELOW(M, l); }
+            Odd = MCQ_BALLOT_OF(l, (MCQ_L(g) & 1u) != 0u);
+            M1 = (A1 & ~Odd) | (A2 & Odd);
+            while (M1 != M) {
                 M = M1;
+                MCQ_FOR_LANES(l) { MCQ_L(g) = phase0 + MCQ_COUNT_BELOW(M, l); }
+                Odd = MCQ_BALLOT_OF(l, (MCQ_L(g) & 1u) != 0u);
+                M1 = (A1 & ~Odd) | (A2 & Odd);
             }
-            const uint64_t Odd = MCQ_BALLOT_OF(l, (MCQ_L(g) & 1u) != 0u);
             const uint64_t R2 = M & Odd; /* the accepted second indices: one attempt each (l.168) */
             MCQ_FOR_LANES(l) {
                 MCQ_L(v) = (MCQ_L(g) & 1u) ? MCQ_L(v2) : MCQ_L(v1);
