@@ -157,6 +157,8 @@ def test_replay_few_long_queries_by_state_blocks(eng, monkeypatch):
     runs = g.choice([2000, 5000, 12000, 20000], B)
     runs[3] = 1
     runs[7] = 0
+    c = g.permutation(52)[:7]   # a query that draws nothing: one player, the table complete
+    hole[13], board[13], npl[13] = c[:2], c[2:], 1
     q = npa.pack_queries(hole, board, npl, runs)
     first = 2 ** 32 - 10
     exp = O.run_batch(O.MODE_MT, q.view(np.uint8).reshape(-1, 16), 7, first, threads=8)
