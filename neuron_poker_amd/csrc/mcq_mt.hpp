@@ -170,42 +170,42 @@ MCQ_HD void mcq_mt_seed(W &w, uint32_t s) {
     }
 }
 
-// The next 624 state words.  new[k] needs old[k], old[k+1] and [k+397]: old for k < 227, else new[k-227] -- three
-// sweeps of at most 227 independent elements each.  A sweep reads ALL its operands (four steps of 64 lanes, twelve LDS
-// reads in flight) before it writes any of its results: one round trip to LDS per sweep instead of one per step, and
-// within a sweep no element is read after it has been written (a sweep only reads its own range, the word behind it
-// and ranges of other sweeps).
-template <class W>
-MCQ_HD void mcq_mt_regen_sweep(W &w, uint32_t first, uint32_t lim) {
-    MCQ_PL(uint32_t, nv)[4];
-    MCQ_FOR_LANES(l) {
-#pragma unroll
-        for (uint32_t s = 0; s < 4u; s++) {
-            const uint32_t k = first + 64u * s + l;
-            MCQ_L(nv)[s] = 0;
-            if (k < lim) {
-                const uint32_t far = k < 227u ? k + MCQ_MT_M : k - 227u;
-                MCQ_L(nv)[s] = w.mt[far] ^ mcq_mt_twist(w.mt[k], w.mt[k + 1u]);
-            }
-        }
-    }
-    MCQ_WAVE_SYNC();
-    MCQ_FOR_LANES(l) {
-#pragma unroll
-        for (uint32_t s = 0; s < 4u; s++) {
-            const uint32_t k = first + 64u * s + l;
-            if (k < lim) w.mt[k] = MCQ_L(nv)[s];
-        }
-    }
-    MCQ_WAVE_SYNC();
-}
+// The next 624 state words.  new[k] needs old[k], old[k + 1] and old[k + 397] -- or, from k = 227 on, new[k - 227]: three
+// sweeps of at most 227 words, each waiting for the one before.  But the word a sweep waits for is the one the SAME
+// lane made in the sweep before (k - 227 is its word there), so a lane makes the chains new[t], new[227 + t], new[454 + t]
+// of four t = 64 s + lane out of registers, from words of the OLD state that it reads all at once -- indices clamped,
+// no read behind a condition on the lane (the compiler would put the wait in front of it): one round trip to LDS per
+// block instead of twelve, 288 instead of 375 instructions per block in the producer wave.  (new[623] needs new[0]:
+// every lane makes that one too.)  All reads precede all writes: in place.
 template <class W>
 MCQ_HD void mcq_mt_regenerate(W &w) {
-    mcq_mt_regen_sweep(w, 0u, 227u);
-    mcq_mt_regen_sweep(w, 227u, 454u);
-    mcq_mt_regen_sweep(w, 454u, 623u);
+    MCQ_PL(uint32_t, nA)[4];
+    MCQ_PL(uint32_t, nB)[4];
+    MCQ_PL(uint32_t, nC)[4];
     MCQ_FOR_LANES(l) {
-        if (l == 0) w.mt[623] = w.mt[396] ^ mcq_mt_twist(w.mt[623], w.mt[0]);
+        const uint32_t z = w.mt[MCQ_MT_M] ^ mcq_mt_twist(w.mt[0], w.mt[1]); /* the new word 0 */
+#pragma unroll
+        for (uint32_t s = 0; s < 4u; s++) {
+            const uint32_t t0 = 64u * s + l, t = t0 < 226u ? t0 : 226u, tc = t < 169u ? t : 169u;
+            const uint32_t a0 = w.mt[t], a1 = w.mt[t + 1u], f = w.mt[t + MCQ_MT_M], b0 = w.mt[227u + t], b1 = w.mt[228u + t];
+            const uint32_t c0 = w.mt[454u + tc], c1o = w.mt[455u + tc]; /* (tc = 169: the padding behind the state) */
+            const uint32_t c1 = t == 169u ? z : c1o;
+            MCQ_L(nA)[s] = f ^ mcq_mt_twist(a0, a1);
+            MCQ_L(nB)[s] = MCQ_L(nA)[s] ^ mcq_mt_twist(b0, b1);
+            MCQ_L(nC)[s] = MCQ_L(nB)[s] ^ mcq_mt_twist(c0, c1);
+        }
+    }
+    MCQ_WAVE_SYNC();
+    MCQ_FOR_LANES(l) {
+#pragma unroll
+        for (uint32_t s = 0; s < 4u; s++) {
+            const uint32_t t = 64u * s + l;
+            if (t < 227u) {
+                w.mt[t] = MCQ_L(nA)[s];
+                w.mt[227u + t] = MCQ_L(nB)[s];
+            }
+            if (t < 170u) w.mt[454u + t] = MCQ_L(nC)[s];
+        }
     }
     MCQ_WAVE_SYNC();
 }
