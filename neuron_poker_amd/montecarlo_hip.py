@@ -244,22 +244,37 @@ def get_equity(player_cards, table_cards, players, runs):
     return (out[2] + out[3]) / out[0]
 
 
-def get_equity_batch(hole, board, n_players, runs, seed=None, first_query_id=0, mode=None, engine=None):
+_MULTI = {}   # n_gpus -> MultiEngine over devices 0 .. n_gpus - 1 (made at first use, kept)
+
+
+def get_equity_batch(hole, board, n_players, runs, seed=None, first_query_id=0, mode=None, engine=None, n_gpus=None):
     """Many states in one launch.
 
     hole [B,2] u8 card ids, board [B,5] u8 (0xFF = empty), n_players scalar or [B], runs scalar or [B].
     -> (equity[B] float64, tallies[B,13] uint64) with tally columns runs, passes, win, tie, by_type[9].
     Query i gets query id first_query_id + i: splitting a batch keeps every per-query tally identical.
+    n_gpus > 1: the batch is sharded over the first n_gpus devices of the node by the library's
+    multi-GPU entry (mcq_multi_*: one all-reduce of the integer tallies; production mode only) -- the tallies are
+    the same integers as on one GPU.
     """
     q = _lib.pack_queries(hole, board, n_players, runs)
-    eng = engine or _lib.default_engine()
     m = _state["mode"] if mode is None else _MODES[mode]
     if seed is None:
         s, base = _take_ids(len(q))
         first_query_id = base + first_query_id
     else:
         s = int(seed)
-    res = eng.eval_batch(q, s, first_query_id=first_query_id, mode=m)
+    if n_gpus is not None and int(n_gpus) > 1:
+        if m != _lib.MODE_PHILOX or engine is not None:
+            raise ValueError("n_gpus > 1: production mode on the library's own contexts only")
+        with _lock:
+            me = _MULTI.get(int(n_gpus))
+            if me is None:
+                me = _MULTI[int(n_gpus)] = _lib.MultiEngine(list(range(int(n_gpus))))
+        res = me.eval_batch(q, s, first_query_id=first_query_id)
+    else:
+        eng = engine or _lib.default_engine()
+        res = eng.eval_batch(q, s, first_query_id=first_query_id, mode=m)
     tallies = res.view(np.uint64).reshape(len(q), 13)
     runs_f = np.maximum(tallies[:, 0], 1).astype(np.float64)
     equity = (tallies[:, 2] + tallies[:, 3]).astype(np.float64) / runs_f

@@ -972,6 +972,23 @@ def test_multi_gpu_device_entry_equals_single_context(eng):
             me.close()
 
 
+def test_get_equity_batch_over_several_gpus(eng):
+    """the batched call of the shim with n_gpus=: the library's multi-GPU entry behind it, the same integers
+    as on one GPU.  (Needs two devices; on a one-GPU box the argument is only checked.)"""
+    with pytest.raises(ValueError):
+        mh.get_equity_batch([[51, 47]], [[255] * 5], 2, 100, seed=1, mode="replay", n_gpus=2)
+    n_dev = npa.load_library().mcq_device_count()
+    if n_dev < 2:
+        pytest.skip("one device")
+    g = np.random.default_rng(3)
+    cards = np.array([g.permutation(52)[:7] for _ in range(600)], np.uint8)
+    board = np.full((600, 5), 255, np.uint8)
+    board[::2, :3] = cards[::2, 2:5]
+    one = mh.get_equity_batch(cards[:, :2], board, 6, 3000, seed=9, engine=eng)[1]
+    many = mh.get_equity_batch(cards[:, :2], board, 6, 3000, seed=9, n_gpus=n_dev)[1]
+    assert np.array_equal(one, many)
+
+
 def test_multi_gpu_entry_partitions_equal_single_context(eng):
     """mcq_multi_eval_batch (include/mcq.h): shards + one ncclAllReduce.  Whatever the partition -- blocks of
     queries, shares of every query's iterations, more shards than queries, one shard -- the tallies are those of
