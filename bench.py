@@ -108,11 +108,28 @@ def make_states(n_states, rank):
     return hole, board
 
 
+def make_configs3_states():
+    """BASELINE configs[3] / SURVEY 8d config 4: 65 536 states, default_rng(65536), flop (even i) / turn (odd i) tables,
+    -> (hole [B,2], board [B,5] with 0xFF = empty)."""
+    g3 = np.random.default_rng(65536)
+    keys = g3.random((65536, 52)).argsort(axis=1)[:, :6].astype(np.uint8)   # 6 distinct cards per state
+    b3 = np.full((65536, 5), 255, np.uint8)
+    b3[:, :3] = keys[:, 2:5]
+    b3[1::2, 3] = keys[1::2, 5]
+    return keys[:, :2].copy(), b3
+
+
+CONFIGS3 = {"states": 65536, "players": 6, "iters": 20000}
+METRIC = "Monte Carlo hand evals/sec @100k iters, 6-max preflop"
+METRIC_CONFIGS3 = ("Monte Carlo hand evals/sec, BASELINE configs[3]: 65 536 mixed flop/turn states x 6 players x 20k iters, "
+                   "sharded over the GPUs, one tally all-reduce")
+
+
 def cpu_baseline(n_players, runs, seconds=12.0, threads=None):
     """Time the oracle (kind 'port') on this host's cores on a bounded sample of the same workload."""
     from oracle import oracle as O
     cores = max(1, len(os.sched_getaffinity(0)))
-    threads = min(cores, 64) if threads is None else threads
+    threads = cores if threads is None else threads   # ALL the host's cores (SURVEY 8d); `cores` in the result says how many
     hole, board = make_states(threads, 0)
     probe = O.pack_queries(hole, board, n_players, 20000)
     t0 = time.perf_counter()
@@ -183,9 +200,15 @@ def native_multi(args):
         raise SystemExit("--gpus %d but %d devices visible" % (args.gpus, n_dev))
     me = npa.MultiEngine(devices)
     k = len(devices)
-    B, N, runs = args.states * k, args.players, args.iters
-    hole = np.concatenate([make_states(args.states, r)[0] for r in range(k)])
-    board = np.full((B, 5), 255, np.uint8)
+    configs3 = args.workload == "configs3"
+    N, runs = args.players, args.iters
+    if configs3:
+        hole, board = make_configs3_states()
+        B = len(hole)
+    else:
+        B = args.states * k
+        hole = np.concatenate([make_states(args.states, r)[0] for r in range(k)])
+        board = np.full((B, 5), 255, np.uint8)
     raw = npa.pack_queries(hole, board, N, runs).view(np.uint8).reshape(B, 16)
     d_q = [torch.from_numpy(raw[B * s // k:B * (s + 1) // k].copy()).to("cuda:%d" % d) for s, d in enumerate(devices)]
     d_res = [torch.zeros((B, 13), dtype=torch.int64, device="cuda:%d" % d) for d in devices]
@@ -215,24 +238,29 @@ def native_multi(args):
     info = me.info
     kernel_ms = float(np.mean(kmax))
     pc, fresh = profile_counters()
-    if pc and pc.get("workload") != {"states": args.states, "iters": runs, "players": N}:
+    if configs3 or (pc and pc.get("workload") != {"states": args.states, "iters": runs, "players": N}):
         pc = None
+    per_it = 0.5 * (alg_ops_per_iteration(N, 3) + alg_ops_per_iteration(N, 4)) if configs3 else alg_ops_per_iteration(N, 0)
     roof = issue_roofline("mcq_eval_kernel<0, false>", kernel_ms, pc, fresh,
-                          model_ops_per_launch=float(args.states) * runs * alg_ops_per_iteration(N, 0),
-                          model_basis="SURVEY 8(d): %d lane-ops per iteration" % alg_ops_per_iteration(N, 0))
+                          model_ops_per_launch=float(B) / k * runs * per_it,
+                          model_basis="SURVEY 8(d): %d lane-ops per iteration" % per_it)
     roof["traffic"] = pc.get("hbm_bytes_per_launch") if pc else None
     roof["note"] = "per shard: the slowest shard's evaluation kernel"
+    import hashlib
+    what = ("BASELINE configs[3]: 65 536 flop/turn states (default_rng(65536)) IN ALL" if configs3
+            else "%d random preflop states per GPU" % args.states)
     print(json.dumps({
-        "metric": "Monte Carlo hand evals/sec @100k iters, 6-max preflop", "value": evals * args.steps / elapsed,
+        "metric": METRIC_CONFIGS3 if configs3 else METRIC, "value": evals * args.steps / elapsed,
         "unit": "hand-evals/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u32", "data": "synthetic",
-        "config": {"workload": "%d random preflop states per GPU x %d players x %d iterations, ONE process, %d shards on "
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong" if configs3 else "weak",
+        "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": "%s x %d players x %d iterations, ONE process, %d shards on "
                                "devices %s via mcq_multi_eval_batch_device (queries and tallies resident in HBM), partition "
                                "'%s', one ncclAllReduce of the [%d,13] uint64 tally matrix over %d device(s)" %
-                               (args.states, N, runs, info["shards"], devices, info["last_partition"], B, info["devices"]),
-                   "states_per_gpu": args.states, "n_players": N, "iterations": runs, "n_board": 0,
-                   "hand_evals_per_step": evals},
+                               (what, N, runs, info["shards"], devices, info["last_partition"], B, info["devices"]),
+                   "states_per_gpu": B // k, "states_total": B, "n_players": N, "iterations": runs,
+                   "n_board": "3 / 4 alternating" if configs3 else 0, "hand_evals_per_step": evals},
+        "tallies_sha256": hashlib.sha256(np.ascontiguousarray(t).tobytes()).hexdigest(),
         "roofline": roof,
         "collective": {"all_reduce_ms": float(np.mean(ar)), "bytes": B * 104, "ranks": info["devices"],
                        "rccl_version": info["rccl_version"]},
@@ -255,9 +283,15 @@ def main():
     ap.add_argument("--native-multi", action="store_true", help="ONE process drives all --gpus devices through the C ABI's "
                     "mcq_multi_* entry (shards + one ncclAllReduce from ncclCommInitAll) instead of one rank per GPU; "
                     "host buffers, so the figure includes PCIe")
+    ap.add_argument("--workload", default="headline", choices=["headline", "configs3"],
+                    help="headline: --states preflop states PER GPU x 6 players x 100k iterations (weak scaling). configs3: "
+                         "BASELINE configs[3], 65 536 flop/turn states x 6 players x 20k iterations IN ALL, block-sharded over "
+                         "the --gpus ranks (strong scaling), one all-reduce of the [65536,13] tally matrix")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
+    if args.workload == "configs3":
+        args.players, args.iters = CONFIGS3["players"], CONFIGS3["iters"]
 
     under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if args.native_multi or under_launcher or args.gpus == 1:
@@ -300,19 +334,29 @@ def main():
             dist.init_process_group(args.backend)
 
     eng = npa.Engine(local_rank, kernel_times=True)
-    B, N, runs = args.states, args.players, args.iters
-    hole, board = make_states(B, rank)
+    N, runs = args.players, args.iters
+    configs3 = args.workload == "configs3"
+    if configs3:   # a fixed batch, block-distributed (queries [n*r/k, n*(r+1)/k) to rank r, ids = global index)
+        total = CONFIGS3["states"]
+        hole_all, board_all = make_configs3_states()
+        first_qid, hi_q = total * rank // world, total * (rank + 1) // world
+        hole, board = hole_all[first_qid:hi_q], board_all[first_qid:hi_q]
+    else:          # --states per rank, every rank its own generator (weak scaling)
+        total = world * args.states
+        first_qid = rank * args.states
+        hole, board = make_states(args.states, rank)
+    B = len(hole)   # this rank's queries
     q = npa.pack_queries(hole, board, N, runs)
     d_q = torch.from_numpy(q.view(np.uint8).reshape(B, 16).copy()).to(dev)
-    tallies = torch.zeros((world * B, 13), dtype=torch.int64, device=dev)  # mcq_result rows of the whole job
-    mine = tallies[rank * B:(rank + 1) * B]
+    tallies = torch.zeros((total, 13), dtype=torch.int64, device=dev)  # mcq_result rows of the whole job
+    mine = tallies[first_qid:first_qid + B]
     stream = torch.cuda.current_stream()
     seed = 20261004
 
     def step(i):
         if grouped:
             tallies.zero_()
-        eng.eval_batch_device(d_q.data_ptr(), B, seed + i, mine.data_ptr(), first_query_id=rank * B,
+        eng.eval_batch_device(d_q.data_ptr(), B, seed + i, mine.data_ptr(), first_query_id=first_qid,
                               stream=stream.cuda_stream)
         if grouped:
             if args.backend == "nccl":
@@ -357,7 +401,7 @@ def main():
         ar_ms = e0.elapsed_time(e1) / 5
     kt = eng.kernel_times(min(args.steps, 64))  # HIP events on the launch stream, recorded inside the timed region
     kernel_ms = float(np.mean(kt)) if len(kt) else float("nan")
-    evals_per_step = float(world) * B * runs * N
+    evals_per_step = float(total) * runs * N
     value = evals_per_step * args.steps / elapsed
 
     if rank != 0:
@@ -366,33 +410,50 @@ def main():
 
     # counter-based figures: from the committed PMC passes of exactly this workload (kernel time is measured live)
     pc, fresh = profile_counters()
-    if pc and pc.get("workload") != {"states": B, "iters": runs, "players": N}:
-        pc = None
-    roof = issue_roofline("mcq_eval_kernel<0, false>", kernel_ms, pc, fresh,
-                          model_ops_per_launch=float(B) * runs * alg_ops_per_iteration(N, 0),
-                          model_basis="SURVEY 8(d): A(N,b) = 48 D + 30 + 82 N = %d lane-ops per iteration" %
-                                      alg_ops_per_iteration(N, 0))
+    if configs3:   # counters of this workload: profiles/current.json -> "configs3" (tools/profile.sh), for the whole batch on ONE GPU
+        pc = (pc or {}).get("configs3")
+        if pc and world != 1:
+            pc = None
+        model_ops = float(B) * runs * 0.5 * (alg_ops_per_iteration(N, 3) + alg_ops_per_iteration(N, 4))
+        model_basis = "SURVEY 8(d): A(6,3) = %d / A(6,4) = %d lane-ops per iteration" % (alg_ops_per_iteration(N, 3),
+                                                                                         alg_ops_per_iteration(N, 4))
+    else:
+        if pc and pc.get("workload") != {"states": B, "iters": runs, "players": N}:
+            pc = None
+        model_ops = float(B) * runs * alg_ops_per_iteration(N, 0)
+        model_basis = "SURVEY 8(d): A(N,b) = 48 D + 30 + 82 N = %d lane-ops per iteration" % alg_ops_per_iteration(N, 0)
+    roof = issue_roofline("mcq_eval_kernel<0, false>", kernel_ms, pc, fresh, model_ops_per_launch=model_ops,
+                          model_basis=model_basis)
     roof["traffic"] = pc.get("hbm_bytes_per_launch") if pc else None
     roof["hbm"] = {"algorithmic_bytes_per_launch": B * 120, "achieved_GBps": B * 120 / (kernel_ms * 1e-3) / 1e9,
                    "peak_GBps": HBM_PEAK_GBPS}
+    ar_text = (", one %s all-reduce of the [%d,13] int64 tally matrix per step" %
+               ("RCCL" if args.backend == "nccl" else args.backend, total)) if grouped else ""
+    if configs3:
+        workload = ("BASELINE configs[3]: 65 536 states (default_rng(65536)), flop / turn tables alternating, x %d players x %d "
+                    "iterations IN ALL, block-sharded over %d rank(s) (queries [n*r/k, n*(r+1)/k) on rank r under their global "
+                    "ids), production RNG (MCQ-CTR v5), queries and tallies resident in HBM%s" % (N, runs, world, ar_text))
+    else:
+        workload = ("%d random preflop states per GPU (default_rng(4096+rank), as BASELINE configs[2]) x %d players x %d "
+                    "iterations, production RNG (Philox-keyed MWC64X, MCQ-CTR v5), queries and tallies resident in HBM%s" %
+                    (B, N, runs, ar_text))
     out = {
-        "metric": "Monte Carlo hand evals/sec @100k iters, 6-max preflop", "value": value, "unit": "hand-evals/s",
+        "metric": METRIC_CONFIGS3 if configs3 else METRIC, "value": value, "unit": "hand-evals/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-        "config": {"workload": "%d random preflop states per GPU (default_rng(4096+rank), as BASELINE configs[2]) x "
-                               "%d players x %d iterations, production RNG (Philox-keyed MWC64X, MCQ-CTR v5), queries and "
-                               "tallies resident in HBM%s" %
-                               (B, N, runs, ", one %s all-reduce of the [%d,13] int64 tally matrix per step" %
-                                ("RCCL" if args.backend == "nccl" else args.backend, world * B) if grouped else ""),
-                   "states_per_gpu": B, "n_players": N, "iterations": runs, "n_board": 0,
-                   "hand_evals_per_step": evals_per_step},
+        "higher_is_better": True, "scaling": "strong" if configs3 else "weak", "vs_baseline": None, "dtype": "u32",
+        "data": "synthetic",
+        "config": {"workload": workload, "states_per_gpu": B, "states_total": total, "n_players": N, "iterations": runs,
+                   "n_board": "3 / 4 alternating" if configs3 else 0, "hand_evals_per_step": evals_per_step},
         "roofline": roof,
     }
+    if configs3:   # a checksum of the whole tally matrix: equal for every --gpus (the tallies do not depend on the partition)
+        import hashlib
+        out["tallies_sha256"] = hashlib.sha256(np.ascontiguousarray(t).tobytes()).hexdigest()
     if grouped:
-        out["collective"] = {"all_reduce_ms": ar_ms, "bytes": world * B * 104, "ranks": world,
+        out["collective"] = {"all_reduce_ms": ar_ms, "bytes": total * 104, "ranks": world,
                              "backend": "RCCL (torch.distributed nccl)" if args.backend == "nccl" else args.backend}
     side_counters = (profile_counters()[0] or {}).get("side_kernels", {})  # PMC passes of tools/side_kernels.py's workloads
-    if world == 1 and not args.no_extras:  # single-GPU side measurements; never delay the other ranks' teardown
+    if world == 1 and not args.no_extras and not configs3:  # single-GPU side measurements; never delay the other ranks' teardown
         extras = {}
 
         def side_measurements():  # a failure here must never cost the headline line
@@ -540,12 +601,8 @@ def main():
                                                             "hand_evals_per_s": 4 * 1000 / dt}
             # BASELINE configs[3] (the 8-GPU config) on this one GPU: 65 536 states, flop / turn tables alternating, 6 players,
             # 20k iterations, host buffers; one rank of 8 would take an eighth of the queries
-            g3 = np.random.default_rng(65536)
-            keys = g3.random((65536, 52)).argsort(axis=1)[:, :6].astype(np.uint8)   # 6 distinct cards per state
-            b3 = np.full((65536, 5), 255, np.uint8)
-            b3[:, :3] = keys[:, 2:5]
-            b3[1::2, 3] = keys[1::2, 5]
-            q4 = npa.pack_queries(keys[:, :2], b3, 6, 20000)
+            h3, b3 = make_configs3_states()
+            q4 = npa.pack_queries(h3, b3, 6, 20000)
             eng.eval_batch(q4, seed=1)  # warm-up at full size: the pinned staging buffers grow once
             t1 = time.perf_counter()
             eng.eval_batch(q4, seed=2)
@@ -652,11 +709,11 @@ def main():
             exp = np.zeros((len(rows), 13), np.uint64)
             import concurrent.futures as cf
             with cf.ThreadPoolExecutor(threads) as ex:  # one oracle call per row: the row's own query id keys its streams
-                futs = {ex.submit(O.run_batch, O.MODE_CTR, raw[r:r + 1], last_seed, rank * B + int(r)): k
+                futs = {ex.submit(O.run_batch, O.MODE_CTR, raw[r:r + 1], last_seed, first_qid + int(r)): k
                         for k, r in enumerate(rows)}
                 for f, k in futs.items():
                     exp[k] = f.result()[0]
-            got = t[rows]
+            got = t[first_qid + rows]
             equal = bool(np.array_equal(got, exp))
             if not equal:
                 first_bad = int(rows[np.nonzero((got != exp).any(1))[0][0]])

@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 #define MCQ_VERSION_MAJOR 0
-#define MCQ_VERSION_MINOR 2
+#define MCQ_VERSION_MINOR 3
 #define MCQ_VERSION_PATCH 0
 
 /* error codes */
@@ -39,6 +39,7 @@ extern "C" {
 #define MCQ_EINVAL (-1)  /* bad argument: card out of range, duplicate card, n_players not in [1,10], ... */
 #define MCQ_EDEVICE (-2) /* HIP runtime failure; mcq_last_error() carries the HIP error string */
 #define MCQ_ENOMEM (-3)  /* host or device allocation failed */
+#define MCQ_EBUSY (-4)   /* another call is running on this context (or mcq_multi object): one call in flight per context */
 
 /* random-number front ends (the deal -> evaluate -> tally body is shared) */
 #define MCQ_MODE_PHILOX 0         /* production: counter-based streams, Philox4x32-10 keyed MWC64X (MCQ-CTR v5) */
@@ -108,7 +109,9 @@ MCQ_API int mcq_device_count(void);
 
 /* Create an engine bound to HIP device `device` (one context per GPU / per process rank).  Owns its stream,
  * device and pinned staging buffers and lookup tables until mcq_destroy.  Not re-entrant: one call in flight
- * per context.  Returns NULL on failure (see mcq_last_error). flags must be 0. */
+ * per context -- create one per thread (they are cheap: a stream, a table image, staging buffers that grow on demand).
+ * The library checks it: an entry point called while another call is running on the same context returns MCQ_EBUSY
+ * and touches nothing.  Returns NULL on failure (see mcq_last_error). flags must be 0. */
 MCQ_API mcq_ctx *mcq_create(int device, int flags);
 MCQ_API void mcq_destroy(mcq_ctx *ctx);
 

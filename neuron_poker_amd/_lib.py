@@ -14,7 +14,7 @@ import numpy as np
 
 MODE_PHILOX = 0
 MODE_REPLAY_MT19937 = 1
-MCQ_EINVAL, MCQ_EDEVICE, MCQ_ENOMEM = -1, -2, -3
+MCQ_EINVAL, MCQ_EDEVICE, MCQ_ENOMEM, MCQ_EBUSY = -1, -2, -3, -4
 
 QUERY_DTYPE = np.dtype([("hole", "u1", (2,)), ("board", "u1", (5,)), ("n_board", "u1"), ("n_players", "u1"),
                         ("reserved", "u1", (3,)), ("runs", "<u4")])
@@ -39,6 +39,11 @@ _lock = threading.Lock()
 
 class McqError(RuntimeError):
     """HIP / allocation failure reported by libmcq_hip.so (MCQ_EDEVICE, MCQ_ENOMEM)."""
+
+
+class McqBusyError(McqError):
+    """MCQ_EBUSY: a second call on a context (Engine / MultiEngine) while one is running on it -- a context allows ONE
+    call in flight; use one Engine per thread (default_engine() does)."""
 
 
 def library_path():
@@ -149,6 +154,8 @@ def _raise(rc):
     msg = (load_library().mcq_last_error() or b"").decode("utf-8", "replace")
     if rc == MCQ_EINVAL:
         raise ValueError(msg)
+    if rc == MCQ_EBUSY:
+        raise McqBusyError(msg)
     raise McqError("libmcq_hip error %d: %s" % (rc, msg))
 
 
@@ -244,7 +251,8 @@ def pack_query_ext(n, ghost=None, known2=None, hero_range=None, opp_range=None, 
 
 
 class Engine:
-    """One mcq_ctx: an equity engine bound to one GPU.  Not re-entrant (one call in flight per engine)."""
+    """One mcq_ctx: an equity engine bound to one GPU.  Not re-entrant: one call in flight per engine -- a second thread
+    calling into the same Engine meanwhile gets McqBusyError (the library checks).  One Engine per thread."""
 
     def __init__(self, device=0, kernel_times=False):
         self._lib = load_library()
@@ -412,6 +420,7 @@ class MultiEngine:
             msg = (self._lib.mcq_last_error() or b"").decode("utf-8", "replace")
             raise McqError("mcq_multi_create(%s) failed: %s" % ([int(d) for d in devs], msg))
         self.devices = [int(d) for d in devs]
+        self.lock = threading.Lock()   # the shim's shared MultiEngines serialise their callers on it
 
     def close(self):
         if getattr(self, "_m", None):
@@ -558,17 +567,46 @@ class Tables:
         return d
 
 
-_default = None
+_tls = threading.local()      # .engine: the calling thread's default engine
+_default_law = "reference"    # dealing law of the default engines (montecarlo_hip.configure(dealing=...))
+_default_engines = []         # weak references to every live default engine, for set_default_dealing_law
 
 
 def default_engine():
-    """Process-wide engine on device $MCQ_DEVICE (else $LOCAL_RANK, else 0), created on first use."""
-    global _default
-    if _default is None:
+    """The calling THREAD's engine on device $MCQ_DEVICE (else $LOCAL_RANK, else 0), created at the thread's first use.
+    A context allows one call in flight (include/mcq.h), and ctypes drops the GIL for the duration of a call, so threads
+    must not share one: every thread gets its own (own stream, own staging buffers), freed when the thread ends."""
+    eng = getattr(_tls, "engine", None)
+    if eng is None:
         dev = int(os.environ.get("MCQ_DEVICE", os.environ.get("LOCAL_RANK", "0")))
         n = load_library().mcq_device_count()
         if n <= 0:
             raise McqError("no HIP device visible: neuron_poker_amd needs an AMD GPU (no CPU fallback). " +
                            (load_library().mcq_last_error() or b"").decode("utf-8", "replace"))
-        _default = Engine(dev % n)
-    return _default
+        eng = Engine(dev % n)
+        import weakref
+        with _lock:
+            if _default_law != "reference":
+                eng.set_dealing_law(_default_law)
+            _default_engines[:] = [r for r in _default_engines if r() is not None]
+            _default_engines.append(weakref.ref(eng))
+        _tls.engine = eng
+    return eng
+
+
+def default_dealing_law():
+    return _default_law
+
+
+def set_default_dealing_law(law):
+    """Dealing law of every thread's default engine, present and future.  Call it while no equity call is running on
+    them (an engine in the middle of a call answers McqBusyError)."""
+    global _default_law
+    if law not in ("reference", "uniform"):
+        raise ValueError("law must be 'reference' or 'uniform'")
+    with _lock:
+        _default_law = law
+        for r in _default_engines:
+            e = r()
+            if e is not None and getattr(e, "_ctx", None):
+                e.set_dealing_law(law)

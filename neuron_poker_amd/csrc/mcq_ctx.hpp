@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/mcq.h"
+#include "mcq_busy.hpp"
 #include "mcq_internal.hpp"
 #include "mcq_layout.hpp"
 
@@ -33,6 +34,12 @@ int mcq_fail(int code, const char *what, const char *detail = nullptr);
     catch (const std::bad_alloc &) { return mcq_fail(MCQ_ENOMEM, who, "out of host memory"); } \
     catch (const std::exception &ex) { return mcq_fail(MCQ_EDEVICE, who, ex.what()); }         \
     catch (...) { return mcq_fail(MCQ_EDEVICE, who, "unexpected exception"); }
+
+/* Public entry points that take a context come in through this (after their null check): a second caller while a call
+ * is running on the context is turned away. */
+#define MCQ_ENTER(c, who)                      \
+    McqBusyScope busy_(&(c)->busy);            \
+    if (!busy_.ok) return mcq_fail(MCQ_EBUSY, who, MCQ_BUSY_MESSAGE)
 
 /* Entry points select the context's device and leave the caller's current device as they found it (a host
  * application -- or torch -- keeps its own notion of "current device"). */
@@ -101,6 +108,7 @@ struct PinBuf {
 };
 
 struct mcq_ctx {
+    McqBusyFlag busy; /* one call in flight per context: see MCQ_ENTER */
     int device = 0;
     int n_cu = 0;
     int occ[3] = {1, 1, 1}; /* resident kBlock-thread blocks per CU of the eval kernels (by internal mode) */

@@ -192,7 +192,7 @@ inline uint32_t tasks_of(const mcq_query &q) { return mcq_tasks_of(q); }
 inline int validate(const mcq_query *q, size_t n) { return mcq_validate_queries(q, n); }
 }  // namespace
 
-extern "C" int mcq_kernel_times(mcq_ctx *c, float *ms, int max_n);
+static int kernel_times_impl(mcq_ctx *c, float *ms, int max_n);
 
 namespace {
 
@@ -296,7 +296,7 @@ int replay_batch_device(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed,
     const int launched = (int)(c->n_timed - timed0);
     if (launched > 0 && launched <= mcq_ctx::kRing) {
         float ms[mcq_ctx::kRing];
-        if (mcq_kernel_times(c, ms, launched) == launched)
+        if (kernel_times_impl(c, ms, launched) == launched)
             for (int i = 0; i < launched; i++) total += ms[i];
     }
     c->last_ms = total;
@@ -345,7 +345,7 @@ int replay_batch(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed, uint64
         if (rc) return rc;
         HIP_TRY(hipStreamSynchronize(c->stream)); /* staging buffers are reused by the next chunk */
         float ms = 0.f;
-        if (c->timing && mcq_kernel_times(c, &ms, 1) == 1) replay_ms += ms;
+        if (c->timing && kernel_times_impl(c, &ms, 1) == 1) replay_ms += ms;
         a = b;
     }
     HIP_TRY(hipMemcpyAsync(c->h_res.p, c->d_res.p, n * sizeof(mcq_result), hipMemcpyDeviceToHost, c->stream));
@@ -526,6 +526,13 @@ mcq_ctx *mcq_create(int device, int flags) {
 
 int mcq_kernel_times(mcq_ctx *c, float *ms, int max_n) {
     if (!c || !ms || max_n < 0) return mcq_fail(MCQ_EINVAL, "mcq_kernel_times: bad argument");
+    MCQ_ENTER(c, "mcq_kernel_times");
+    return kernel_times_impl(c, ms, max_n);
+}
+
+}  // extern "C"
+
+static int kernel_times_impl(mcq_ctx *c, float *ms, int max_n) {
     uint64_t have = c->n_timed < (uint64_t)mcq_ctx::kRing ? c->n_timed : (uint64_t)mcq_ctx::kRing;
     int n = (int)(have < (uint64_t)max_n ? have : (uint64_t)max_n);
     McqDeviceScope dev_(c->device);
@@ -539,14 +546,18 @@ int mcq_kernel_times(mcq_ctx *c, float *ms, int max_n) {
     return n;
 }
 
+extern "C" {
+
 int mcq_set_kernel_timing(mcq_ctx *c, int on) {
     if (!c) return mcq_fail(MCQ_EINVAL, "mcq_set_kernel_timing: null context");
+    MCQ_ENTER(c, "mcq_set_kernel_timing");
     c->timing = on != 0;
     return MCQ_OK;
 }
 
 int mcq_set_dealing_law(mcq_ctx *c, int law) {
     if (!c || (law != MCQ_LAW_REFERENCE && law != MCQ_LAW_UNIFORM)) return mcq_fail(MCQ_EINVAL, "mcq_set_dealing_law: bad argument");
+    MCQ_ENTER(c, "mcq_set_dealing_law");
     c->law = law;
     return MCQ_OK;
 }
@@ -554,9 +565,11 @@ int mcq_set_dealing_law(mcq_ctx *c, int law) {
 float mcq_last_kernel_ms(mcq_ctx *c) {
     float ms = 0.f;
     if (!c) return 0.f;
+    McqBusyScope busy_(&c->busy);
+    if (!busy_.ok) return 0.f; /* a call is running on the context: no time to report yet */
     if (c->last_ms > 0.f) return c->last_ms;
     if (!c->timing) return 0.f;
-    return mcq_kernel_times(c, &ms, 1) == 1 ? ms : 0.f;
+    return kernel_times_impl(c, &ms, 1) == 1 ? ms : 0.f;
 }
 
 int mcq_eval_batch_device(mcq_ctx *c, const void *d_queries, size_t n, uint64_t seed, uint64_t first_query_id,
@@ -566,6 +579,7 @@ int mcq_eval_batch_device(mcq_ctx *c, const void *d_queries, size_t n, uint64_t 
     if (n == 0) return MCQ_OK;
     if (!d_queries || !d_results) return mcq_fail(MCQ_EINVAL, "mcq_eval_batch_device: null buffer");
     if (n > 0x7fffffffu) return mcq_fail(MCQ_EINVAL, "mcq_eval_batch_device: n too large");
+    MCQ_ENTER(c, "mcq_eval_batch_device");
     McqDeviceScope dev_(c->device);
     HIP_TRY(dev_.err);
     hipStream_t s = (hipStream_t)hip_stream; /* NULL = the HIP null stream */
@@ -587,6 +601,7 @@ int mcq_eval_batch_device_small(mcq_ctx *c, const void *d_queries, size_t n, uin
     if (n == 0) return MCQ_OK;
     if (!d_queries || !d_results) return mcq_fail(MCQ_EINVAL, "mcq_eval_batch_device_small: null buffer");
     if (n >= (1u << 24)) return mcq_fail(MCQ_EINVAL, "mcq_eval_batch_device_small: n too large");
+    MCQ_ENTER(c, "mcq_eval_batch_device_small");
     McqDeviceScope dev_(c->device);
     HIP_TRY(dev_.err);
     hipStream_t s = (hipStream_t)hip_stream;
@@ -786,7 +801,7 @@ static int eval_host_philox(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t s
                 return std::chrono::duration<double, std::micro>(b - a).count();
             };
             float kms = 0.f;
-            if (timed) (void)mcq_kernel_times(c, &kms, 1);
+            if (timed) (void)kernel_times_impl(c, &kms, 1);
             fprintf(stderr, "mcq direct n=%zu waves=%llu grid=%u rounds=%u: launch %.1f us, wait %.1f us (%s), copy out %.1f us, "
                     "kernel %.1f us\n", n, (unsigned long long)lay.waves, grid, rounds, us(t0, t1), us(t1, t2),
                     seen ? "flag" : "stream sync", us(t2, std::chrono::steady_clock::now()), 1e3 * kms);
@@ -822,7 +837,7 @@ static int eval_host_philox(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t s
         HIP_TRY(hipMemsetAsync(c->d_res.p, 0, r_pad, c->stream)); /* not waited for: the next call finds its rows zero */
     }
     c->res_clean = r_pad;
-    if (!total_tasks || !c->timing || mcq_kernel_times(c, &c->last_ms, 1) != 1) c->last_ms = 0.f;
+    if (!total_tasks || !c->timing || kernel_times_impl(c, &c->last_ms, 1) != 1) c->last_ms = 0.f;
     memcpy(out, c->h_res.p, r_bytes);
     for (size_t i = 0; i < n; i++) out[i].runs = mcq_part(tasks_of(q[i]), q[i].runs, part, n_parts).runs;
     return MCQ_OK;
@@ -836,6 +851,7 @@ static int eval_batch_impl(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t se
         return mcq_fail(MCQ_EINVAL, who, "only MCQ_MODE_PHILOX can split the iterations of a query");
     if (n == 0) return MCQ_OK;
     if (!c) return mcq_fail(MCQ_EINVAL, who, "null context");
+    MCQ_ENTER(c, who);
     McqDeviceScope dev_(c->device);
     HIP_TRY(dev_.err);
     if (mode == MCQ_MODE_PHILOX) return eval_host_philox(c, q, n, seed, first_query_id, part, n_parts, out, who);
@@ -889,6 +905,7 @@ int mcq_eval_batch_ext(mcq_ctx *c, const mcq_query *q, const mcq_query_ext *ext,
         if (t > most_tasks) most_tasks = t;
     }
     if (total_tasks > 0xfffffff0ull) return mcq_fail(MCQ_EINVAL, "mcq_eval_batch_ext: too many iterations in one call");
+    MCQ_ENTER(c, "mcq_eval_batch_ext");
     McqDeviceScope dev_(c->device);
     HIP_TRY(dev_.err);
     HIP_TRY(c->h_res.reserve(n * sizeof(mcq_result)));
@@ -932,7 +949,7 @@ int mcq_eval_batch_ext(mcq_ctx *c, const mcq_query *q, const mcq_query_ext *ext,
         if (timed) c->n_timed++;
         rc = wait_ticket(c, ticket, nullptr);
         if (rc) return rc;
-        if (timed && mcq_kernel_times(c, &c->last_ms, 1) != 1) c->last_ms = 0.f;
+        if (timed && kernel_times_impl(c, &c->last_ms, 1) != 1) c->last_ms = 0.f;
         const uint64_t *hr = (const uint64_t *)c->h_res.p; /* one 13-word row per block */
         static_assert(sizeof(mcq_result) == 13 * sizeof(uint64_t), "result row");
         for (size_t i = 0; i < n; i++) {
@@ -1002,7 +1019,7 @@ int mcq_eval_batch_ext(mcq_ctx *c, const mcq_query *q, const mcq_query_ext *ext,
     if (c->timing) c->n_timed++;
     HIP_TRY(hipMemcpyAsync(c->h_res.p, c->d_res.p, n * sizeof(mcq_result), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (!c->timing || mcq_kernel_times(c, &c->last_ms, 1) != 1) c->last_ms = 0.f;
+    if (!c->timing || kernel_times_impl(c, &c->last_ms, 1) != 1) c->last_ms = 0.f;
     const mcq_result *hr = (const mcq_result *)c->h_res.p;
     for (size_t i = 0; i < n; i++)
         if (hr[i].runs != q[i].runs || hr[i].passes == ~0ull) /* (parity mode: the stream walk marks such a query) */
@@ -1018,6 +1035,7 @@ int mcq_eval_batch_numpy_stream(mcq_ctx *c, const mcq_query *q, size_t n, uint32
     if (n == 0) return MCQ_OK;
     if (!mt_key || !mt_pos || *mt_pos > 624) return mcq_fail(MCQ_EINVAL, "mcq_eval_batch_numpy_stream: bad MT19937 state");
     if (!c) return mcq_fail(MCQ_EINVAL, "mcq_eval_batch_numpy_stream: null context");
+    MCQ_ENTER(c, "mcq_eval_batch_numpy_stream");
     McqDeviceScope dev_(c->device);
     HIP_TRY(dev_.err);
     int rc = stage_queries(c, q, n, out, "mcq_eval_batch_numpy_stream");
@@ -1048,6 +1066,7 @@ int mcq_showdown(mcq_ctx *c, const uint8_t *hands, size_t n_tables, int n_player
     const size_t per_table = 7u * (size_t)n_players, nh = n_tables * (size_t)n_players;
     const size_t pad_tables = (n_tables + 255u) & ~(size_t)255u;
     const size_t in_bytes = pad_tables * per_table, key_bytes = keys ? pad_tables * n_players * sizeof(uint32_t) : 0;
+    MCQ_ENTER(c, "mcq_showdown");
     McqDeviceScope dev_(c->device);
     HIP_TRY(dev_.err);
     HIP_TRY(c->h_misc.reserve(in_bytes + 2 * pad_tables + key_bytes + 64));
@@ -1091,6 +1110,7 @@ int mcq_exact_batch(mcq_ctx *c, const mcq_query *q, size_t n, int law, mcq_resul
     for (size_t i = 0; i < n; i++)
         if (q[i].n_players > 3)
             return mcq_fail(MCQ_EINVAL, "mcq_exact_batch: exact enumeration covers 1 to 3 players");
+    MCQ_ENTER(c, "mcq_exact_batch");
     McqDeviceScope dev_(c->device);
     HIP_TRY(dev_.err);
     HIP_TRY(c->d_res.reserve(n * sizeof(mcq_result)));

@@ -129,6 +129,7 @@ struct Call { /* arguments of the call in flight, read by the workers */
 }  // namespace
 
 struct mcq_multi {
+    McqBusyFlag busy; /* one call in flight per object (the call state below is per call) */
     std::vector<Shard> shards;
     std::vector<int> devices;       /* distinct devices, in order of first appearance */
     std::vector<int> primary_shard; /* per distinct device */
@@ -425,6 +426,7 @@ int mcq_multi_eval_batch(mcq_multi *m, const mcq_query *q, size_t n, uint64_t se
     if (n == 0) return MCQ_OK;
     if (!q || !out) return mcq_fail(MCQ_EINVAL, "mcq_multi_eval_batch: null buffer");
     if (n > 0x7fffffffu) return mcq_fail(MCQ_EINVAL, "mcq_multi_eval_batch: n too large");
+    MCQ_ENTER(m, "mcq_multi_eval_batch");
     return multi_eval(m, q, n, seed, first_query_id, partition, out);
     ABI_GUARD_END("mcq_multi_eval_batch")
 }
@@ -445,6 +447,7 @@ int mcq_multi_eval_batch_device(mcq_multi *m, const void *const *d_queries, size
         if (!d_results[s] || (has_work && !d_queries[s]))
             return mcq_fail(MCQ_EINVAL, "mcq_multi_eval_batch_device: null device pointer of a shard");
     }
+    MCQ_ENTER(m, "mcq_multi_eval_batch_device");
     return multi_eval(m, nullptr, n, seed, first_query_id, partition, nullptr, d_queries, d_results);
     ABI_GUARD_END("mcq_multi_eval_batch_device")
 }
@@ -468,6 +471,7 @@ int mcq_multi_times(const mcq_multi *m, float ms[3]) {
 
 int mcq_multi_set_dealing_law(mcq_multi *m, int law) {
     if (!m) return mcq_fail(MCQ_EINVAL, "mcq_multi_set_dealing_law: null object");
+    MCQ_ENTER(m, "mcq_multi_set_dealing_law");
     for (Shard &sh : m->shards) {
         const int rc = mcq_set_dealing_law(sh.ctx, law);
         if (rc) return rc;

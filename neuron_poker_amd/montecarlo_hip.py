@@ -36,25 +36,38 @@ from .cards import TYPES, card_id
 
 __all__ = ["get_equity", "get_equity_batch", "get_equity_exact", "MonteCarlo", "seed", "configure"]
 
-_state = {"seed": int.from_bytes(os.urandom(8), "little"), "counter": 0, "couple_numpy": False,
+_state = {"couple_numpy": False,
           "mode": _lib.MODE_REPLAY_MT19937 if os.environ.get("MCQ_MODE", "philox").lower() == "replay"
           else _lib.MODE_PHILOX}
 _lock = threading.Lock()
+
+
+class _Stream(threading.local):
+    """(seed, query counter) of the calling THREAD: seed(s) in a thread makes that thread's calls reproducible whatever
+    other threads do meanwhile (every thread also has its own engine, _lib.default_engine()).  A thread that never
+    called seed() starts from the operating system's entropy."""
+
+    def __init__(self):
+        self.seed = int.from_bytes(os.urandom(8), "little")
+        self.counter = 0
+
+
+_stream = _Stream()
 _MODES = {"philox": _lib.MODE_PHILOX, "replay": _lib.MODE_REPLAY_MT19937,
           _lib.MODE_PHILOX: _lib.MODE_PHILOX, _lib.MODE_REPLAY_MT19937: _lib.MODE_REPLAY_MT19937}
 
 
 def seed(s):
-    """Counterpart of np.random.seed(s) for this module: the next call uses stream `s`."""
-    with _lock:
-        _state["seed"] = int(s) & (2 ** 64 - 1)
-        _state["counter"] = 0
+    """Counterpart of np.random.seed(s) for this module: the calling thread's next call uses stream `s`."""
+    _stream.seed = int(s) & (2 ** 64 - 1)
+    _stream.counter = 0
 
 
 def configure(mode=None, couple_numpy=None, dealing=None):
     """mode: 'philox' (default, production) or 'replay' (bit-exact MT19937 replay of the reference).
     dealing: 'reference' (default: the Python reference's law incl. its index bias) or 'uniform' (unbiased, what
-    the reference's Cython/C++ variants deal; production mode only) -- applied to the default engine.
+    the reference's Cython/C++ variants deal; production mode only) -- applied to every thread's default engine and
+    to the multi-GPU engines of get_equity_batch(n_gpus=...); call it while no equity call is running.
     couple_numpy=True (replay mode only): draw from numpy's GLOBAL random state and advance it exactly as the
     reference does, so that code sharing np.random with the equity call (gym_env/env.py:142,680,686 deals with
     it) follows the reference's trajectory after np.random.seed(s)."""
@@ -65,7 +78,12 @@ def configure(mode=None, couple_numpy=None, dealing=None):
     if couple_numpy is not None:
         _state["couple_numpy"] = bool(couple_numpy)
     if dealing is not None:
-        _lib.default_engine().set_dealing_law(dealing)
+        _lib.set_default_dealing_law(dealing)
+        with _lock:
+            multis = list(_MULTI.values())
+        for me in multis:
+            with me.lock:
+                me.set_dealing_law(dealing)
 
 
 _CLASS_ORDER = None
@@ -128,10 +146,9 @@ def _ext_record(hero, hero_is_range, known_hands, ghost_cards, opponent_range, o
 
 
 def _take_ids(n):
-    with _lock:
-        first = _state["counter"]
-        _state["counter"] += n
-        return _state["seed"], first
+    first = _stream.counter
+    _stream.counter = first + n
+    return _stream.seed, first
 
 
 def _query(player_cards, table_cards, players, runs):
@@ -244,18 +261,23 @@ def get_equity(player_cards, table_cards, players, runs):
     return (out[2] + out[3]) / out[0]
 
 
-_MULTI = {}   # n_gpus -> MultiEngine over devices 0 .. n_gpus - 1 (made at first use, kept)
+_MULTI = {}   # tuple of device ordinals -> MultiEngine (made at first use, kept; its callers take turns on its lock)
 
 
-def get_equity_batch(hole, board, n_players, runs, seed=None, first_query_id=0, mode=None, engine=None, n_gpus=None):
+def get_equity_batch(hole, board, n_players, runs, seed=None, first_query_id=0, mode=None, engine=None, n_gpus=None,
+                     devices=None):
     """Many states in one launch.
 
     hole [B,2] u8 card ids, board [B,5] u8 (0xFF = empty), n_players scalar or [B], runs scalar or [B].
     -> (equity[B] float64, tallies[B,13] uint64) with tally columns runs, passes, win, tie, by_type[9].
     Query i gets query id first_query_id + i: splitting a batch keeps every per-query tally identical.
-    n_gpus > 1: the batch is sharded over the first n_gpus devices of the node by the library's
-    multi-GPU entry (mcq_multi_*: one all-reduce of the integer tallies; production mode only) -- the tallies are
-    the same integers as on one GPU.
+    n_gpus > 1: the batch is sharded over the first n_gpus devices of the node -- counted from
+    $MCQ_DEVICE / $LOCAL_RANK's device as the single-GPU path does -- by the library's multi-GPU entry (mcq_multi_*: one
+    all-reduce of the integer tallies; production mode only); the tallies are the same integers as on one GPU, under the
+    dealing law configure(dealing=...) has set.  devices=[...] names the shards' devices explicitly instead (one
+    ordinal per shard, repeats allowed: several shards on one GPU).
+    STATUS of n_gpus > 1: untested on more than one distinct device (no multi-GPU node was reachable; the partitions,
+    the same-device add and a one-rank RCCL communicator are tested on one GPU with devices=[0, 0, ...]).
     """
     q = _lib.pack_queries(hole, board, n_players, runs)
     m = _state["mode"] if mode is None else _MODES[mode]
@@ -264,14 +286,24 @@ def get_equity_batch(hole, board, n_players, runs, seed=None, first_query_id=0, 
         first_query_id = base + first_query_id
     else:
         s = int(seed)
-    if n_gpus is not None and int(n_gpus) > 1:
+    if devices is None and n_gpus is not None and int(n_gpus) > 1:
+        n_dev = _lib.load_library().mcq_device_count()
+        if int(n_gpus) > n_dev:
+            raise ValueError("n_gpus = %d, but %d HIP device(s) are visible" % (int(n_gpus), n_dev))
+        dev0 = int(os.environ.get("MCQ_DEVICE", os.environ.get("LOCAL_RANK", "0"))) % max(n_dev, 1)
+        devices = [(dev0 + k) % n_dev for k in range(int(n_gpus))]
+    if devices is not None:
         if m != _lib.MODE_PHILOX or engine is not None:
-            raise ValueError("n_gpus > 1: production mode on the library's own contexts only")
+            raise ValueError("n_gpus > 1 / devices: production mode on the library's own contexts only")
+        key = tuple(int(d) for d in devices)
         with _lock:
-            me = _MULTI.get(int(n_gpus))
+            me = _MULTI.get(key)
             if me is None:
-                me = _MULTI[int(n_gpus)] = _lib.MultiEngine(list(range(int(n_gpus))))
-        res = me.eval_batch(q, s, first_query_id=first_query_id)
+                me = _MULTI[key] = _lib.MultiEngine(list(key))
+                if _lib.default_dealing_law() != "reference":
+                    me.set_dealing_law(_lib.default_dealing_law())
+        with me.lock:   # mcq_multi keeps per-call state: one call at a time per object
+            res = me.eval_batch(q, s, first_query_id=first_query_id)
     else:
         eng = engine or _lib.default_engine()
         res = eng.eval_batch(q, s, first_query_id=first_query_id, mode=m)

@@ -55,3 +55,6 @@ MCQ_LIBRARY=$T/libmcq_tsan.so MCQ_SAN_STUB=1 python3 -m pytest tests/test_table_
 # ... and over the shard workers of the multi-GPU entry (csrc/mcq_worker.hpp: submit / wait / join as mcq_multi.cpp drives them)
 g++ -O1 -g -fsanitize=thread -fno-omit-frame-pointer -std=c++17 -I$R/include -o $T/tsan_worker $R/tests/tsan_worker.cpp -lpthread
 TSAN_OPTIONS="exitcode=66" $T/tsan_worker
+# ... and over the in-flight guard of the entry points (csrc/mcq_busy.hpp)
+g++ -O1 -g -fsanitize=thread -fno-omit-frame-pointer -std=c++17 -o $T/tsan_busy $R/tests/tsan_busy.cpp -lpthread
+TSAN_OPTIONS="exitcode=66" $T/tsan_busy

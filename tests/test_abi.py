@@ -79,3 +79,43 @@ def test_header_is_plain_c_and_layouts_match_the_binding(tmp_path):
     assert [int(x) for x in out] == [_lib.QUERY_DTYPE.itemsize, _lib.RESULT_DTYPE.itemsize, _lib.QUERY_EXT_DTYPE.itemsize,
                                      t.itemsize, t.fields["seed"][1], t.fields["seat_kind"][1],
                                      t.fields["min_call_equity"][1]]
+
+
+def test_in_flight_guard_of_the_entry_points(tmp_path):
+    """One call in flight per context (include/mcq.h): the guard every entry point comes in through
+    (csrc/mcq_busy.hpp) lets exactly one of eight hammering threads in at a time (tests/tsan_busy.cpp; under
+    ThreadSanitizer in tests/sanitize_cpu.sh).  The GPU tests check the MCQ_EBUSY a second caller gets."""
+    import subprocess
+    exe = str(tmp_path / "tsan_busy")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", os.path.join(ROOT, "tests", "tsan_busy.cpp"), "-o", exe])
+    out = subprocess.check_output([exe]).decode()
+    assert "busy guard ok" in out
+    assert re.search(r"#define MCQ_EBUSY \(-4\)", header()) and _lib.MCQ_EBUSY == -4
+    assert issubclass(npa.McqBusyError, npa.McqError)
+
+
+def test_hand_evaluator_dropin_surface_without_gpu():
+    """neuron_poker_amd.hand_evaluator_hip mirrors tools/hand_evaluator.py:9-24 (names, arguments); argument errors are
+    raised before anything touches the GPU."""
+    import inspect
+    from neuron_poker_amd import hand_evaluator_hip as he
+    assert list(inspect.signature(he.get_winner).parameters)[:2] == ["player_hands", "table_cards"]
+    assert list(inspect.signature(he.eval_best_hand).parameters)[:1] == ["hands"]
+    with pytest.raises(ValueError):
+        he.get_winner([["AH", "1H"]], ["2C", "3C", "4C", "5D", "9S"])   # not in the deck
+    with pytest.raises(ValueError):
+        he.eval_best_hand([["AH", "KH", "2C"]])                          # not seven cards
+    with pytest.raises(IndexError):
+        he.eval_best_hand([])
+
+
+def test_seed_state_is_per_thread():
+    """montecarlo_hip.seed(s) sets the CALLING thread's stream (SURVEY 8b threading)."""
+    import threading
+    from neuron_poker_amd import montecarlo_hip as mh
+    mh.seed(5)
+    assert mh._take_ids(3) == (5, 0) and mh._take_ids(2) == (5, 3)
+    seen = []
+    th = threading.Thread(target=lambda: (mh.seed(9), seen.append(mh._take_ids(4)), seen.append(mh._take_ids(1))))
+    th.start(); th.join()
+    assert seen == [(9, 0), (9, 4)] and mh._take_ids(1) == (5, 5)

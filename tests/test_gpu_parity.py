@@ -1224,3 +1224,162 @@ def test_torch_tensors_in_hbm_end_to_end(eng):
     assert np.array_equal(t.cpu().numpy().view(np.uint64), t_ref) and np.array_equal(eq.cpu().numpy(), eq_ref)
     with pytest.raises(ValueError):
         torch_ops.get_equity_batch_torch(torch.from_numpy(hole), torch.from_numpy(board), 2, 10)
+
+
+# ------------------------------------------------------------------------------------------ round 4: threads, get_winner
+def test_hand_evaluator_dropin_matches_reference(eng):
+    """neuron_poker_amd.hand_evaluator_hip -- get_winner / eval_best_hand with the reference's card strings
+    (tools/hand_evaluator.py:9-24; gym_env/env.py:587 is the caller) -- on the reference's own showdowns and cases."""
+    from neuron_poker_amd import hand_evaluator_hip as he
+    z = np.load(os.path.join(G, "showdowns.npz"))
+    hands, n, win, wt = z["hands"], z["n_players"], z["winner"], z["winner_type"]
+    for i in range(0, len(hands), 97):   # every 97th of the 24 000 reference showdowns, 2 to 10 hands, one call each
+        p = int(n[i])
+        rows = [[npa.card_str(c) for c in hands[i, k]] for k in range(p)]
+        table = rows[0][2:]
+        if all(r[2:] == table for r in rows):   # one table for all: the get_winner form
+            assert he.get_winner([r[:2] for r in rows], table) == (int(win[i]), npa.TYPES[int(wt[i])])
+        best, kind = he.eval_best_hand(rows)
+        assert best == rows[int(win[i])] and kind == npa.TYPES[int(wt[i])]
+    for c in jload("evaluator_cases.json"):
+        ids = [[npa.card_id(x) for x in h] for h in c["hands"]]
+        if any(len(set(h)) != 7 for h in ids):
+            with pytest.raises(ValueError):   # a card named twice: outside the domain (documented difference)
+                he.eval_best_hand(c["hands"])
+            continue
+        best, kind = he.eval_best_hand(c["hands"])
+        assert best == c["hands"][c["winner"]] and kind == c["winner_type"], c
+    # many tables in one launch
+    sel = np.nonzero(n == 6)[0][:500]
+    same_table = [i for i in sel if (hands[i, :6, 2:] == hands[i, 0, 2:]).all()]
+    if same_table:
+        w, t = he.get_winner_batch(hands[same_table, :6, :2], hands[same_table, 0, 2:])
+        assert np.array_equal(w, win[same_table]) and np.array_equal(t, wt[same_table])
+    with pytest.raises(ValueError):
+        he.get_winner([["AH", "KH"], ["QD", "2C"]], ["2C", "3C", "4C", "5D", "9S"])   # 2C twice in one hand
+    with pytest.raises(ValueError):
+        he.get_winner([["AH", "1H"]], ["2C", "3C", "4C", "5D", "9S"])
+
+
+def _equity_calls(seed, count):
+    """`count` get_equity calls as HoldemTable makes them (gym_env/env.py:261-262), stream `seed` of this thread."""
+    g = np.random.default_rng(seed)
+    mh.seed(seed)
+    out = []
+    for _ in range(count):
+        nb = int(g.choice([0, 3, 4, 5]))
+        cards = [npa.card_str(c) for c in g.choice(52, 2 + nb, replace=False)]
+        out.append(mh.get_equity(set(cards[:2]), set(cards[2:]), int(g.integers(2, 7)), 1000))
+    return out
+
+
+def test_threads_calling_get_equity_equal_the_serial_calls():
+    """SURVEY 8b threading: a context allows one call in flight, ctypes drops the GIL during a call -- so every thread
+    has its own default engine and its own (seed, counter) stream: four threads x 200 get_equity calls == the same calls
+    made one after the other."""
+    import threading
+    got, errors = {}, []
+
+    def work(t):
+        try:
+            got[t] = _equity_calls(1000 + t, 200)
+        except Exception as e:   # noqa: BLE001 -- reported below
+            errors.append((t, repr(e)))
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for t in range(4):
+        assert got[t] == _equity_calls(1000 + t, 200), t
+    engines = set()
+    box = []
+    th = threading.Thread(target=lambda: box.append(npa.default_engine()))
+    th.start(); th.join()
+    engines.add(id(box[0])); engines.add(id(npa.default_engine()))
+    assert len(engines) == 2   # per thread
+
+
+def test_second_call_on_a_busy_context_is_turned_away(eng):
+    """include/mcq.h: one call in flight per context; the library checks it (MCQ_EBUSY) instead of letting two callers
+    race on the context's staging buffers."""
+    import threading
+    import time
+    g = np.random.default_rng(5)
+    cards = np.array([g.permutation(52)[:2] for _ in range(4096)], np.uint8)
+    big = npa.pack_queries(cards, np.full((4096, 5), 255, np.uint8), 6, 100000)   # about 6 ms on the GPU
+    small = mkq(["AH", "KH"], [], 2, 1000)
+    want_small = u64(eng.eval_batch(small, seed=3))
+    started, results, busy = threading.Event(), [], [0]
+
+    def long_call():
+        started.set()
+        results.append(u64(eng.eval_batch(big, seed=1)))
+    th = threading.Thread(target=long_call)
+    th.start()
+    started.wait()
+    deadline = time.time() + 5
+    while th.is_alive() and time.time() < deadline:
+        try:
+            assert np.array_equal(u64(eng.eval_batch(small, seed=3)), want_small)   # got in between two calls: fine
+        except npa.McqBusyError as e:
+            assert "context busy" in str(e)
+            busy[0] += 1
+    th.join()
+    assert busy[0] > 0
+    assert np.array_equal(results[0], u64(eng.eval_batch(big, seed=1)))   # the long call was not disturbed
+    assert np.array_equal(u64(eng.eval_batch(small, seed=3)), want_small)
+
+
+def test_get_equity_batch_shards_on_one_device_follow_the_dealing_law(eng):
+    """The shim's multi-GPU branch on the one GPU there is (devices=[0, 0, 0]: three shards, one all-reduce rank): same
+    integers as the single-context call -- under the uniform law too, which configure() hands on to the multi-GPU engines
+    (round-3 advice: it did not)."""
+    g = np.random.default_rng(12)
+    cards = np.array([g.permutation(52)[:7] for _ in range(900)], np.uint8)
+    board = np.full((900, 5), 255, np.uint8)
+    board[::2, :3] = cards[::2, 2:5]
+    try:
+        for law in ("reference", "uniform", "reference"):
+            mh.configure(dealing=law)
+            eng.set_dealing_law(law)
+            one = mh.get_equity_batch(cards[:, :2], board, 6, 3000, seed=9, engine=eng)[1]
+            many = mh.get_equity_batch(cards[:, :2], board, 6, 3000, seed=9, devices=[0, 0, 0])[1]
+            own = mh.get_equity_batch(cards[:, :2], board, 6, 3000, seed=9)[1]   # this thread's default engine
+            assert np.array_equal(one, many) and np.array_equal(one, own), law
+        ref = one
+        mh.configure(dealing="uniform")
+        assert not np.array_equal(ref, mh.get_equity_batch(cards[:, :2], board, 6, 3000, seed=9, devices=[0, 0, 0])[1])
+    finally:
+        mh.configure(dealing="reference")
+        eng.set_dealing_law("reference")
+
+
+def test_bench_configs3_workload_is_partition_invariant():
+    """`bench.py --workload configs3` (BASELINE configs[3]: 65 536 flop/turn states x 6 x 20k IN ALL, block-sharded over the
+    ranks, strong scaling, one all-reduce): one rank, two ranks on this GPU (gloo carrying the collective), and the
+    one-process multi-GPU entry with three shards all print ONE line with the same checksum of the whole tally matrix."""
+    import json as _json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--workload", "configs3", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    runs = {"one rank": ["--gpus", "1"],
+            "two ranks": ["--gpus", "2", "--single-device", "--backend", "gloo"],
+            "three shards": ["--gpus", "3", "--single-device", "--native-multi"]}
+    sums = {}
+    for name, extra in runs.items():
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra + common, capture_output=True, text=True,
+                             timeout=600, cwd=root)
+        assert out.returncode == 0, (name, out.stderr[-2000:])
+        line = [x for x in out.stdout.splitlines() if x.startswith("{")]
+        assert len(line) == 1, (name, out.stdout)
+        d = _json.loads(line[0])
+        assert d["scaling"] == "strong" and "configs[3]" in d["metric"] and "configs[3]" in d["config"]["workload"], name
+        assert d["config"]["hand_evals_per_step"] == 65536 * 6 * 20000 and d["config"]["states_total"] == 65536
+        assert d["value"] > 0 and d["roofline"]["kernel_ms"] > 0, name
+        if name != "one rank":
+            assert d["collective"]["bytes"] == 65536 * 104, name
+        sums[name] = d["tallies_sha256"]
+    assert len(set(sums.values())) == 1, sums
