@@ -275,8 +275,8 @@ MCQ_API int mcq_multi_eval_batch(mcq_multi *m, const mcq_query *q, size_t n, uin
  * shard's device.  d_queries[s]: MCQ_PARTITION_QUERIES -> the shard's block, queries [n*s/k, n*(s+1)/k) of the batch
  * (k shards); MCQ_PARTITION_ITERATIONS -> all n queries.  d_results[s] -> mcq_result[n], overwritten: after the
  * all-reduce EVERY shard's buffer holds the complete matrix.  Blocks until all devices have finished.  The host never
- * sees the queries, so they are validated on the device: an invalid query's row has runs = 0 (and, under
- * MCQ_PARTITION_QUERIES, passes = UINT64_MAX). */
+ * sees the queries, so they are validated on the device: an invalid query's row has runs = 0 and passes = UINT64_MAX
+ * (under either partition: only one share of a query writes the marker, so the sum over the shares keeps it). */
 MCQ_API int mcq_multi_eval_batch_device(mcq_multi *m, const void *const *d_queries, size_t n, uint64_t seed,
                                         uint64_t first_query_id, int partition, void *const *d_results);
 MCQ_API int mcq_multi_set_dealing_law(mcq_multi *m, int law);

@@ -150,6 +150,7 @@ struct mcq_ctx {
     bool ext_small = true; /* a few extended queries of the production mode in one launch (MCQ_EXT_SMALL=0: always the general path) */
     size_t direct_uniform_min = 128; /* one-launch path: from this many queries on the kernel lays its own work out (MCQ_DIRECT_UNIFORM_MIN; measured: 512 queries 39 -> 33 us per call, 1024: 48 -> 42, 4096: 137 -> 113) */
     bool direct_poll = true;      /* pick the rows up at the flag instead of synchronising the stream (MCQ_DIRECT_POLL) */
+    bool direct_sleep = true;     /* sleep through half of a long kernel's expected time before polling (MCQ_DIRECT_SLEEP) */
     McqDirectLayout direct_layout;      /* the one-launch path's layout of the current call */
     std::vector<uint64_t> direct_cost;
 };

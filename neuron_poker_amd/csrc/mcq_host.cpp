@@ -257,13 +257,18 @@ int replay_batch_device(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed,
             }
             blk[m] = (uint32_t)total;
             grp[m] = (uint32_t)groups;
-            if (total >= kMtbMinBlocks && total <= kMtbMaxBlocks) {
-                const auto pad16 = [](uint64_t x) { return (x + 15u) & ~15ull; };
-                const uint64_t o_ovf = pad16(2 * (m + 1) * 4), o_ent = o_ovf + pad16(m * 4),
-                               o_gen = o_ent + pad16(total * sizeof(McqMtbEntry)), o_gw = o_gen + pad16(groups * sizeof(McqMtbEntry)),
-                               o_gi = o_gw + groups * MCQ_MTB_LANES * 4u, o_ex = o_gi + groups * MCQ_MTB_LANES * 4u,
-                               o_raw = o_ex + total * MCQ_MTB_LANES * 4u, bytes = o_raw + total * MCQ_MT_N * 4u + 64u;
-                HIP_TRY(c->d_mt.reserve(bytes));
+            const auto pad16 = [](uint64_t x) { return (x + 15u) & ~15ull; };
+            const uint64_t o_ovf = pad16(2 * (m + 1) * 4), o_ent = o_ovf + pad16(m * 4),
+                           o_gen = o_ent + pad16(total * sizeof(McqMtbEntry)), o_gw = o_gen + pad16(groups * sizeof(McqMtbEntry)),
+                           o_gi = o_gw + groups * MCQ_MTB_LANES * 4u, o_ex = o_gi + groups * MCQ_MTB_LANES * 4u,
+                           o_raw = o_ex + total * MCQ_MTB_LANES * 4u, bytes = o_raw + total * MCQ_MT_N * 4u + 64u;
+            bool room = total >= kMtbMinBlocks && total <= kMtbMaxBlocks;
+            if (room && c->d_mt.reserve(bytes) != hipSuccess) { /* no room for the blocks' scratch (2.7 KB per block): the
+                                                                  * serial walk, which needs none, serves the call */
+                (void)hipGetLastError();
+                room = false;
+            }
+            if (room) {
                 char *base = (char *)c->d_mt.p;
                 HIP_TRY(hipMemcpyAsync(base, blk, 2 * (m + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
                 mtb.d_blk_off = (const uint32_t *)base;
@@ -394,6 +399,7 @@ mcq_ctx *mcq_ctx_clone(const mcq_ctx *c) {
         d->load_waves = c->load_waves;
         d->direct_max_tasks = c->direct_max_tasks;
         d->direct_poll = c->direct_poll;
+        d->direct_sleep = c->direct_sleep;
         d->direct_uniform_min = c->direct_uniform_min;
         d->ext_small = c->ext_small;
         d->mt_blocks = c->mt_blocks;
@@ -484,6 +490,7 @@ mcq_ctx *mcq_create(int device, int flags) {
         c->direct_max_tasks = (uint32_t)(v < 0 ? 0 : v > (int)MCQ_DIRECT_TASKS_LIMIT ? (int)MCQ_DIRECT_TASKS_LIMIT : v);
     }
     if (const char *e = getenv("MCQ_DIRECT_POLL")) c->direct_poll = atoi(e) != 0;
+    if (const char *e = getenv("MCQ_DIRECT_SLEEP")) c->direct_sleep = atoi(e) != 0; /* see wait_ticket */
     if (const char *e = getenv("MCQ_EXT_SMALL")) c->ext_small = atoi(e) != 0; /* see mcq_eval_batch_ext */
     if (const char *e = getenv("MCQ_MT_BLOCKS")) c->mt_blocks = atoi(e) != 0;  /* see replay_batch_device */
     if (const char *e = getenv("MCQ_MT_BLOCKS_MARGIN")) c->mt_blocks_margin = atoi(e);
@@ -664,7 +671,9 @@ static int wait_ticket(mcq_ctx *c, uint32_t ticket, bool *by_flag, double est_us
     const volatile uint32_t *flag = static_cast<const volatile uint32_t *>(c->h_flag.p);
     bool seen = false;
     if (c->direct_poll) {
-        if (est_us > 300.0) std::this_thread::sleep_for(std::chrono::microseconds((long long)(0.85 * est_us) - 60));
+        /* (half of the estimate: the constant behind est_us was measured on a whole MI355X under one dealing law; an
+         * overshoot would add to the call what the flag was built to save.  MCQ_DIRECT_SLEEP=0: never sleep) */
+        if (c->direct_sleep && est_us > 300.0) std::this_thread::sleep_for(std::chrono::microseconds((long long)(0.5 * est_us)));
         const auto t1 = std::chrono::steady_clock::now();
         for (uint32_t spin = 0;; spin++) {
             if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == ticket) { seen = true; break; }

@@ -134,7 +134,8 @@ __global__ __launch_bounds__(1024) void mcq_prep_kernel(const mcq_query *__restr
             my_tasks = ok ? pt.t_hi - pt.t_lo : 0u;
             uint64_t *r = reinterpret_cast<uint64_t *>(res + i);
             r[0] = ok ? pt.runs : 0ull;
-            r[1] = ok ? 0ull : ~0ull;
+            r[1] = ok || part_idx != 0u ? 0ull : ~0ull; /* the marker of an invalid query: from ONE share only, so that the
+                                                          * sum of the shares (same-device add, all-reduce) still shows it */
 #pragma unroll
             for (int k = 2; k < 13; k++) r[k] = 0;
         }
