@@ -83,7 +83,8 @@ def issue_roofline(kernel, kernel_ms, counters, fresh, model_ops_per_launch=None
         r["valu_busy"] = counters.get("valu_busy")
         r["counters"] = {k: counters.get(k) for k in (
             "kernel_avg_ms_rocprof", "valu_wave_instructions_per_launch", "valu_instructions_per_wave_iteration",
-            "lane_utilisation", "lds_bank_conflict_over_lds_active", "lds_pipe_busy", "hbm_bytes_per_launch", "hbm_GBps")
+            "lane_utilisation", "lds_bank_conflict_over_lds_active", "lds_pipe_busy", "hbm_bytes_per_launch", "hbm_GBps",
+            "shader_clock_ghz")
             if counters.get(k) is not None}
         r["counters"]["source"] = "rocprofv3 --pmc passes, profiles/current.json"
     if model_ops_per_launch:
@@ -93,6 +94,35 @@ def issue_roofline(kernel, kernel_ms, counters, fresh, model_ops_per_launch=None
                       "note": "a-priori cost model, NOT a fraction of a hardware bound: the kernel needs fewer instructions "
                               "than the model counts, so this ratio can exceed 1"}
     return r
+
+
+def practical_roofline(kernel_ms, wave_iterations_per_launch, counters):
+    """The mix-weighted issue bound of the bulk kernel's straight-line iteration (tools/isa_hist.py ->
+    profiles/current_isa_hist.json: every VALU instruction of the 6-max preflop loop priced at the cadence of its issue
+    class as measured on the hardware, profiles/r07_issue_probe*.txt / r07_replay.txt) against the cycles a SIMD spends
+    per wave-iteration in this run (kernel time x shader clock x 1024 SIMDs / wave-iterations, four waves per SIMD)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "current_isa_hist.json")) as f:
+            h = json.load(f)
+    except (OSError, ValueError):
+        return None
+    clock = (counters or {}).get("shader_clock_ghz") or 2.4
+    measured = kernel_ms * 1e-3 * clock * 1e9 * 1024 / wave_iterations_per_launch if kernel_ms and wave_iterations_per_launch else None
+    bound = h.get("cycles_per_wave_iteration_bound")
+    return {"cycles_per_wave_iteration_bound": bound,
+            "cycles_per_wave_iteration_as_scheduled": h.get("cycles_as_scheduled"),
+            "cycles_per_wave_iteration_at_2_per_instruction": h.get("cycles_at_2_per_instruction"),
+            "cycles_per_wave_iteration_measured": measured, "shader_clock_ghz": clock,
+            "frac_of_practical": bound / measured if bound and measured else None,
+            "valu_instructions": h.get("valu"), "by_class": {k: h.get("classes", {}).get(k) for k in ("fast", "slow", "mul64", "sel_vcc")},
+            "fast_class_instructions_at_the_slow_cadence": h.get("poisoned_fast_instructions"),
+            "class_costs_simd_cycles": h.get("costs_simd_cycles"),
+            "histogram_fresh": h.get("kernel_sources_sha256") == kernel_source_hash(),
+            "basis": "bound = sum over the loop's VALU instructions of the cost of their issue class (fast 2.6, slow 4.7 "
+                     "SIMD-cycles per wave64 instruction: this loop's own instructions replayed class by class, "
+                     "tools/ubench/replay_loop.py); as_scheduled = the same with the cadence rule applied to the compiler's "
+                     "ORDER (a fast-class instruction behind a slow-class one of its VALU run issues at the slow cadence); "
+                     "measured = kernel time x clock x 1024 SIMDs / wave-iterations"}
 
 
 def alg_ops_per_iteration(n_players, n_board):
@@ -425,6 +455,8 @@ def main():
     roof = issue_roofline("mcq_eval_kernel<0, false>", kernel_ms, pc, fresh, model_ops_per_launch=model_ops,
                           model_basis=model_basis)
     roof["traffic"] = pc.get("hbm_bytes_per_launch") if pc else None
+    if not configs3 and N == 6:   # the histogram is of the 6-max preflop iteration (5 opponents, 5 table cards to come)
+        roof["practical"] = practical_roofline(kernel_ms, float(B) * runs / 64.0, pc)
     roof["hbm"] = {"algorithmic_bytes_per_launch": B * 120, "achieved_GBps": B * 120 / (kernel_ms * 1e-3) / 1e9,
                    "peak_GBps": HBM_PEAK_GBPS}
     ar_text = (", one %s all-reduce of the [%d,13] int64 tally matrix per step" %

@@ -12,23 +12,36 @@ fits -- 2 * nopp + ndeal card reads (ds_read_b128) and 3 * nopp + ndeal + ceil(n
 (one per random word, one per bounded draw; mcq_device.hpp: McqCtrDrawsT, McqMwc64x).  Every instruction of that loop
 is put into an issue class:
 
-    fast     VALU of the 2.3-cycle class: v_add/sub/subrev_u32, v_and/or/xor/not_b32, v_mov_b32, v_lshrrev/ashrrev,
-             (also with a literal); an SGPR or SDWA/DPP operand moves the instruction to `slow`
-    slow     every other VALU instruction (4.3 cycles): shifts left, compares, selects, bit counts, min/max, all
-             three-operand VOP3 forms (v_and_or, v_or3, v_add3, v_lshl_add, v_lshl_or, v_bfi, v_bfe, v_perm, v_sad_u8,
-             v_bitop3 ...), SDWA / DPP forms, anything that reads an SGPR
-    mul64    v_mad_u64_u32 (4.4-4.8 cycles; the full-width multiplier)
-    sel_vcc  VOP2 / SDWA v_cndmask_b32 taking its mask from VCC (4.3 right behind the vector compare that wrote VCC,
-             16-23 cycles otherwise: priced at 4.3 when the previous VALU instruction that wrote VCC is a v_cmp at most
-             `--vcc-window` VALU instructions back, else at the stale price)
+    fast     VALU of the 2-cycle class (profiles/r07_issue_probe.txt, priced among plain adds): v_add/sub/subrev_u32,
+             v_and/or/xor/not_b32, v_mov_b32, v_lshrrev/ashrrev (also with a literal or an SGPR operand), v_bitop3_b32,
+             v_cndmask_b32_e64 (mask in an SGPR pair), v_addc_co_u32
+    slow     every other VALU instruction (4-cycle class): shifts left, compares, the VOP2 / SDWA selects, bit counts,
+             min/max, every other three-operand form (v_and_or, v_or3, v_add3, v_lshl_add, v_lshl_or, v_bfi, v_bfe, v_perm,
+             v_sad_u8, v_xad ...), multiplies, SDWA / DPP forms
+    mul64    v_mad_u64_u32 (the full-width multiplier; priced with the slow class)
+    sel_vcc  VOP2 / SDWA v_cndmask_b32 taking its mask from VCC (slow class; 16-23 cycles when VCC was not written by a
+             vector compare just before -- profiles/r06_vcc_probe.txt -- counted as `stale_vcc_selects`)
     salu, lds, vmem, wait, branch, other: not VALU (counted, priced 0 on the VALU pipe)
 
-and the tool prints / writes: count per class and per opcode, the mix-weighted bound `cycles_per_wave_iteration_bound`
-= sum(count x cost) (what the SIMD needs to ISSUE one wave-iteration when nothing else stalls), the 2-cycle figure the
-guide's peak assumes (2 x VALU count), and -- with --roles -- the split of the VALU instructions by role obtained by
-DIFFERENCE against diagnostic builds of the same kernel with one stage stubbed out (-DMCQ_ABLATE_RNG / _HOLES / _EVAL,
-mcq_device.hpp): RNG + bounded draws, hole scan (dealing without search), evaluator, rest (card records, board
-accumulation, compare / tally, loop).
+THE CADENCE RULE (profiles/r07_issue_probe*.txt): the class of an instruction is not its price.  Once a wave has issued
+a slow-class instruction, every VALU instruction it issues afterwards goes at the 4-cycle cadence -- fast-class ones too --
+until a NON-VALU instruction of that wave (SALU, s_nop, s_waitcnt, LDS, VMEM, branch) comes by.  So the tool prices the loop
+three ways, in SIMD-cycles per wave-iteration at four waves per SIMD:
+
+    cycles_if_every_class_kept_its_cadence   sum(count x class cost): what a schedule that never lets a fast-class
+                                             instruction follow a slow-class one inside a VALU run would need -- the
+                                             PRACTICAL BOUND of this instruction mix (`cycles_per_wave_iteration_bound`)
+    cycles_as_scheduled                      the same walk with the cadence rule applied to the instruction ORDER the
+                                             compiler chose: a fast-class instruction behind a slow-class one of its run
+                                             is priced slow (`poisoned_fast_instructions` says how many)
+    cycles_at_2_per_instruction              2 x VALU count: the guide's peak, which no mix with a slow-class
+                                             instruction in it can reach
+
+Class costs: measured on THIS loop's own instructions replayed as a stand-alone kernel (tools/ubench/replay_loop.py,
+profiles/r07_replay.txt): its 261 fast-class instructions alone 2.61 cycles each, its 245 slow-class ones alone 4.67, the
+whole VALU stream in the compiler's order 4.28 per instruction (= the production kernel's 4.2-4.3).  With --roles the VALU
+instructions are split by role by DIFFERENCE against diagnostic builds with one stage stubbed out (-DMCQ_ABLATE_RNG /
+_HOLES / _EVAL, mcq_device.hpp).
 
 bench.py reads the JSON (profiles/current_isa_hist.json) and reports roofline.practical from it.
 """
@@ -46,10 +59,11 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 
 # measured issue costs, SIMD-cycles per wave64 instruction at 4 waves per SIMD (profiles/r01_ubench.txt,
 # r06_vcc_probe.txt; refined per context by profiles/r07_issue_probe.txt when that file's table is passed in)
-COST = {"fast": 2.3, "slow": 4.3, "mul64": 4.4, "sel_vcc": 4.3, "sel_vcc_stale": 19.0}
+COST = {"fast": 2.61, "slow": 4.67, "mul64": 4.67, "sel_vcc": 4.67, "fast_at_slow_cadence": 4.2}
 
 FAST_OPS = {"v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_not_b32", "v_mov_b32",
-            "v_lshrrev_b32", "v_ashrrev_i32", "v_add_f32", "v_mul_f32", "v_sub_f32"}
+            "v_lshrrev_b32", "v_ashrrev_i32", "v_add_f32", "v_mul_f32", "v_sub_f32", "v_bitop3_b32", "v_addc_co_u32",
+            "v_nop"}
 
 
 def run(cmd, **kw):
@@ -158,16 +172,11 @@ def classify(op, args):
     if op.startswith("v_"):
         if base == "v_mad_u64_u32":
             return "mul64"
-        if base == "v_cndmask_b32" and not op.endswith("_e64") and re.search(r"\bvcc\b", args):
-            return "sel_vcc"
+        if base == "v_cndmask_b32":
+            return "fast" if op.endswith("_e64") else "sel_vcc"
         if op.endswith("_sdwa") or op.endswith("_dpp"):
             return "slow"
-        if base in FAST_OPS:
-            srcs = args.split(",")[1:]
-            if any(re.match(r"\s*(s\d+|s\[\d+:\d+\]|vcc|vcc_lo|vcc_hi|exec|exec_lo|exec_hi|m0)\b", s) for s in srcs):
-                return "slow"  # an SGPR operand: the 4-cycle class
-            return "fast"
-        return "slow"
+        return "fast" if base in FAST_OPS else "slow"
     if op.startswith("s_waitcnt") or op == "s_nop":
         return "wait"
     if op.startswith("s_cbranch") or op == "s_branch":
@@ -181,27 +190,39 @@ def classify(op, args):
     return "other"
 
 
-def histogram(body, vcc_window):
+def histogram(body, vcc_window, guarded=()):
+    """guarded: index ranges of `body` that are executed only when some lane needs them (counted, priced 0)."""
     classes, ops = {}, {}
-    cycles = 0.0
-    last_vcc_writer = None  # (kind, VALU instructions since)
-    since = 10 ** 9
-    stale = 0
-    for _, op, args in body:
+    bound = scheduled = 0.0
+    last_vcc_writer, since, stale = None, 10 ** 9, 0
+    slow_cadence = False  # a slow-class instruction has been issued since the wave's last non-VALU instruction
+    poisoned = 0
+    rare = set()
+    for a, b in guarded:
+        rare.update(range(a, b))
+    for k, (_, op, args) in enumerate(body):
         c = classify(op, args)
         key = op
-        if c == "sel_vcc":
-            fresh = last_vcc_writer == "v_cmp" and since <= vcc_window
-            if not fresh:
-                stale += 1
-                key = op + " (VCC not fresh from a v_cmp)"
-            cycles += COST["sel_vcc"] if fresh else COST["sel_vcc_stale"]
-        elif c in COST:
-            cycles += COST[c]
+        if c == "sel_vcc" and not (last_vcc_writer == "v_cmp" and since <= vcc_window):
+            stale += 1
+            key = op + " (VCC not fresh from a v_cmp)"
         classes[c] = classes.get(c, 0) + 1
         ops.setdefault(c, {})
         ops[c][key] = ops[c].get(key, 0) + 1
-        # who wrote VCC last?
+        if k not in rare:
+            if c == "fast":
+                bound += COST["fast"]
+                if slow_cadence:
+                    poisoned += 1
+                    scheduled += COST["fast_at_slow_cadence"]
+                else:
+                    scheduled += COST["fast"]
+            elif c in ("slow", "mul64", "sel_vcc"):
+                bound += COST[c]
+                scheduled += COST[c]
+                slow_cadence = True
+            else:
+                slow_cadence = False  # any non-VALU instruction of the wave ends the slow cadence
         dst = args.split(",")[0].strip() if args else ""
         if op.startswith("v_"):
             since += 1
@@ -213,7 +234,8 @@ def histogram(body, vcc_window):
             last_vcc_writer, since = "salu", 0
     valu = sum(classes.get(k, 0) for k in ("fast", "slow", "mul64", "sel_vcc"))
     return {"classes": classes, "opcodes": ops, "valu": valu, "stale_vcc_selects": stale,
-            "cycles_per_wave_iteration_bound": round(cycles, 1), "cycles_at_2_per_instruction": 2 * valu,
+            "cycles_per_wave_iteration_bound": round(bound, 1), "cycles_as_scheduled": round(scheduled, 1),
+            "poisoned_fast_instructions": poisoned, "cycles_at_2_per_instruction": 2 * valu,
             "fast_share": round(classes.get("fast", 0) / valu, 4) if valu else 0.0}
 
 
@@ -272,7 +294,7 @@ def main():
         name, ins = kernel_instructions(disassemble(co), a.kernel)
         j, i = pick_loop(ins, a.nopp, a.ndeal)
         body = ins[j:i + 1]
-        h = histogram(body, a.vcc_window)
+        h = histogram(body, a.vcc_window, [(x - j, y - j) for x, y in guarded_ranges(ins, j, i)])
         if a.dump:
             with open(a.dump, "w") as f:
                 for ad, op, args in body:

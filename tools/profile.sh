@@ -11,6 +11,11 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_THREA
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc2 -o p -- $B --steps 2 --warmup 1 > $OUT/pmc2.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc3 -o p -- $B --steps 2 --warmup 1 > $OUT/pmc3.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc4 -o p -- $B --steps 2 --warmup 1 > $OUT/pmc4.log 2>&1 || exit 1
+# BASELINE configs[3] on this one GPU (bench.py --workload configs3): kernel trace + the instruction counters
+C3="python3 $R/bench.py --workload configs3 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c3kt -o p -- $C3 --steps 5 --warmup 1 > $OUT/c3kt.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/c3pmc1 -o p -- $C3 --steps 2 --warmup 1 > $OUT/c3pmc1.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/c3pmc4 -o p -- $C3 --steps 2 --warmup 1 > $OUT/c3pmc4.log 2>&1 || exit 1
 # the side kernels (parity mode's stream walk, one-launch kernel, extended queries) on tools/side_kernels.py's workloads
 S="python3 $R/tools/side_kernels.py"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/skt -o p -- $S > $OUT/skt.log 2>&1 || exit 1
@@ -60,6 +65,8 @@ def summary(kt_dir, dirs, match, iterations):
          "lds_bank_conflict_over_lds_active": m["SQ_LDS_BANK_CONFLICT"] / m["SQ_LDS_IDX_ACTIVE"] if m.get("SQ_LDS_IDX_ACTIVE") else None,
          # LDS pipe: index-active cycles per CU over the GPU-active cycles of one XCD (256 CUs in 8 XCDs)
          "lds_pipe_busy": m["SQ_LDS_IDX_ACTIVE"] / 256 / (m["GRBM_GUI_ACTIVE"] / xcds) if "GRBM_GUI_ACTIVE" in m and "SQ_LDS_IDX_ACTIVE" in m else None,
+         # shader clock during the kernel: GPU-active cycles of one XCD over the kernel's time
+         "shader_clock_ghz": m["GRBM_GUI_ACTIVE"] / xcds / avg_ns if "GRBM_GUI_ACTIVE" in m else None,
          "FETCH_SIZE_KB": m.get("FETCH_SIZE"), "WRITE_SIZE_KB": m.get("WRITE_SIZE"),
          # MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads -> doubled; WRITE_SIZE exact
          "hbm_bytes_per_launch": (2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024 if "FETCH_SIZE" in m and "WRITE_SIZE" in m else None}
@@ -73,6 +80,9 @@ def summary(kt_dir, dirs, match, iterations):
 s, raw = summary("kt", ["pmc1", "pmc2", "pmc3", "pmc4"], "mcq_eval_kernel", 4096 * 100000)
 json.dump(raw, open("$OUT/pmc_eval_kernel.json", "w"), indent=1)
 s = dict({"kernel_sources_sha256": kernel_source_hash(), "workload": {"states": 4096, "iters": 100000, "players": 6}}, **s)
+c3, _ = summary("c3kt", ["c3pmc1", "c3pmc4"], "mcq_eval_kernel", 65536 * 20000)
+if c3:
+    s["configs3"] = c3
 units = [json.loads(l) for l in open("$OUT/skt.log") if l.startswith("{")][-1]
 s["side_kernels"] = {}
 for name, u in units.items():

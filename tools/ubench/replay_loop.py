@@ -1,0 +1,329 @@
+#!/usr/bin/env python3
+"""Replays the straight-line iteration of the bulk kernel as a stand-alone gfx950 kernel -- same instructions, same
+registers, same order, four waves per SIMD, one 1024-thread block per CU -- so that ISSUE behaviour can be studied (and
+re-orderings tried) without the memory side and without rebuilding the library:
+
+    python tools/ubench/replay_loop.py --out /tmp/replay [--nopp 5 --ndeal 5] [--variant as_compiled --variant sep ...]
+    -> /tmp/replay/<variant>.s / .co  (+ replay_host: `replay_host <variant>.co [iters]` prints cycles per wave-iteration)
+
+What is changed with respect to the loop in libmcq_hip.so: branches and EXEC manipulation are dropped (all lanes run
+`iters` trips), the rarely executed quads lookups (behind s_cbranch_execz) are dropped with them, the twelve global
+loads per trip read a small valid buffer at a fixed offset (they hit L1 as the real ones mostly do), register contents
+are arbitrary (LDS reads go to arbitrary, mostly out-of-range, addresses: they return zeros, conflicts are random).
+Results mean nothing; the instruction stream is what the SIMD sees in production.
+
+Variants (functions below): as_compiled, sep (s_nop 0 behind every slow-class VALU instruction followed by a VALU
+instruction: tools/isa_cadence.py's rule), sep_all (behind every slow-class instruction), no_lds (LDS reads dropped),
+no_vmem, only_valu (neither), ... -- see VARIANTS.
+"""
+import argparse
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import isa_cadence  # noqa: E402
+import isa_hist  # noqa: E402
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def loop_body(lib, kernel, nopp, ndeal):
+    with tempfile.TemporaryDirectory() as wd:
+        co = isa_hist.code_object(lib, wd)
+        _, ins = isa_hist.kernel_instructions(isa_hist.disassemble(co), kernel)
+    j, i = isa_hist.pick_loop(ins, nopp, ndeal)
+    body = ins[j:i + 1]
+    drop = set()
+    for a, b in isa_hist.guarded_ranges(ins, j, i):
+        drop.update(range(a - j, b - j))
+    out = []
+    for k, (_, op, args) in enumerate(body):
+        if k in drop:
+            continue
+        if op.startswith("s_cbranch") or op == "s_branch":
+            continue
+        if re.match(r"exec\b", args) or op.startswith("s_and_saveexec") or op.startswith("s_or_saveexec"):
+            continue
+        args = re.sub(r"\s*//.*$", "", args).strip()
+        if op.startswith("global_load_dword"):
+            m = re.match(r"(v\d+|v\[\d+:\d+\]),\s*v\d+,\s*s\[\d+:\d+\](.*)$", args)
+            if not m:
+                raise SystemExit("unexpected global load: %s %s" % (op, args))
+            args = "%s, v127, s[98:99]" % m.group(1)
+        out.append((op, args))
+    return out
+
+
+def used_regs(body):
+    v, s = set(), set()
+    for _, args in body:
+        for m in re.finditer(r"\bv\[(\d+):(\d+)\]", args):
+            v.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        for m in re.finditer(r"\bv(\d+)\b", args):
+            v.add(int(m.group(1)))
+        for m in re.finditer(r"\bs\[(\d+):(\d+)\]", args):
+            s.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        for m in re.finditer(r"\bs(\d+)\b", args):
+            s.add(int(m.group(1)))
+    return v, s
+
+
+def is_slow(op, args):
+    return isa_cadence.is_slow(op, args)
+
+
+def v_as_compiled(body):
+    return list(body)
+
+
+def v_sep(body):
+    out = []
+    for k, (op, args) in enumerate(body):
+        out.append((op, args))
+        if is_slow(op, args) and k + 1 < len(body) and body[k + 1][0].startswith("v_"):
+            out.append(("s_nop", "0"))
+    return out
+
+
+def sep_with(sep_op, sep_args, only_before_fast=False):
+    def f(body):
+        out = []
+        for k, (op, args) in enumerate(body):
+            out.append((op, args))
+            if is_slow(op, args) and k + 1 < len(body) and body[k + 1][0].startswith("v_"):
+                if only_before_fast and is_slow(*body[k + 1]):
+                    continue
+                out.append((sep_op, sep_args))
+        return out
+    return f
+
+
+def compose(*fs):
+    def f(body):
+        for g in fs:
+            body = g(body)
+        return body
+    return f
+
+
+def v_sep_all(body):
+    out = []
+    for op, args in body:
+        out.append((op, args))
+        if is_slow(op, args):
+            out.append(("s_nop", "0"))
+    return out
+
+
+def v_no_lds(body):
+    return [(o, a) for o, a in body if not o.startswith("ds_")]
+
+
+def v_no_vmem(body):
+    return [(o, a) for o, a in body if not o.startswith("global_")]
+
+
+def v_only_valu(body):
+    return [(o, a) for o, a in body if o.startswith("v_")]
+
+
+def v_only_valu_sep(body):
+    return v_sep(v_only_valu(body))
+
+
+def v_valu_salu(body):
+    return [(o, a) for o, a in body if o.startswith("v_") or (o.startswith("s_") and not o.startswith("s_waitcnt"))]
+
+
+def v_no_wait(body):
+    return [(o, a) for o, a in body if not o.startswith("s_waitcnt")]
+
+
+def v_fast_only(body):
+    """only the fast-class VALU instructions (what they cost alone)"""
+    return [(o, a) for o, a in body if o.startswith("v_") and not is_slow(o, a)]
+
+
+def v_slow_only(body):
+    return [(o, a) for o, a in body if o.startswith("v_") and is_slow(o, a)]
+
+
+VARIANTS = {"as_compiled": v_as_compiled, "sep": v_sep, "sep_all": v_sep_all, "no_lds": v_no_lds, "no_vmem": v_no_vmem,
+            "only_valu": v_only_valu, "only_valu_sep": v_only_valu_sep, "valu_salu": v_valu_salu, "no_wait": v_no_wait,
+            "fast_only": v_fast_only, "slow_only": v_slow_only}
+NOWAIT = ("s_waitcnt", "vmcnt(63) expcnt(7) lgkmcnt(15)")
+for _n, _sep in (("w", NOWAIT), ("p", ("s_setprio", "0")), ("m", ("s_mov_b32", "s97, s97")), ("n", ("s_nop", "0"))):
+    VARIANTS["valu_sep_" + _n] = compose(v_only_valu, sep_with(*_sep))
+    VARIANTS["valu_sepf_" + _n] = compose(v_only_valu, sep_with(*_sep, only_before_fast=True))
+    VARIANTS["nolds_sep_" + _n] = compose(v_no_lds, sep_with(*_sep))
+    VARIANTS["nolds_sepf_" + _n] = compose(v_no_lds, sep_with(*_sep, only_before_fast=True))
+
+TEMPLATE = """\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"
+\t.amdhsa_code_object_version 6
+\t.text
+\t.globl\treplay
+\t.p2align\t8
+\t.type\treplay,@function
+replay:
+\ts_load_dwordx2 s[98:99], s[0:1], 0x0
+\ts_load_dword s100, s[0:1], 0x8
+\tv_and_b32_e32 v127, 63, v0
+\tv_lshlrev_b32_e32 v127, 2, v127
+{init}
+\ts_waitcnt lgkmcnt(0)
+.Lloop:
+{body}
+\ts_sub_u32 s100, s100, 1
+\ts_cmp_lg_u32 s100, 0
+\ts_cbranch_scc1 .Lloop
+\ts_waitcnt vmcnt(0) lgkmcnt(0)
+\ts_endpgm
+.Lend:
+\t.size\treplay, .Lend-replay
+\t.rodata
+\t.p2align\t6
+\t.amdhsa_kernel replay
+\t\t.amdhsa_group_segment_fixed_size {lds}
+\t\t.amdhsa_private_segment_fixed_size 0
+\t\t.amdhsa_kernarg_size 16
+\t\t.amdhsa_user_sgpr_count 2
+\t\t.amdhsa_user_sgpr_kernarg_segment_ptr 1
+\t\t.amdhsa_system_sgpr_workgroup_id_x 1
+\t\t.amdhsa_system_vgpr_workitem_id 0
+\t\t.amdhsa_next_free_vgpr 128
+\t\t.amdhsa_next_free_sgpr 102
+\t\t.amdhsa_accum_offset 128
+\t\t.amdhsa_reserve_vcc 1
+\t\t.amdhsa_float_denorm_mode_32 3
+\t\t.amdhsa_float_denorm_mode_16_64 3
+\t\t.amdhsa_dx10_clamp 1
+\t\t.amdhsa_ieee_mode 1
+\t.end_amdhsa_kernel
+\t.text
+\t.amdgpu_metadata
+---
+amdhsa.kernels:
+  - .agpr_count:     0
+    .args:
+      - .address_space:  global
+        .offset:         0
+        .size:           8
+        .value_kind:     global_buffer
+      - .offset:         8
+        .size:           4
+        .value_kind:     by_value
+    .group_segment_fixed_size: {lds}
+    .kernarg_segment_align: 8
+    .kernarg_segment_size: 16
+    .max_flat_workgroup_size: 1024
+    .name:           replay
+    .private_segment_fixed_size: 0
+    .sgpr_count:     108
+    .sgpr_spill_count: 0
+    .symbol:         replay.kd
+    .uniform_work_group_size: 1
+    .uses_dynamic_stack: false
+    .vgpr_count:     128
+    .vgpr_spill_count: 0
+    .wavefront_size: 64
+amdhsa.target:   amdgcn-amd-amdhsa--gfx950
+amdhsa.version:
+  - 1
+  - 2
+...
+\t.end_amdgpu_metadata
+"""
+
+
+def emit(body, vregs, sregs, lds):
+    init = []
+    for r in sorted(vregs):
+        if r in (0, 127):
+            continue
+        init.append("\tv_mul_u32_u24_e32 v%d, %d, v0" % (r, 2654435 + 977 * r))
+    for r in sorted(sregs):
+        if r in (0, 1) or r >= 98:
+            continue
+        init.append("\ts_mov_b32 s%d, 0x%x" % (r, (0x9E3779B9 * (r + 3)) & 0xFFFF))
+    text = "\n".join("\t%s %s" % (o, a) for o, a in body)
+    return TEMPLATE.format(init="\n".join(init), body=text, lds=lds)
+
+
+HOST = r'''// replay_host.cpp -- loads a code object made by tools/ubench/replay_loop.py and times its kernel `replay`:
+//   replay_host <file.co> [iters]  ->  SIMD-cycles per wave-iteration at four waves per SIMD (2.4 GHz assumed)
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+int main(int argc, char **argv) {
+    if (argc < 2) return 2;
+    const int iters = argc > 2 ? atoi(argv[2]) : 2000;
+    hipDeviceProp_t p;
+    CHK(hipGetDeviceProperties(&p, 0));
+    hipModule_t mod;
+    hipFunction_t fn;
+    CHK(hipModuleLoad(&mod, argv[1]));
+    CHK(hipModuleGetFunction(&fn, mod, "replay"));
+    void *buf;
+    CHK(hipMalloc(&buf, 1 << 20));
+    CHK(hipMemset(buf, 0, 1 << 20));
+    struct { void *p; int iters; int pad; } args = {buf, 20, 0};
+    size_t sz = sizeof args;
+    void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+    hipEvent_t e0, e1;
+    CHK(hipEventCreate(&e0));
+    CHK(hipEventCreate(&e1));
+    CHK(hipModuleLaunchKernel(fn, p.multiProcessorCount, 1, 1, 1024, 1, 1, 0, 0, nullptr, cfg));
+    CHK(hipDeviceSynchronize());
+    args.iters = iters;
+    CHK(hipEventRecord(e0));
+    CHK(hipModuleLaunchKernel(fn, p.multiProcessorCount, 1, 1, 1024, 1, 1, 0, 0, nullptr, cfg));
+    CHK(hipEventRecord(e1));
+    CHK(hipEventSynchronize(e1));
+    float ms;
+    CHK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%-40s %8.3f ms  %8.1f SIMD-cycles per wave-iteration\n", argv[1], ms, ms * 1e-3 * 2.4e9 / (4.0 * iters));
+    return 0;
+}
+'''
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lib", default=os.path.join(isa_hist.ROOT, "neuron_poker_amd", "libmcq_hip.so"))
+    ap.add_argument("--kernel", default="mcq_eval_kernelILi0ELb0")
+    ap.add_argument("--nopp", type=int, default=5)
+    ap.add_argument("--ndeal", type=int, default=5)
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--variant", action="append", default=[])
+    ap.add_argument("--lds", type=int, default=115712)
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    body = loop_body(a.lib, a.kernel, a.nopp, a.ndeal)
+    vregs, sregs = used_regs([(o, a) for o, a in body if not o.startswith("global_load")])
+    if max(vregs) >= 127 or max(sregs) >= 98:
+        raise SystemExit("the loop uses v%d / s%d: the harness's own registers collide" % (max(vregs), max(sregs)))
+    for name in (a.variant or list(VARIANTS)):
+        b = VARIANTS[name](body)
+        n_valu = sum(1 for o, _ in b if o.startswith("v_"))
+        s_path = os.path.join(a.out, name + ".s")
+        with open(s_path, "w") as f:
+            f.write(emit(b, vregs, sregs, a.lds))
+        obj = os.path.join(a.out, name + ".o")
+        subprocess.check_call([LLVM + "/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", s_path, "-o", obj])
+        subprocess.check_call([LLVM + "/lld", "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", "-o",
+                               os.path.join(a.out, name + ".co"), obj])
+        os.remove(obj)
+        print("%-16s %4d instructions, %4d VALU" % (name, len(b), n_valu))
+    host = os.path.join(a.out, "replay_host.cpp")
+    with open(host, "w") as f:
+        f.write(HOST)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-o", os.path.join(a.out, "replay_host"), host])
+
+
+if __name__ == "__main__":
+    main()
