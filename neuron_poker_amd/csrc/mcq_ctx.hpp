@@ -146,6 +146,8 @@ struct mcq_ctx {
     size_t publish_max_rows = 8192; /* host-buffer calls of at most this many rows get them through mcq_publish_kernel + flag (MCQ_PUBLISH_MAX_ROWS, 0 = never) */
     bool timing = false; /* mcq_set_kernel_timing: launches carry timestamp events */
     int mt_blocks_margin = 8; /* state blocks beyond the estimate (MCQ_MT_BLOCKS_MARGIN; negative: the tests' way to the fall-back) */
+    bool mt_jump_always = false;
+    bool mt_jump = true;   /* ... their blocks generated in segments side by side, start states by jump-ahead (MCQ_MT_JUMP=0: one work-group per query) */
     bool mt_blocks = true; /* parity mode, few long queries: the state blocks of a query parsed side by side (MCQ_MT_BLOCKS=0: always the serial walk) */
     bool ext_small = true; /* a few extended queries of the production mode in one launch (MCQ_EXT_SMALL=0: always the general path) */
     size_t direct_uniform_min = 128; /* one-launch path: from this many queries on the kernel lays its own work out (MCQ_DIRECT_UNIFORM_MIN; measured: 512 queries 39 -> 33 us per call, 1024: 48 -> 42, 4096: 137 -> 113) */
@@ -172,6 +174,7 @@ struct McqMtbLaunch {
     uint32_t *d_gword, *d_gits;
     void *d_gentry;
     uint32_t *d_ovf;
+    uint32_t *d_part; /* the jumps' partial sums (mcq_mtb_part_words() words per query), or null: no jumps */
 };
 int mcq_run_slice(mcq_ctx *c, int mode, const mcq_query *d_q, uint32_t n, mcq_result *d_res, uint64_t seed,
                   uint64_t first_qid, uint64_t total_tasks, const uint8_t *d_draws, const uint64_t *d_off, hipStream_t s,

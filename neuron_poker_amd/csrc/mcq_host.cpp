@@ -155,7 +155,7 @@ int mcq_run_slice(mcq_ctx *c, int mode, const mcq_query *d_q, uint32_t n, mcq_re
         if (mtb)
             HIP_TRY(mcq_launch_mt_blocks(d_q, n, *mt_seed32, mtb->d_blk_off, mtb->d_grp_off, mtb->max_blocks, mtb->d_raw, mtb->d_exits,
                                          mtb->d_entries, mtb->d_gword, mtb->d_gits, mtb->d_gentry, mtb->d_ovf,
-                                         const_cast<uint8_t *>(d_draws), d_off, d_res, s));
+                                         const_cast<uint8_t *>(d_draws), d_off, d_res, mtb->d_part, s));
         else
             HIP_TRY(mcq_launch_mt_parse(d_q, n, *mt_seed32, const_cast<uint8_t *>(d_draws), d_off, d_res,
                                         const_cast<uint32_t *>(reinterpret_cast<const uint32_t *>(d_prefix + n + 2)),
@@ -242,7 +242,7 @@ int replay_batch_device(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed,
         if (allow_blocks && c->mt_blocks && m <= kMtbQueries && chunks.size() == 1) {
             HIP_TRY(c->h_misc.reserve(2 * (m + 1) * sizeof(uint32_t)));
             uint32_t *blk = (uint32_t *)c->h_misc.p, *grp = blk + m + 1; /* block / group offsets of the queries */
-            uint64_t total = 0, groups = 0;
+            uint64_t total = 0, groups = 0, jumps = 0;
             for (size_t i = 0; i < m; i++) {
                 const mcq_query &qq = q[ch.a + i];
                 blk[i] = (uint32_t)total;
@@ -253,15 +253,26 @@ int replay_batch_device(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed,
                     total += nb;
                     groups += (nb + MCQ_MTB_GROUP - 1u) / MCQ_MTB_GROUP;
                     if (nb > mtb.max_blocks) mtb.max_blocks = nb;
+                    jumps += (nb - 1u) / MCQ_MTB_SEG;
                 }
             }
             blk[m] = (uint32_t)total;
             grp[m] = (uint32_t)groups;
             const auto pad16 = [](uint64_t x) { return (x + 15u) & ~15ull; };
+            /* segments side by side pay when the jumps (6.2 M word-XORs each: eight work-groups for 15 us, i.e. 0.4 us of
+             * the whole GPU) and the three launches per round of 4096 blocks cost less than the longest query's blocks one
+             * behind the other (0.19 us each) -- measured: ONE 6-max 100 000-run query 0.99 -> 0.29 ms; 64 queries of 780
+             * blocks, all jumping: 1.18 -> 1.34 ms with the first jump kernel (49 us per 30 jumps) */
+            const uint64_t rounds = (mtb.max_blocks + MCQ_MTB_SEG * MCQ_MTB_MAX_SEG - 1u) / (MCQ_MTB_SEG * MCQ_MTB_MAX_SEG);
+            const bool use_jump = c->mt_jump && mtb.max_blocks > MCQ_MTB_SEG &&
+                                  (c->mt_jump_always || 45.0 * (double)rounds + 0.4 * (double)jumps < 0.19 * (double)mtb.max_blocks);
             const uint64_t o_ovf = pad16(2 * (m + 1) * 4), o_ent = o_ovf + pad16(m * 4),
                            o_gen = o_ent + pad16(total * sizeof(McqMtbEntry)), o_gw = o_gen + pad16(groups * sizeof(McqMtbEntry)),
                            o_gi = o_gw + groups * MCQ_MTB_LANES * 4u, o_ex = o_gi + groups * MCQ_MTB_LANES * 4u,
-                           o_raw = o_ex + total * MCQ_MTB_LANES * 4u, bytes = o_raw + total * MCQ_MT_N * 4u + 64u;
+                           o_raw = o_ex + total * MCQ_MTB_LANES * 4u, o_part = pad16(o_raw + total * MCQ_MT_N * 4u),
+                           /* (the segments' start states by jump-ahead: only a query of more than one segment has any) */
+                           part_bytes = use_jump ? m * mcq_mtb_part_words() * 4u : 0u,
+                           bytes = o_part + part_bytes + 64u;
             bool room = total >= kMtbMinBlocks && total <= kMtbMaxBlocks;
             if (room && c->d_mt.reserve(bytes) != hipSuccess) { /* no room for the blocks' scratch (2.7 KB per block): the
                                                                   * serial walk, which needs none, serves the call */
@@ -280,6 +291,7 @@ int replay_batch_device(mcq_ctx *c, const mcq_query *q, size_t n, uint64_t seed,
                 mtb.d_gits = (uint32_t *)(base + o_gi);
                 mtb.d_exits = (uint32_t *)(base + o_ex);
                 mtb.d_raw = (uint32_t *)(base + o_raw);
+                mtb.d_part = use_jump ? (uint32_t *)(base + o_part) : nullptr;
                 by_blocks = true;
             }
         }
@@ -404,6 +416,8 @@ mcq_ctx *mcq_ctx_clone(const mcq_ctx *c) {
         d->ext_small = c->ext_small;
         d->mt_blocks = c->mt_blocks;
         d->mt_blocks_margin = c->mt_blocks_margin;
+        d->mt_jump = c->mt_jump;
+        d->mt_jump_always = c->mt_jump_always;
         d->publish_max_rows = c->publish_max_rows;
         d->timing = c->timing;
         d->replay_device_bytes = c->replay_device_bytes;
@@ -494,6 +508,10 @@ mcq_ctx *mcq_create(int device, int flags) {
     if (const char *e = getenv("MCQ_EXT_SMALL")) c->ext_small = atoi(e) != 0; /* see mcq_eval_batch_ext */
     if (const char *e = getenv("MCQ_MT_BLOCKS")) c->mt_blocks = atoi(e) != 0;  /* see replay_batch_device */
     if (const char *e = getenv("MCQ_MT_BLOCKS_MARGIN")) c->mt_blocks_margin = atoi(e);
+    if (const char *e = getenv("MCQ_MT_JUMP")) {
+        c->mt_jump = atoi(e) != 0;
+        c->mt_jump_always = atoi(e) == 2; /* (tests: every query of more than one segment, whatever the estimate says) */
+    }
     if (const char *e = getenv("MCQ_DIRECT_UNIFORM_MIN")) { /* tuning knob, see eval_host_philox */
         const long v = atol(e);
         c->direct_uniform_min = (size_t)(v < 0 ? 0 : v);

@@ -73,7 +73,11 @@ hipError_t mcq_launch_mt_parse(const mcq_query *d_q, uint32_t n, uint32_t seed32
 hipError_t mcq_launch_mt_blocks(const mcq_query *d_q, uint32_t n, uint32_t seed32, const uint32_t *d_blk_off,
                                 const uint32_t *d_grp_off, uint32_t max_blocks, uint32_t *d_raw, uint32_t *d_exits, void *d_entries,
                                 uint32_t *d_gword, uint32_t *d_gits, void *d_gentry, uint32_t *d_ovf, uint8_t *d_draws,
-                                const uint64_t *d_draw_off, mcq_result *d_res, hipStream_t s);
+                                const uint64_t *d_draw_off, mcq_result *d_res,
+                                uint32_t *d_part /* n x mcq_mtb_part_words() words: the segments' start states by jump-ahead;
+                                                    null: one work-group per query makes all its blocks */,
+                                hipStream_t s);
+uint64_t mcq_mtb_part_words(void); /* per query */
 /* ... and for extended queries (mcq_mt_ext.hpp); d_counter zero (mcq_prep_ext_kernel leaves one behind its prefix); a
  * query whose range cannot be dealt gets passes = UINT64_MAX */
 hipError_t mcq_launch_mt_parse_ext(const mcq_query *d_q, const mcq_query_ext *d_ext, uint32_t n, uint32_t seed32, uint8_t *d_draws,

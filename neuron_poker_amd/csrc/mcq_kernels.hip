@@ -295,22 +295,56 @@ __global__ __launch_bounds__(kMtExtBlock) void mcq_mt_parse_ext_kernel(const mcq
 // (1.73 -> 0.6 ms for the 3 900 blocks of a 6-max 100 000-run query).  (x[623] needs the new x[0]: its thread makes that
 // one a second time.)  Two state buffers; three more waves copy the state the first four are reading to HBM as it is --
 // 2 496 B per block; the waves that read it temper it (mcq_mtb_load_block): off the chain, and side by side.
+//
+// Round 4: a query's blocks in SEGMENTS of MCQ_MTB_SEG, one work-group each, side by side.  The generator is linear over
+// GF(2): the state J words ahead is a fixed XOR combination of 19 937 + 623 consecutive words, the same for every seed
+// (mcq_mt_jump_table.inc: t^J mod the characteristic polynomial, made and checked against numpy by
+// tools/mt_jump_table.py).  Per round of MCQ_MTB_MAX_SEG segments, from base block `base` (state number `base`: the seed
+// state, or the last block of the round before): (a) this kernel, one work-group per query, makes the first 33 blocks --
+// the words every jump of the round combines; (b) mcq_mtb_jump_kernel: segment g's start state, kMtbJumpSplit work-groups
+// each XORing their share of the polynomial's terms over all 624 words (partial sums to HBM); (c) this kernel again, a
+// work-group per (segment, query): start state = the seed state / the block in front / the XOR of the partial sums.
+#define MCQ_MTB_TABLE_ATTR __device__ const
+#include "mcq_mt_jump_table.inc"
+constexpr uint32_t kMtbJumpSplit = 8, kMtbJumpWords = MCQ_MT_N / kMtbJumpSplit; /* 78 words of the polynomial per work-group */
+constexpr uint32_t kMtbJumpSpan = MCQ_MT_N / 32u + 14u; /* blocks whose words a round's jumps read: 19 937 + 623 words = 33 */
+static_assert(kMtbJumpSplit * kMtbJumpWords == MCQ_MT_N && kMtbJumpWords % 2u == 0u, "the polynomial's words split evenly, in pairs");
+static_assert(kMtbJumpSpan * MCQ_MT_N >= 32u * MCQ_MT_N + MCQ_MT_N - 1u && kMtbJumpSpan == 33u && kMtbJumpSpan <= MCQ_MTB_SEG, "words 0 .. 20 590");
 constexpr int kMtbGenBlock = 512;
+/* part: [query][segment - 1][kMtbJumpSplit][624] partial sums of the jumps (mcq_mtb_jump_kernel).  limit: blocks a
+ * work-group makes at most (kMtbJumpSpan for step (a), MCQ_MTB_SEG for step (c)) */
 __global__ __launch_bounds__(kMtbGenBlock) void mcq_mtb_generate_kernel(const uint32_t *__restrict__ blk_off, uint32_t seed32,
-                                                                       uint32_t *__restrict__ raw) {
+                                                                       uint32_t *__restrict__ raw, const uint32_t *__restrict__ part,
+                                                                       uint32_t base, uint32_t limit, uint32_t for_jumps) {
     __shared__ __attribute__((aligned(16))) uint32_t mt[2][MCQ_MT_N + 8u];
-    const uint32_t qi = blockIdx.x, tid = threadIdx.x, first = blk_off[qi], nb = blk_off[qi + 1u] - first;
-    if (nb == 0u) return; /* (block-uniform) */
-    if (tid == 0) { /* np.random.seed: init_genrand, a serial recurrence */
-        uint32_t x = seed32 + qi;
-        mt[0][0] = x;
-        for (uint32_t i = 1; i < MCQ_MT_N; i++) {
-            x = 1812433253u * (x ^ (x >> 30)) + i;
+    const uint32_t qi = blockIdx.y, g = blockIdx.x, tid = threadIdx.x, first = blk_off[qi], nb_q = blk_off[qi + 1u] - first;
+    const uint32_t start = base + g * MCQ_MTB_SEG;
+    if (start >= nb_q) return; /* (block-uniform) */
+    if (for_jumps && nb_q - base <= MCQ_MTB_SEG) return; /* step (a) of a query with one segment: no jump reads it */
+    const uint32_t nb = nb_q - start < limit ? nb_q - start : limit;
+    if (start == 0u) {
+        if (tid == 0) { /* np.random.seed: init_genrand, a serial recurrence */
+            uint32_t x = seed32 + qi;
+            mt[0][0] = x;
+            for (uint32_t i = 1; i < MCQ_MT_N; i++) {
+                x = 1812433253u * (x ^ (x >> 30)) + i;
+                mt[0][i] = x;
+            }
+        }
+    } else if (g == 0u) { /* a later round: the block in front */
+        const uint32_t *src = raw + (uint64_t)(first + start - 1u) * MCQ_MT_N;
+        for (uint32_t i = tid; i < MCQ_MT_N; i += kMtbGenBlock) mt[0][i] = src[i];
+    } else { /* the jump's partial sums */
+        const uint32_t *src = part + ((uint64_t)qi * (MCQ_MTB_MAX_SEG - 1u) + (g - 1u)) * kMtbJumpSplit * MCQ_MT_N;
+        for (uint32_t i = tid; i < MCQ_MT_N; i += kMtbGenBlock) {
+            uint32_t x = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < kMtbJumpSplit; w++) x ^= src[w * MCQ_MT_N + i];
             mt[0][i] = x;
         }
     }
     __syncthreads();
-    uint32_t *dst = raw + (uint64_t)first * MCQ_MT_N;
+    uint32_t *dst = raw + (uint64_t)(first + start) * MCQ_MT_N;
     /* two loops with the same barriers: the waves that make the state, the waves that copy it out */
     if (tid < 256u) { /* (wave-uniform) */
         /* every read up front, none behind a condition on the thread (indices clamped instead): ONE round trip to LDS per
@@ -339,11 +373,98 @@ __global__ __launch_bounds__(kMtbGenBlock) void mcq_mtb_generate_kernel(const ui
         }
     } else {
         const uint32_t t = tid - 256u;
-        for (uint32_t b = 0; b <= nb; b++) { /* the query's block b - 1 = state b */
+        for (uint32_t b = 0; b <= nb; b++) { /* the segment's block b - 1 = state b */
             if (b >= 1u && t < MCQ_MT_N / 4u)
                 reinterpret_cast<uint4 *>(dst + (uint64_t)(b - 1u) * MCQ_MT_N)[t] = *reinterpret_cast<const uint4 *>(mt[b & 1u] + 4u * t);
             __syncthreads();
         }
+    }
+}
+
+// 1b. jump: work-group (segment g >= 1, share w) of a query: out[j] = XOR over the set coefficients i of its 78 words of
+// the polynomial of y[i + j], j < 624 -- y = the round's first 33 blocks.  The floor is LDS bandwidth (6.2 M word reads per
+// jump), so the reads are 16 bytes wide: a lane owns j = 4 l .. 4 l + 3 (+ 256, + 512) and reads y[i + 4 l ..] with ONE
+// ds_read_b128 -- aligned whatever i is, because the share's window of y lies in LDS four times, shifted by 0 .. 3 words.
+// The set coefficients are laid out once per work-group as a list of byte offsets (copy + aligned position) in LDS, so a
+// term costs no scalar bit scan: a broadcast read serves eight terms, each term one address add, three wide reads and
+// twelve XORs.  Sixteen waves take the list's terms in turn and add their sums up through LDS.
+constexpr int kMtbJumpBlock = 1024;
+constexpr uint32_t kMtbJumpTerms = kMtbJumpWords * 32u;           /* coefficients of a share: 2496 */
+constexpr uint32_t kMtbJumpCopy = kMtbJumpTerms + 768u;           /* words of one copy of the window: terms + the lanes' offsets */
+__global__ __launch_bounds__(kMtbJumpBlock) void mcq_mtb_jump_kernel(const uint32_t *__restrict__ blk_off,
+                                                                    const uint32_t *__restrict__ raw, uint32_t *__restrict__ part,
+                                                                    uint32_t base) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_y[4][kMtbJumpCopy]; /* s_y[c][k] = y[i_lo + k + c]; later: the waves' sums */
+    __shared__ __attribute__((aligned(16))) uint16_t s_list[kMtbJumpTerms + 8u * (kMtbJumpBlock / 64)];
+    __shared__ uint32_t s_cnt[kMtbJumpWords + 1u], s_pop[kMtbJumpWords];
+    static_assert(sizeof(s_y) >= (kMtbJumpBlock / 64) * 768u * 4u, "the sums of sixteen waves fit where the window was");
+    static_assert(4u * kMtbJumpCopy * 4u < 65536u, "byte offsets as 16-bit words");
+    const uint32_t qi = blockIdx.y, g = blockIdx.x / kMtbJumpSplit + 1u, w = blockIdx.x % kMtbJumpSplit, tid = threadIdx.x;
+    const uint32_t lane = tid & 63u, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t first = blk_off[qi], nb_q = blk_off[qi + 1u] - first;
+    if (base + g * MCQ_MTB_SEG >= nb_q) return; /* (block-uniform) */
+    const uint32_t i_lo = w * kMtbJumpTerms;
+    const uint32_t *src = raw + (uint64_t)(first + base) * MCQ_MT_N;
+    constexpr uint32_t kSpanWords = kMtbJumpSpan * MCQ_MT_N;
+    for (uint32_t k = tid; k < kMtbJumpCopy + 3u; k += kMtbJumpBlock) {
+        const uint32_t v = i_lo + k < kSpanWords ? src[i_lo + k] : 0u;
+#pragma unroll
+        for (uint32_t c = 0; c < 4u; c++)
+            if (k >= c && k - c < kMtbJumpCopy) s_y[c][k - c] = v;
+    }
+    const uint32_t *gw = kMtJump[g - 1u] + w * kMtbJumpWords;
+    if (tid < kMtbJumpWords) s_pop[tid] = (uint32_t)__builtin_popcount(gw[tid]);
+    __syncthreads();
+    if (tid <= kMtbJumpWords) { /* terms in front of word tid: independent reads, no chain */
+        uint32_t x = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kMtbJumpWords; k++) x += k < tid ? s_pop[k] : 0u;
+        s_cnt[tid] = x;
+    }
+    __syncthreads();
+    const uint32_t n_terms = s_cnt[kMtbJumpWords];
+    for (uint32_t t = tid; t < kMtbJumpTerms; t += kMtbJumpBlock) {
+        const uint32_t word = gw[t >> 5], bit = t & 31u;
+        if ((word >> bit) & 1u) {
+            const uint32_t c = t & 3u;
+            s_list[s_cnt[t >> 5] + (uint32_t)__builtin_popcount(word & ((1u << bit) - 1u))] = (uint16_t)((c * kMtbJumpCopy + (t - c)) * 4u);
+        }
+    }
+    /* padding: a wave reads its terms eight at a time; the terms behind the last point at ... a term twice = no term */
+    if (tid < 8u * (kMtbJumpBlock / 64)) s_list[n_terms + tid] = 0xFFFFu;
+    __syncthreads();
+    uint4 acc[3] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+    const char *ybase = reinterpret_cast<const char *>(&s_y[0][0]) + 16u * lane;
+    /* wave wv takes the terms 8 (16 k + wv) .. + 8 */
+    for (uint32_t t0 = 8u * wv; t0 < n_terms; t0 += 8u * (kMtbJumpBlock / 64)) {
+        const uint4 pkv = *reinterpret_cast<const uint4 *>(s_list + t0); /* (a broadcast read; into scalar registers) */
+        const uint32_t pk[4] = {(uint32_t)__builtin_amdgcn_readfirstlane(pkv.x), (uint32_t)__builtin_amdgcn_readfirstlane(pkv.y),
+                                (uint32_t)__builtin_amdgcn_readfirstlane(pkv.z), (uint32_t)__builtin_amdgcn_readfirstlane(pkv.w)};
+        const uint32_t off[8] = {pk[0] & 0xFFFFu, pk[0] >> 16, pk[1] & 0xFFFFu, pk[1] >> 16, pk[2] & 0xFFFFu, pk[2] >> 16, pk[3] & 0xFFFFu, pk[3] >> 16};
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++) {
+            if (off[u] == 0xFFFFu) break; /* (wave-uniform: behind the list's end) */
+            const char *p = ybase + off[u];
+#pragma unroll
+            for (uint32_t h = 0; h < 3u; h++) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(p + 1024u * h);
+                acc[h].x ^= v.x;
+                acc[h].y ^= v.y;
+                acc[h].z ^= v.z;
+                acc[h].w ^= v.w;
+            }
+        }
+    }
+    __syncthreads(); /* the window has been read for the last time */
+    uint32_t *sums = &s_y[0][0]; /* [wave][768] */
+#pragma unroll
+    for (uint32_t h = 0; h < 3u; h++) *reinterpret_cast<uint4 *>(sums + wv * 768u + 256u * h + 4u * lane) = acc[h];
+    __syncthreads();
+    if (tid < MCQ_MT_N) {
+        uint32_t x = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kMtbJumpBlock / 64; k++) x ^= sums[k * 768u + tid];
+        part[(((uint64_t)qi * (MCQ_MTB_MAX_SEG - 1u) + (g - 1u)) * kMtbJumpSplit + w) * MCQ_MT_N + tid] = x;
     }
 }
 
@@ -369,16 +490,23 @@ __device__ __forceinline__ McqMtbPlan mcq_mtb_plan_of(const mcq_query *__restric
 __global__ __launch_bounds__(kMtbBlock) void mcq_mtb_scan_kernel(const mcq_query *__restrict__ queries,
                                                                 const uint32_t *__restrict__ blk_off,
                                                                 const uint32_t *__restrict__ raw, uint32_t *__restrict__ exits) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_yb[kMtbBlock / 64][MCQ_MT_N + 64u];
+    /* a block has at most MCQ_MTB_LANES = 32 entry states: a wave takes TWO blocks, one per half (round 4: the automaton is
+     * bound by vector issue, and half of every instruction's lanes were idle) */
+    __shared__ __attribute__((aligned(16))) uint8_t s_yb[kMtbBlock / 64][2][MCQ_MT_N + 64u];
     __shared__ uint32_t s_pos[kMtbBlock / 64][MCQ_MTB_POS];
+    static_assert(MCQ_MTB_LANES == 32u, "two blocks per wave");
     const uint32_t qi = blockIdx.y, lane = threadIdx.x & 63u, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t first = blk_off[qi], nb = blk_off[qi + 1u] - first, b = blockIdx.x * (kMtbBlock / 64) + wv;
-    if (b >= nb) return; /* (wave-uniform; no block barrier below) */
+    const uint32_t first = blk_off[qi], nb = blk_off[qi + 1u] - first, b0 = 2u * (blockIdx.x * (kMtbBlock / 64) + wv);
+    if (b0 >= nb) return; /* (wave-uniform; no block barrier below) */
     const McqMtbPlan pl = mcq_mtb_plan_of(queries, qi);
     if (lane < MCQ_MTB_POS) s_pos[wv][lane] = mcq_mtb_pos_word(pl, lane < pl.D ? lane : 0u);
-    mcq_mtb_load_block(raw + (uint64_t)(first + b) * MCQ_MT_N, s_yb[wv], lane); /* (ends with a wave barrier) */
-    const uint32_t x = mcq_mtb_automaton(s_yb[wv], s_pos[wv], pl, lane);
-    if (lane < MCQ_MTB_LANES) exits[(uint64_t)(first + b) * MCQ_MTB_LANES + lane] = x;
+    mcq_mtb_load_block(raw + (uint64_t)(first + b0) * MCQ_MT_N, s_yb[wv][0], lane); /* (ends with a wave barrier) */
+    const bool two = b0 + 1u < nb;
+    if (two) mcq_mtb_load_block(raw + (uint64_t)(first + b0 + 1u) * MCQ_MT_N, s_yb[wv][1], lane);
+    const uint32_t half = lane >> 5;
+    if (half != 0u && !two) return;
+    const uint32_t x = mcq_mtb_automaton(s_yb[wv][half], s_pos[wv], pl, lane & 31u);
+    exits[(uint64_t)(first + b0 + half) * MCQ_MTB_LANES + (lane & 31u)] = x;
 }
 
 // 3. stitch, in two levels (mcq_mt_blocks.hpp).  grp_off[q] .. grp_off[q + 1]: the query's groups of MCQ_MTB_GROUP blocks.
@@ -1654,16 +1782,34 @@ hipError_t mcq_launch_mt_parse(const mcq_query *d_q, uint32_t n, uint32_t seed32
     return hipGetLastError();
 }
 
+uint64_t mcq_mtb_part_words(void) { return (uint64_t)(MCQ_MTB_MAX_SEG - 1u) * kMtbJumpSplit * MCQ_MT_N; }
 hipError_t mcq_launch_mt_blocks(const mcq_query *d_q, uint32_t n, uint32_t seed32, const uint32_t *d_blk_off,
                                 const uint32_t *d_grp_off, uint32_t max_blocks, uint32_t *d_raw, uint32_t *d_exits, void *d_entries,
                                 uint32_t *d_gword, uint32_t *d_gits, void *d_gentry, uint32_t *d_ovf, uint8_t *d_draws,
-                                const uint64_t *d_draw_off, mcq_result *d_res, hipStream_t s) {
+                                const uint64_t *d_draw_off, mcq_result *d_res, uint32_t *d_part, hipStream_t s) {
     if (n == 0 || max_blocks == 0) return hipSuccess;
     constexpr uint32_t kWaves = kMtbBlock / 64;
     const uint32_t max_groups = (max_blocks + MCQ_MTB_GROUP - 1u) / MCQ_MTB_GROUP;
     const dim3 per_block((max_blocks + kWaves - 1) / kWaves, n), per_group((max_groups + kWaves - 1) / kWaves, n);
-    hipLaunchKernelGGL(mcq_mtb_generate_kernel, dim3(n), dim3(kMtbGenBlock), 0, s, d_blk_off, seed32, d_raw);
-    hipLaunchKernelGGL(mcq_mtb_scan_kernel, per_block, dim3(kMtbBlock), 0, s, d_q, d_blk_off, d_raw, d_exits);
+    const dim3 per_two_blocks((max_blocks + 2u * kWaves - 1) / (2u * kWaves), n);
+    if (!d_part) { /* no jumps (MCQ_MT_JUMP=0): one work-group per query makes all its blocks, one behind the other */
+        hipLaunchKernelGGL(mcq_mtb_generate_kernel, dim3(1, n), dim3(kMtbGenBlock), 0, s, d_blk_off, seed32, d_raw, d_part, 0u,
+                           max_blocks, 0u);
+    } else {
+        constexpr uint32_t kRound = MCQ_MTB_SEG * MCQ_MTB_MAX_SEG;
+        for (uint32_t base = 0; base < max_blocks; base += kRound) {
+            const uint32_t left = max_blocks - base, segs = left >= kRound ? MCQ_MTB_MAX_SEG : (left + MCQ_MTB_SEG - 1u) / MCQ_MTB_SEG;
+            if (segs > 1u) {
+                hipLaunchKernelGGL(mcq_mtb_generate_kernel, dim3(1, n), dim3(kMtbGenBlock), 0, s, d_blk_off, seed32, d_raw, d_part,
+                                   base, kMtbJumpSpan, 1u);
+                hipLaunchKernelGGL(mcq_mtb_jump_kernel, dim3((segs - 1u) * kMtbJumpSplit, n), dim3(kMtbJumpBlock), 0, s, d_blk_off,
+                                   d_raw, d_part, base);
+            }
+            hipLaunchKernelGGL(mcq_mtb_generate_kernel, dim3(segs, n), dim3(kMtbGenBlock), 0, s, d_blk_off, seed32, d_raw, d_part,
+                               base, (uint32_t)MCQ_MTB_SEG, 0u);
+        }
+    }
+    hipLaunchKernelGGL(mcq_mtb_scan_kernel, per_two_blocks, dim3(kMtbBlock), 0, s, d_q, d_blk_off, d_raw, d_exits);
     hipLaunchKernelGGL(mcq_mtb_compose_kernel, per_group, dim3(kMtbBlock), 0, s, d_q, d_blk_off, d_grp_off, d_exits, d_gword, d_gits);
     hipLaunchKernelGGL(mcq_mtb_stitch_kernel, dim3(n), dim3(64), 0, s, d_q, d_blk_off, d_grp_off, d_gword, d_gits,
                        reinterpret_cast<McqMtbEntry *>(d_gentry), d_ovf, d_res);

@@ -184,6 +184,41 @@ def test_replay_few_long_queries_by_state_blocks(eng, monkeypatch):
             e3.close()
 
 
+def test_replay_state_blocks_in_segments_by_jump_ahead(eng, monkeypatch):
+    """Round 4: a query's state blocks are generated in segments of 128 side by side, segment g's start state by
+    jump-ahead (csrc/mcq_mt_jump_table.inc: a fixed XOR combination of the round's first 33 blocks).  One segment (no
+    jump), a few, all 32 of a round, and more than one round (> 4096 blocks: the next round starts from the last block
+    of the one before); equal to the oracle's literal walk and to the one-work-group generator (MCQ_MT_JUMP=0)."""
+    g = np.random.default_rng(404)
+    cases = [(2, 3000, 0), (6, 100000, 0), (10, 125000, 0), (3, 260000, 3), (2, 100000, 0), (9, 40000, 4)]
+    hole = np.zeros((len(cases), 2), np.uint8)
+    board = np.full((len(cases), 5), 255, np.uint8)
+    for i, (_, _, nb) in enumerate(cases):
+        c = g.permutation(52)[:2 + nb]
+        hole[i] = c[:2]
+        board[i, :nb] = c[2:]
+    q = npa.pack_queries(hole, board, [c[0] for c in cases], [c[1] for c in cases])
+    first = 2 ** 32 - 3
+    exp = O.run_batch(O.MODE_MT, q.view(np.uint8).reshape(-1, 16), 11, first, threads=8)
+    got = u64(eng.eval_batch(q, seed=11, first_query_id=first, mode=npa.MODE_REPLAY_MT19937))
+    assert np.array_equal(got, exp)
+    for i in (1, 2):   # alone: the grid has one query
+        one = u64(eng.eval_batch(q[i:i + 1], seed=11, first_query_id=first + i, mode=npa.MODE_REPLAY_MT19937))
+        assert np.array_equal(one, exp[i:i + 1])
+    for jump in ("0", "2"):   # never / whenever a query has more than one segment (the default goes by a cost estimate)
+        monkeypatch.setenv("MCQ_MT_JUMP", jump)
+        e2 = npa.Engine(0)
+        try:
+            assert np.array_equal(u64(e2.eval_batch(q, seed=11, first_query_id=first, mode=npa.MODE_REPLAY_MT19937)), exp)
+            if jump == "2":   # many queries of a few segments each: the estimate alone would not jump
+                s = np.arange(40) % len(cases)
+                qs = npa.pack_queries(hole[s], board[s], [cases[k][0] for k in s], np.full(40, 9000))
+                ex2 = O.run_batch(O.MODE_MT, qs.view(np.uint8).reshape(-1, 16), 5, 77, threads=8)
+                assert np.array_equal(u64(e2.eval_batch(qs, seed=5, first_query_id=77, mode=npa.MODE_REPLAY_MT19937)), ex2)
+        finally:
+            e2.close()
+
+
 # ------------------------------------------------------------------------------------------ production mode
 def test_philox_equals_oracle_ctr_bit_exact(eng):
     g = np.random.default_rng(5)
