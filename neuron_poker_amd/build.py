@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def build(verbose=False):
-    cmd = ["make", "-C", os.path.join(HERE, "csrc")]
+    cmd = ["make", "-j4", "-C", os.path.join(HERE, "csrc")]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or res.returncode:
         sys.stdout.write(res.stdout)

@@ -268,14 +268,10 @@ def build_variant(define, workdir):
 
 
 def kernel_sources_sha256():
-    h = hashlib.sha256()
-    d = os.path.join(ROOT, "neuron_poker_amd", "csrc")
-    for f in ("mcq_kernels.hip", "mcq_device.hpp", "mcq_mt.hpp", "mcq_mt_ext.hpp", "mcq_mt_blocks.hpp", "mcq_exact.hpp"):
-        p = os.path.join(d, f)
-        if os.path.exists(p):
-            with open(p, "rb") as fh:
-                h.update(fh.read())
-    return h.hexdigest()
+    """the same hash bench.py ties profiles/ to (bench.kernel_source_hash)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    return bench.kernel_source_hash()
 
 
 def main():

@@ -1,0 +1,472 @@
+#!/usr/bin/env python3
+"""Post-pass over gfx950 assembly: (1) three-operand logic ops of the 4-cycle class rewritten as v_bitop3_b32 (2-cycle
+class, same VOP3 encoding and operand rules), (2) the VALU instructions BETWEEN two non-VALU instructions re-ordered so
+that the fast class comes first.
+
+Why (tools/ubench/gen_issue_probe*.py, profiles/r07_issue_probe*.txt, tools/isa_cadence.py): once a wave has issued a
+slow-class VALU instruction, every following VALU instruction of that wave goes at the 4-cycle cadence until a non-VALU
+instruction comes by.  The compiler's schedule knows nothing of it: in the bulk kernel's iteration 197 of 261 fast-class
+instructions sit behind a slow one of the same run.  Inside a run -- a maximal sequence of VALU instructions with no
+other instruction between them -- the order is free up to register dependencies: nothing else (waits, LDS and memory
+instructions, scalar instructions, branches, the compiler's s_nop hazard padding) is crossed, so every wait state and
+every counter the compiler arranged stays as it is.  Emitted order of a run: first the fast-class instructions that depend
+on no slow-class instruction of the run (original order), then the rest in original order -- optionally with a
+separator (`s_nop 0`) wherever a fast-class instruction would follow a slow-class one.
+
+Left alone (they end a run like a non-VALU instruction): SDWA and DPP forms (forwarding hazards of their partial writes),
+v_readlane / v_readfirstlane / v_writelane, v_cmpx, anything whose operands this pass cannot name.
+
+    python tools/isa_resched.py in.s out.s [--only mcq_eval_kernel] [--bitop3] [--reorder] [--sep] [--stats]
+"""
+import argparse
+import re
+import sys
+
+import isa_cadence
+
+INS = isa_cadence.INS
+BITOP3 = {"v_or3_b32": "0xfe", "v_and_or_b32": "0xec", "v_bfi_b32": "0xca"}
+# truth tables (a = 0xf0, b = 0xcc, c = 0xaa): a | b | c; (a & b) | c; (a & b) | (~a & c)
+assert (0xF0 | 0xCC | 0xAA) == 0xFE and ((0xF0 & 0xCC) | 0xAA) == 0xEA and ((0xF0 & 0xCC) | (0x0F & 0xAA)) == 0xCA
+BITOP3["v_and_or_b32"] = "0xea"
+
+REG = re.compile(r"\b(?:(v|s|a)\[(\d+):(\d+)\]|(v|s|a)(\d+)\b|(vcc_lo|vcc_hi|exec_lo|exec_hi|vcc|exec|m0|scc)\b)")
+TWO_DST = ("v_mad_u64_u32", "v_mad_i64_i32", "v_add_co_u32", "v_sub_co_u32", "v_subrev_co_u32", "v_addc_co_u32",
+           "v_subb_co_u32", "v_subbrev_co_u32", "v_div_scale_f32", "v_div_scale_f64")
+PINNED = ("v_rcp", "v_rsq", "v_sqrt", "v_exp", "v_log", "v_sin", "v_cos", "v_readlane", "v_readfirstlane", "v_writelane", "v_cmpx", "v_permlane", "v_mfma", "v_accvgpr", "v_swap",
+          "v_div_", "v_dot", "v_pk_", "v_cvt_", "v_mov_b64", "v_lshlrev_b64", "v_lshrrev_b64", "v_ashrrev_i64")
+
+
+def regs_of(text):
+    out = set()
+    for m in REG.finditer(text):
+        if m.group(1):
+            out.update("%s%d" % (m.group(1), k) for k in range(int(m.group(2)), int(m.group(3)) + 1))
+        elif m.group(4):
+            out.add("%s%s" % (m.group(4), m.group(5)))
+        else:
+            g = m.group(6)
+            out.add("vcc" if g.startswith("vcc") else "exec" if g.startswith("exec") else g)
+    return out
+
+
+def split_operands(args):
+    args = re.sub(r"\s*//.*$", "", args).strip()
+    # modifiers behind the operand list (bitop3:0x.., op_sel:[..], clamp ...) carry no registers
+    parts = [p.strip() for p in args.split(",")]
+    return parts
+
+
+def rw(op, args):
+    """(reads, writes) of a VALU instruction, or None if this pass leaves it where it is"""
+    if not op.startswith("v_") or op.endswith("_sdwa") or op.endswith("_dpp") or op.startswith(PINNED):
+        return None
+    base = isa_cadence.base_of(op)
+    parts = split_operands(args)
+    if not parts or not parts[0]:
+        return None
+    n_dst = 2 if base in TWO_DST and op.endswith("_e64") or base in ("v_mad_u64_u32", "v_mad_i64_i32") else 1
+    if base in TWO_DST and op.endswith("_e32"):
+        n_dst = 2  # vdst, vcc, ...
+    writes, reads = set(), set()
+    for k, p in enumerate(parts):
+        (writes if k < n_dst else reads).update(regs_of(p))
+    if base.startswith("v_cmp_") and op.endswith("_e32"):
+        if not parts[0].startswith("vcc"):
+            writes, reads = {"vcc"}, regs_of(args)  # (older syntax without the explicit vcc)
+    if base == "v_cndmask_b32" and op.endswith("_e32"):
+        reads.add("vcc")
+    if base in ("v_addc_co_u32", "v_subb_co_u32", "v_subbrev_co_u32") and op.endswith("_e32"):
+        reads.add("vcc")
+        writes.add("vcc")
+    reads.add("exec")
+    if not writes:
+        return None
+    return reads, writes
+
+
+def to_bitop3(op, args):
+    base = isa_cadence.base_of(op)
+    if base in BITOP3:
+        a = re.sub(r"\s*//.*$", "", args).rstrip()
+        return "v_bitop3_b32", "%s bitop3:%s" % (a, BITOP3[base])
+    return op, args
+
+
+def split3(op, args):
+    """v_add3_u32 / v_xad_u32 / v_bfe_u32 (4-cycle class) as two instructions of the 2-cycle class, where no temporary
+    register is needed; else None"""
+    base = isa_cadence.base_of(op)
+    if base not in ("v_add3_u32", "v_xad_u32", "v_bfe_u32"):
+        return None
+    parts = split_operands(args)
+    if len(parts) != 4 or not re.fullmatch(r"v\d+", parts[0]):
+        return None
+    d, a, b, c = parts
+    isv = lambda x: re.fullmatch(r"v\d+", x) is not None
+    def vop2(op2, dst, x, y):  # VOP2: src1 must be a VGPR
+        if not isv(y):
+            x, y = y, x
+        if not isv(y):
+            return None
+        return (op2 + "_e32", "%s, %s, %s" % (dst, x, y))
+    if base == "v_add3_u32":
+        srcs = [a, b, c]
+        # the first add must not overwrite the source the second one still needs: put a source equal to d first
+        if d in srcs:
+            srcs.remove(d)
+            srcs.insert(0, d)
+        i1 = vop2("v_add_u32", d, srcs[0], srcs[1])
+        i2 = vop2("v_add_u32", d, srcs[2], d)
+        if i1 is None or i2 is None or (srcs[2] == d):
+            return None
+        if not isv(srcs[0]) and not isv(srcs[1]):
+            return None
+        return [i1, i2]
+    if base == "v_xad_u32":  # (a ^ b) + c
+        if c == d:
+            return None
+        i1 = vop2("v_xor_b32", d, a, b)
+        i2 = vop2("v_add_u32", d, c, d)
+        if i1 is None or i2 is None:
+            return None
+        return [i1, i2]
+    if base == "v_bfe_u32":  # (a >> b) & ((1 << c) - 1), constant field
+        if not isv(a) or not re.fullmatch(r"\d+|0x[0-9a-f]+", b) or not re.fullmatch(r"\d+|0x[0-9a-f]+", c):
+            return None
+        off, width = int(b, 0), int(c, 0)
+        if off + width > 32 or width == 0:
+            return None
+        out = [("v_lshrrev_b32_e32", "%s, %d, %s" % (d, off, a))] if off else []
+        if off + width < 32:
+            out.append(("v_and_b32_e32", "%s, 0x%x, %s" % (d, (1 << width) - 1, d if off else a)))
+        return out or None
+    return None
+
+
+def taint(run, slow):
+    """tainted[k]: slow, or depends (RAW, WAR, WAW -- anything that pins its place) on an earlier tainted instruction of the run"""
+    n = len(run)
+    tainted = [False] * n
+    for k in range(n):
+        if slow[k]:
+            tainted[k] = True
+            continue
+        rk, wk = run[k][2]
+        for j in range(k):
+            if not tainted[j]:
+                continue
+            rj, wj = run[j][2]
+            if (wj & (rk | wk)) or (rj & wk):
+                tainted[k] = True
+                break
+    return tainted
+
+
+def order_run(run, sep):
+    """run: list of (op, args, (reads, writes)); returns the new list of (op, args)"""
+    n = len(run)
+    slow = [isa_cadence.is_slow(o, a) for o, a, _ in run]
+    if not any(slow) or all(slow):
+        return [(o, a) for o, a, _ in run], 0
+    tainted = taint(run, slow)
+    first = [k for k in range(n) if not tainted[k]]
+    rest = [k for k in range(n) if tainted[k]]
+    # an untainted instruction moves in front of tainted ones only: check it does not jump over a dependency the other way
+    # (a tainted instruction j < k that READS what k writes, or writes what k reads/writes, taints k above: nothing left)
+    out, moved = [], 0
+    for k in first:
+        out.append(run[k][:2])
+    moved = sum(1 for i, k in enumerate(first) if k != i)
+    prev_slow = False
+    for k in rest:
+        if sep and prev_slow and not slow[k]:
+            out.append(("s_nop", "0"))
+        out.append(run[k][:2])
+        prev_slow = slow[k]
+    return out, moved
+
+
+def transform(body, bitop3=True, reorder=True, sep=False, split=False, sink=False, check_only=False):
+    """body: list of (op, args) of ONE basic block (or any instruction list in which labels have been made barriers by
+    the caller).  Returns the new list and counters."""
+    stats = {"bitop3": 0, "moved": 0, "runs": 0, "sep": 0}
+    if bitop3:
+        nb = []
+        for op, args in body:
+            o2, a2 = to_bitop3(op, args)
+            stats["bitop3"] += o2 != op
+            nb.append((o2, a2))
+        body = nb
+    if split:
+        nb, stats["split"] = [], 0
+        for op, args in body:
+            two = split3(op, args)
+            if two:
+                nb.extend(two)
+                stats["split"] += 1
+            else:
+                nb.append((op, args))
+        body = nb
+    if check_only:
+        fix_hazards(body, stats)
+        return body, stats
+    if not reorder:
+        return body, stats
+    # segments: runs of movable VALU instructions, everything else one by one
+    segs = []  # ("run", [(op, args, (reads, writes))]) | ("bar", (op, args))
+    for op, args in body:
+        d = rw(op, args) if op is not None else None
+        if d is None:
+            segs.append(("bar", (op, args)))
+        elif segs and segs[-1][0] == "run":
+            segs[-1][1].append((op, args, d))
+        else:
+            segs.append(("run", [(op, args, d)]))
+    if sink:
+        stats["sunk"] = sink_pass(segs)
+    out = []
+    for kind, item in segs:
+        if kind == "bar":
+            out.append(item)
+        elif item:
+            new, moved = order_run(item, sep)
+            stats["moved"] += moved
+            stats["runs"] += 1
+            stats["sep"] += len(new) - len(item)
+            out.extend(new)
+    out = fix_hazards(out, stats)
+    return out, stats
+
+
+# ------------------------------------------------------------------------------------------ hazards
+# The compiler pads the wait states gfx950 asks for between certain instruction pairs; re-ordering must not shorten them.
+# Rules (LLVM's GCNHazardRecognizer for gfx940/gfx950; a wait state = one instruction issued, s_nop N = N + 1):
+#   a VALU instruction writes an SGPR or VCC   -> a VALU instruction reads it (explicitly, or VCC implicitly):      2
+#   a VALU instruction writes an SGPR          -> a vector-memory instruction reads it:                             5
+#   a VALU instruction writes a VGPR           -> v_readlane / v_readfirstlane reads it:                            1
+#   a VALU instruction writes a VGPR           -> a DPP instruction reads it:                                       2
+#   a transcendental instruction, or an SDWA one with dst_sel other than DWORD, writes a VGPR -> a VALU instruction reads it: 1
+# fix_hazards() walks a block and pads (s_nop) wherever the text in front of it has fewer; on the compiler's own output it
+# must find nothing to do (checked by `--check`).
+TRANS = ("v_rcp", "v_rsq", "v_sqrt", "v_exp", "v_log", "v_sin", "v_cos")
+VMEM = ("global_", "buffer_", "flat_", "scratch_", "tbuffer_")
+
+
+def rw_loose(op, args):
+    """(reads, writes) of ANY vector instruction: first operand(s) written, the rest read (SDWA / DPP / lane forms too)"""
+    base = isa_cadence.base_of(op)
+    for suf in ("_sdwa", "_dpp"):
+        if base.endswith(suf):
+            base = base[: -len(suf)]
+    parts = split_operands(args)
+    n_dst = 2 if base in TWO_DST else 1
+    if base.startswith("v_cmpx"):
+        n_dst = 0
+    writes, reads = set(), set()
+    for k, p in enumerate(parts):
+        (writes if k < n_dst else reads).update(regs_of(p))
+    if base.startswith("v_cmp") and not op.endswith("_e64") and not (parts and parts[0].startswith(("vcc", "s"))):
+        writes.add("vcc")
+    if base.startswith("v_cmpx"):
+        writes.add("exec")
+    if base == "v_cndmask_b32" and not op.endswith("_e64"):
+        reads.add("vcc")
+    if base in ("v_addc_co_u32", "v_subb_co_u32", "v_subbrev_co_u32", "v_div_fmas_f32", "v_div_fmas_f64") and not op.endswith("_e64"):
+        reads.add("vcc")
+    if base.startswith("v_writelane") or "dst_unused:UNUSED_PRESERVE" in args:
+        reads |= writes
+    return reads, writes
+
+
+def fix_hazards(body, stats=None):
+    out = []
+    ws = 0                      # wait states issued so far
+    w_sgpr, w_vgpr, w_fwd = {}, {}, {}   # register -> wait-state index of the VALU instruction that wrote it last
+    for op, args in body:
+        need = 0
+        if op.startswith("v_"):
+            reads, writes = rw_loose(op, args)
+            lane = op.startswith(("v_readlane", "v_readfirstlane"))
+            dpp = op.endswith("_dpp")
+            for r in reads:
+                if (r.startswith("s") or r == "vcc") and r in w_sgpr:
+                    need = max(need, 2 - (ws - w_sgpr[r] - 1))
+                if r.startswith("v") and r != "vcc":
+                    if lane and r in w_vgpr:
+                        need = max(need, 1 - (ws - w_vgpr[r] - 1))
+                    if dpp and r in w_vgpr:
+                        need = max(need, 2 - (ws - w_vgpr[r] - 1))
+                    if r in w_fwd:
+                        need = max(need, 1 - (ws - w_fwd[r] - 1))
+        elif op.startswith(VMEM):
+            for r in regs_of(args):
+                if r.startswith("s") and r in w_sgpr:
+                    need = max(need, 5 - (ws - w_sgpr[r] - 1))
+        if need > 0:
+            out.append(("s_nop", str(need - 1)))
+            ws += need
+            if stats is not None:
+                stats["hazard_nops"] = stats.get("hazard_nops", 0) + 1
+        out.append((op, args))
+        if op == "s_nop":
+            m = re.match(r"\s*(\d+)", args)
+            ws += (int(m.group(1)) if m else 0) + 1
+            continue
+        if op.startswith("v_"):
+            for r in writes:
+                if r.startswith("s") or r == "vcc":
+                    w_sgpr[r] = ws
+                elif r.startswith("v"):
+                    w_vgpr[r] = ws
+                    if op.startswith(TRANS) or (op.endswith("_sdwa") and "dst_sel:" in args and "dst_sel:DWORD" not in args):
+                        w_fwd[r] = ws
+                    else:
+                        w_fwd.pop(r, None)
+        else:  # a scalar or memory instruction that names a register as its first operand may be writing it
+            parts = split_operands(args)
+            if parts:
+                for r in regs_of(parts[0]):
+                    w_sgpr.pop(r, None)
+                    w_vgpr.pop(r, None)
+                    w_fwd.pop(r, None)
+        ws += 1
+    return out
+
+
+CROSSABLE = re.compile(r"^(s_waitcnt|ds_read|ds_write|global_load|s_(mov|and|or|andn2|orn2|xor|lshl|lshr|add|sub|cmp|bfe|cselect|ff1|bcnt1|not|mul|min|max)_)")
+
+
+def bar_regs(op, args):
+    """registers a non-movable instruction touches (all of them count as read AND written), or None: never crossed"""
+    if not CROSSABLE.match(op + ("_" if op == "s_waitcnt" else "")) or "exec" in op:
+        return None
+    regs = regs_of(re.sub(r"\s*//.*$", "", args))
+    if "exec" in regs or "m0" in regs:
+        return None
+    return regs
+
+
+def sink_pass(segs):
+    """A fast-class instruction that sits behind a slow one of its run (so it would issue at the 4-cycle cadence, or cost a
+    separator) moves to the head of the NEXT run when nothing forbids it: it writes only VGPRs, no later instruction of its
+    own run touches what it writes or writes what it reads, and the instructions between the runs (waits, LDS and memory
+    instructions, plain scalar arithmetic -- never a branch, s_nop, barrier, EXEC or M0 writer, SDWA/DPP/lane instruction)
+    touch none of its registers.  Moving later never shortens the distance to a consumer behind a wait."""
+    sunk = 0
+    i = 0
+    while i < len(segs):
+        if segs[i][0] != "run":
+            i += 1
+            continue
+        # the bars between this run and the next
+        j = i + 1
+        between = set()
+        ok = True
+        while j < len(segs) and segs[j][0] == "bar":
+            r = bar_regs(*segs[j][1])
+            if r is None:
+                ok = False
+                break
+            between |= r
+            j += 1
+        if not ok or j >= len(segs) or j == i + 1:
+            i += 1
+            continue
+        run, nxt = segs[i][1], segs[j][1]
+        slow = [isa_cadence.is_slow(o, a) for o, a, _ in run]
+        if not any(slow):
+            i += 1
+            continue
+        first_slow = slow.index(True)
+        tainted = taint(run, slow)
+        move = []  # indices, descending pass: an instruction may sink if everything behind it in the run that stays is independent
+        stay_r, stay_w = set(), set()
+        for k in range(len(run) - 1, first_slow, -1):
+            rk, wk = run[k][2]
+            vg_only = all(x.startswith("v") and x != "vcc" for x in wk)
+            free = vg_only and tainted[k] and not slow[k] and not (wk & (stay_r | stay_w)) and not (rk & stay_w) \
+                and not ((wk | (rk - {"exec"})) & between)
+            if free:
+                move.append(k)
+            else:
+                stay_r |= rk
+                stay_w |= wk
+        if move:
+            move.sort()
+            segs[j] = ("run", [run[k] for k in move] + nxt)
+            segs[i] = ("run", [run[k] for k in range(len(run)) if k not in set(move)])
+            sunk += len(move)
+        i += 1
+    return sunk
+
+
+def process_file(lines, only, bitop3=False, **kw):
+    """bitop3: everywhere; the other transforms: only inside the functions --only names (substring of the symbol; none
+    given: everywhere).  Never inside an inline-asm region (;APP .. ;NO_APP); labels, directives and comments end a block."""
+    out, total = [], {}
+    func, active, in_app = None, False, False
+    block = []
+
+    def flush():
+        nonlocal block
+        if block:
+            new, st = transform(block, bitop3=bitop3, **(kw if active else {"reorder": False}))
+            for k, v in st.items():
+                total[k] = total.get(k, 0) + v
+            out.extend("\t%s %s\n" % (o, a.strip()) if a.strip() else "\t%s\n" % o for o, a in new)
+            block = []
+
+    for line in lines:
+        s = line.rstrip("\n")
+        if s.startswith("\t.type") and "@function" in s:
+            flush()
+            func = s.split()[1].split(",")[0]
+            active = (not only) or any(o in func for o in only)
+        if ";APP" in s:
+            flush()
+            in_app = True
+        m = INS.match(s)
+        if m and func and not in_app and not s.lstrip().startswith((".", ";")):
+            block.append((m.group(1), re.sub(r"\s*;.*$", "", m.group(2))))
+        else:
+            flush()
+            out.append(line)
+        if ";NO_APP" in s:
+            in_app = False
+    flush()
+    return out, total
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("src")
+    ap.add_argument("dst")
+    ap.add_argument("--only", action="append", default=[])
+    ap.add_argument("--bitop3", action="store_true")
+    ap.add_argument("--reorder", action="store_true")
+    ap.add_argument("--sep", action="store_true")
+    ap.add_argument("--split", action="store_true")
+    ap.add_argument("--sink", action="store_true")
+    ap.add_argument("--check", action="store_true", help="only count the hazard paddings this pass would add to the text as it is")
+    ap.add_argument("--stats", action="store_true")
+    ap.add_argument("--obj", help="assemble the result into this object (branch islands where a branch range demands)")
+    a = ap.parse_args()
+    with open(a.src) as f:
+        lines = f.readlines()
+    if a.check:
+        _, st = process_file(lines, a.only, bitop3=False, reorder=True, check_only=True)
+        print(" ".join("%s=%d" % kv for kv in sorted(st.items())), file=sys.stderr)
+        return
+    out, st = process_file(lines, a.only, bitop3=a.bitop3, reorder=a.reorder, sep=a.sep, split=a.split, sink=a.sink)
+    if a.obj:
+        n = isa_cadence.assemble(out, a.dst, a.obj)
+        st["islands"] = n
+    with open(a.dst, "w") as f:
+        f.writelines(out)
+    if a.stats:
+        print(" ".join("%s=%d" % kv for kv in sorted(st.items())), file=sys.stderr)
+
+
+if __name__ == "__main__":
+    main()
