@@ -85,11 +85,27 @@ def rw(op, args):
     return reads, writes
 
 
+INLINE = re.compile(r"^(?:v\d+|-?\d+|0x[0-9a-f]+)$")
+SEL64 = False  # measured on the bulk kernel: 5.59-5.63 ms with, 5.59-5.62 without (profiles/r08_postpass_lib_ab.txt): off
+
+
 def to_bitop3(op, args):
     base = isa_cadence.base_of(op)
     if base in BITOP3:
         a = re.sub(r"\s*//.*$", "", args).rstrip()
         return "v_bitop3_b32", "%s bitop3:%s" % (a, BITOP3[base])
+    if op == "v_cndmask_b32_e32" and SEL64:
+        # the select in its long encoding takes its mask as an ordinary operand (VCC included): 2-cycle class, and no
+        # 16-23-cycle stall when VCC was not written by the vector compare just before (profiles/r06_vcc_probe.txt).
+        # Only where the other two sources are registers or small inline constants (one scalar source per VOP3).
+        parts = split_operands(args)
+        if len(parts) == 4 and parts[3] == "vcc" and all(INLINE.match(x) for x in parts[1:3]):
+            ok = True
+            for x in parts[1:3]:
+                if not x.startswith("v"):
+                    ok = ok and -16 <= int(x, 0) <= 64
+            if ok:
+                return "v_cndmask_b32_e64", " " + ", ".join(parts)
     return op, args
 
 
