@@ -119,12 +119,16 @@ def practical_roofline(kernel_ms, wave_iterations_per_launch, counters):
             "frac_of_practical": bound / measured if bound and measured else None,
             "valu_instructions": h.get("valu"), "by_class": {k: h.get("classes", {}).get(k) for k in ("fast", "slow", "mul64", "sel_vcc")},
             "fast_class_instructions_at_the_slow_cadence": h.get("poisoned_fast_instructions"),
+            "separators_behind_slow_class": h.get("separators_behind_slow"),
+            "slow_class_directly_behind_slow_class": h.get("slow_directly_behind_slow"),
             "class_costs_simd_cycles": h.get("costs_simd_cycles"),
             "histogram_fresh": h.get("kernel_sources_sha256") == kernel_source_hash(),
             "basis": "bound = sum over the loop's VALU instructions of the cost of their issue class (fast 2.6, slow 4.7 "
                      "SIMD-cycles per wave64 instruction: this loop's own instructions replayed class by class, "
                      "tools/ubench/replay_loop.py); as_scheduled = the same with the cadence rule applied to the compiler's "
-                     "ORDER (a fast-class instruction behind a slow-class one of its VALU run issues at the slow cadence); "
+                     "ORDER of the shipped text, i.e. behind tools/isa_resched.py (a fast-class instruction behind a slow-class one of its "
+                     "VALU run issues at the slow cadence; a separator costs 0.8, a slow-class instruction directly behind another "
+                     "one 1.0 more: profiles/r07_issue_probe3.txt); "
                      "measured = kernel time x clock x 1024 SIMDs / wave-iterations"}
 
 

@@ -59,7 +59,7 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 
 # measured issue costs, SIMD-cycles per wave64 instruction at 4 waves per SIMD (profiles/r01_ubench.txt,
 # r06_vcc_probe.txt; refined per context by profiles/r07_issue_probe.txt when that file's table is passed in)
-COST = {"fast": 2.61, "slow": 4.67, "mul64": 4.67, "sel_vcc": 4.67, "fast_at_slow_cadence": 4.2}
+COST = {"fast": 2.61, "slow": 4.67, "mul64": 4.67, "sel_vcc": 4.67, "fast_at_slow_cadence": 4.2, "separator": 0.8, "slow_behind_slow": 1.0}
 
 FAST_OPS = {"v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_not_b32", "v_mov_b32",
             "v_lshrrev_b32", "v_ashrrev_i32", "v_add_f32", "v_mul_f32", "v_sub_f32", "v_bitop3_b32", "v_addc_co_u32",
@@ -197,6 +197,8 @@ def histogram(body, vcc_window, guarded=()):
     last_vcc_writer, since, stale = None, 10 ** 9, 0
     slow_cadence = False  # a slow-class instruction has been issued since the wave's last non-VALU instruction
     poisoned = 0
+    prev_class = None
+    separators = slow_pairs = 0
     rare = set()
     for a, b in guarded:
         rare.update(range(a, b))
@@ -210,6 +212,16 @@ def histogram(body, vcc_window, guarded=()):
         ops.setdefault(c, {})
         ops[c][key] = ops[c].get(key, 0) + 1
         if k not in rare:
+            # round 4 (profiles/r07_issue_probe3.txt): a separator is not free (`fSn` 6.64 cycles against `fnSn` 8.40: 0.4-1.1
+            # each), and a slow-class instruction directly behind another one costs 0.9-1.3 more than alone (`fSSn` 11.6
+            # against `fSnSn` 10.2 + a separator)
+            if op == "s_nop" and prev_class in ("slow", "mul64", "sel_vcc"):
+                separators += 1
+                scheduled += COST["separator"]
+            if c in ("slow", "mul64", "sel_vcc") and prev_class in ("slow", "mul64", "sel_vcc"):
+                slow_pairs += 1
+                scheduled += COST["slow_behind_slow"]
+            prev_class = c
             if c == "fast":
                 bound += COST["fast"]
                 if slow_cadence:
@@ -235,7 +247,8 @@ def histogram(body, vcc_window, guarded=()):
     valu = sum(classes.get(k, 0) for k in ("fast", "slow", "mul64", "sel_vcc"))
     return {"classes": classes, "opcodes": ops, "valu": valu, "stale_vcc_selects": stale,
             "cycles_per_wave_iteration_bound": round(bound, 1), "cycles_as_scheduled": round(scheduled, 1),
-            "poisoned_fast_instructions": poisoned, "cycles_at_2_per_instruction": 2 * valu,
+            "poisoned_fast_instructions": poisoned, "separators_behind_slow": separators, "slow_directly_behind_slow": slow_pairs,
+            "cycles_at_2_per_instruction": 2 * valu,
             "fast_share": round(classes.get("fast", 0) / valu, 4) if valu else 0.0}
 
 
