@@ -470,6 +470,7 @@ __global__ __launch_bounds__(kMtbJumpBlock) void mcq_mtb_jump_kernel(const uint3
 
 // 2. scan: one wave per (query, block); lane = entry state (mcq_mtb_automaton), the block's bytes through LDS.
 constexpr int kMtbBlock = 256;
+constexpr int kMtbParseBlock = 1024; /* parse: sixteen blocks per work-group (70 KB of LDS, two work-groups per CU), their attempts in one atomic */
 /* a block's state words -> its bytes (y & 63) | 0x80 in LDS (dst: MCQ_MT_N + 64 bytes, the last 64 padding) */
 __device__ __forceinline__ void mcq_mtb_load_block(const uint32_t *__restrict__ src, uint8_t *dst, uint32_t lane) {
     uint32_t y[10];
@@ -491,7 +492,9 @@ __global__ __launch_bounds__(kMtbBlock) void mcq_mtb_scan_kernel(const mcq_query
                                                                 const uint32_t *__restrict__ blk_off,
                                                                 const uint32_t *__restrict__ raw, uint32_t *__restrict__ exits) {
     /* a block has at most MCQ_MTB_LANES = 32 entry states: a wave takes TWO blocks, one per half (round 4: the automaton is
-     * bound by vector issue, and half of every instruction's lanes were idle) */
+     * bound by vector issue, and half of every instruction's lanes had been idle: 98 -> 75 us for the 3 900 blocks of a
+     * 6-max 100 000-run query.  Two blocks per HALF, walked word by word in turn -- mcq_mtb_automaton2 -- to hide the
+     * chain's lookups behind each other: 125 us, the two automata's rejections diverge) */
     __shared__ __attribute__((aligned(16))) uint8_t s_yb[kMtbBlock / 64][2][MCQ_MT_N + 64u];
     __shared__ uint32_t s_pos[kMtbBlock / 64][MCQ_MTB_POS];
     static_assert(MCQ_MTB_LANES == 32u, "two blocks per wave");
@@ -609,19 +612,22 @@ __global__ __launch_bounds__(kMtbBlock) void mcq_mtb_expand_kernel(const mcq_que
 
 // 4. parse: one wave per (query, block) from the block's true entry (mcq_mtb_parse_block: the batch code of the serial
 // walk), draws straight to the draw buffer, the attempts added to the row's `passes`.
-__global__ __launch_bounds__(kMtbBlock) void mcq_mtb_parse_kernel(const mcq_query *__restrict__ queries,
+__global__ __launch_bounds__(kMtbParseBlock) void mcq_mtb_parse_kernel(const mcq_query *__restrict__ queries,
                                                                  const uint32_t *__restrict__ blk_off,
                                                                  const uint32_t *__restrict__ state,
                                                                  const McqMtbEntry *__restrict__ entries,
                                                                  const uint32_t *__restrict__ ovf, uint8_t *__restrict__ draws,
                                                                  const uint64_t *__restrict__ draw_off, mcq_result *__restrict__ res) {
-    __shared__ __attribute__((aligned(16))) McqMtBlockWave ws[kMtbBlock / 64];
+    __shared__ __attribute__((aligned(16))) McqMtBlockWave ws[kMtbParseBlock / 64];
+    __shared__ unsigned long long s_passes[kMtbParseBlock / 64];
     const uint32_t qi = blockIdx.y, lane = threadIdx.x & 63u, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t first = blk_off[qi], nb = blk_off[qi + 1u] - first, b = blockIdx.x * (kMtbBlock / 64) + wv;
-    if (b >= nb) return; /* (wave-uniform; no block barrier below) */
-    if (ovf[qi] != 0u) {
+    const uint32_t first = blk_off[qi], nb = blk_off[qi + 1u] - first, b = blockIdx.x * (kMtbParseBlock / 64) + wv;
+    if (blockIdx.x * (kMtbParseBlock / 64) >= nb) return; /* (block-uniform) */
+    const bool mine = b < nb;                                         /* (wave-uniform) */
+    if (ovf[qi] != 0u) { /* (block-uniform) */
         /* the stream ran past the query's blocks: the host repeats the call with the serial walk; the evaluation kernel
          * behind this one still reads the query's draws -- give it valid ones (index 0), not whatever the buffer held */
+        if (!mine) return;
         const uint4 raw = reinterpret_cast<const uint4 *>(queries)[qi];
         const McqQueryWords q = {raw.x, raw.y, raw.z, raw.w};
         const uint64_t bytes = (((uint64_t)q.runs() + 63u) & ~63ull) * (2u * (q.n_players() - 1u) + 5u - q.n_board());
@@ -630,27 +636,40 @@ __global__ __launch_bounds__(kMtbBlock) void mcq_mtb_parse_kernel(const mcq_quer
         for (uint64_t k = lo / 16u + lane; k < hi / 16u; k += 64u) dst[k] = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
         return;
     }
-    /* (into scalar registers by hand: the compiler knows that a load at a uniform address is uniform, drops a
-     * readfirstlane of it -- and then cannot pin the walk's state in SGPRs where mcq_mt_batch asks for that) */
-    const McqMtbEntry en0 = entries[first + b];
-    McqMtbEntry en;
-    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(en.it0) : "v"(en0.it0));
-    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(en.dp) : "v"(en0.dp));
-    if (!(en.dp >> 31)) return; /* the stream ended in an earlier block */
-    McqMtBlockWave &w = ws[wv];
-    const uint4 raw = reinterpret_cast<const uint4 *>(queries)[qi];
-    const McqQueryWords q = {(uint32_t)__builtin_amdgcn_readfirstlane(raw.x), (uint32_t)__builtin_amdgcn_readfirstlane(raw.y),
-                             (uint32_t)__builtin_amdgcn_readfirstlane(raw.z), (uint32_t)__builtin_amdgcn_readfirstlane(raw.w)};
-    const uint32_t L0 = 50u - q.n_board(), n_opp = q.n_players() - 1u, n_deal = 5u - q.n_board(), runs = q.runs();
-    mcq_mtb_load_block(state + (uint64_t)(first + b) * MCQ_MT_N, w.yb, lane);
-    if (lane == 0) {
-        w.draws = draws + draw_off[qi];
-        w.stride = ((uint64_t)runs + 63u) & ~63ull;
-        w.two_opp = 2u * n_opp;
+    uint64_t passes = 0;
+    if (mine) {
+        /* (into scalar registers by hand: the compiler knows that a load at a uniform address is uniform, drops a
+         * readfirstlane of it -- and then cannot pin the walk's state in SGPRs where mcq_mt_batch asks for that) */
+        const McqMtbEntry en0 = entries[first + b];
+        McqMtbEntry en;
+        asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(en.it0) : "v"(en0.it0));
+        asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(en.dp) : "v"(en0.dp));
+        if (en.dp >> 31) { /* (else: the stream ended in an earlier block) */
+            McqMtBlockWave &w = ws[wv];
+            const uint4 raw = reinterpret_cast<const uint4 *>(queries)[qi];
+            const McqQueryWords q = {(uint32_t)__builtin_amdgcn_readfirstlane(raw.x), (uint32_t)__builtin_amdgcn_readfirstlane(raw.y),
+                                     (uint32_t)__builtin_amdgcn_readfirstlane(raw.z), (uint32_t)__builtin_amdgcn_readfirstlane(raw.w)};
+            const uint32_t L0 = 50u - q.n_board(), n_opp = q.n_players() - 1u, n_deal = 5u - q.n_board(), runs = q.runs();
+            mcq_mtb_load_block(state + (uint64_t)(first + b) * MCQ_MT_N, w.yb, lane);
+            if (lane == 0) {
+                w.draws = draws + draw_off[qi];
+                w.stride = ((uint64_t)runs + 63u) & ~63ull;
+                w.two_opp = 2u * n_opp;
+            }
+            mcq_mt_fill_ptab(w, L0, n_opp, 2u * n_opp + n_deal); /* (ends with a wave barrier) */
+            passes = mcq_mtb_parse_block(w, L0, n_opp, n_deal, runs, en);
+        }
     }
-    mcq_mt_fill_ptab(w, L0, n_opp, 2u * n_opp + n_deal); /* (ends with a wave barrier) */
-    const uint64_t passes = mcq_mtb_parse_block(w, L0, n_opp, n_deal, runs, en);
-    if (lane == 0 && passes) atomicAdd(reinterpret_cast<unsigned long long *>(res + qi) + 1, (unsigned long long)passes);
+    /* the attempts of the work-group's blocks in ONE atomic: thousands of them on one row's word serialise (14 ns each:
+     * 3 900 blocks of a 6-max 100 000-run query 54 us, the whole parse kernel's time) */
+    if (lane == 0) s_passes[wv] = passes;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long sum = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kMtbParseBlock / 64; k++) sum += s_passes[k];
+        if (sum) atomicAdd(reinterpret_cast<unsigned long long *>(res + qi) + 1, sum);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- multi-GPU helper
@@ -744,9 +763,8 @@ struct WaveTally { /* per-lane running sums of the current (wave, query) pair */
         if (lane == 2) mine = ties;
         return mine;
     }
-    /* lanes -> wave (shuffles) -> one 64-bit atomic per counter */
-    __device__ __forceinline__ void flush(mcq_result *row, uint32_t lane) {
-        if (!dirty) return;
+    /* lanes -> wave (shuffles): lane l < 12 holds word 1 + l of the row (passes, win, tie, by_type[9]) */
+    __device__ __forceinline__ uint64_t row_value(uint32_t lane) {
         uint32_t wins = 0;
         uint64_t mine = 0;
 #pragma unroll
@@ -761,6 +779,12 @@ struct WaveTally { /* per-lane running sums of the current (wave, query) pair */
         if (lane == 0) mine = pass;
         if (lane == 1) mine = wins - ties;
         if (lane == 2) mine = ties;
+        return mine;
+    }
+    /* ... -> one 64-bit atomic per counter */
+    __device__ __forceinline__ void flush(mcq_result *row, uint32_t lane) {
+        if (!dirty) return;
+        const uint64_t mine = row_value(lane);
         if (lane < 12 && mine != 0)
             atomicAdd(reinterpret_cast<unsigned long long *>(row) + 1 + lane, (unsigned long long)mine);
         clear();
@@ -784,7 +808,20 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
      * skips ahead in its lane's stream), so the tallies do not depend on it. */
     __shared__ __attribute__((aligned(16))) LdsTablesEval tab;
     __shared__ McqCard base_tab[kMaxBlock]; /* per wave: the query's ordered remaining deck, 64 entries x 16 B */
-    load_tables(tab, g_tab);
+    /* SPLIT (small batches): the rows the work-group's waves END on are added up in LDS when they are one query's -- a
+     * single long query is hundreds of waves, and twelve atomics per wave on ONE row serialise (a 100 000-run query: 392
+     * waves, 18 us where the arithmetic takes 6) -- and the last wave sends the sum: s_key = that query (claimed by the
+     * first wave to finish), s_done = waves that have finished */
+    __shared__ unsigned long long s_row[12];
+    __shared__ uint32_t s_key, s_done;
+    if (SPLIT) {
+        if (threadIdx.x < 12u) s_row[threadIdx.x] = 0ull;
+        if (threadIdx.x == 12u) {
+            s_key = 0xFFFFFFFFu;
+            s_done = 0u;
+        }
+    }
+    load_tables(tab, g_tab); /* (ends with a block barrier) */
 
     const uint32_t lane = threadIdx.x & 63u;
     /* small batches launch more waves than take work: the extra ones only help to bring the 97 KB table image in */
@@ -796,7 +833,6 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
     const uint64_t total = prefix[n] << split; /* cost axis in sub-task units */
     /* this wave's slice of the cost axis; a task belongs to the slice its start position falls into */
     const uint64_t lo = total * wave / n_waves, hi = total * (wave + 1ull) / n_waves;
-    if (lo >= hi) return;
     McqCard *base = base_tab + (threadIdx.x & ~63u);
 
     uint32_t a = 0, b = n; /* last query with prefix <= lo: it has a positive cost because lo < total */
@@ -811,7 +847,7 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
     WaveTally tally;
     tally.clear();
     bool fresh = true; /* query record qi not loaded yet */
-    for (;;) {
+    for (; lo < hi;) { /* (a wave without a slice goes straight to the end: the work-group counts it there) */
         if (fresh) {
             if (qi >= n) break;
             const uint4 raw = reinterpret_cast<const uint4 *>(queries)[qi];
@@ -878,7 +914,34 @@ __global__ __launch_bounds__(kMaxBlock) void mcq_eval_kernel(const mcq_query *__
         tally.add(acc);
         task++;
     }
-    if (qi < n) tally.flush(res + qi, lane);
+    if (!SPLIT) {
+        if (qi < n) tally.flush(res + qi, lane);
+        return;
+    }
+    const bool have = qi < n && tally.dirty; /* (wave-uniform) */
+    if (have) {
+        const uint64_t mine = tally.row_value(lane);
+        uint32_t key = 0;
+        if (lane == 0) key = atomicCAS(&s_key, 0xFFFFFFFFu, qi);
+        key = __builtin_amdgcn_readfirstlane(key);
+        if (key == 0xFFFFFFFFu || key == qi) {
+            if (lane < 12u && mine != 0) atomicAdd(&s_row[lane], (unsigned long long)mine);
+        } else if (lane < 12u && mine != 0) { /* another query's tail: straight to its row */
+            atomicAdd(reinterpret_cast<unsigned long long *>(res + qi) + 1 + lane, (unsigned long long)mine);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); /* the sums are in LDS before this wave counts as finished */
+    uint32_t done = 0;
+    if (lane == 0) done = atomicAdd(&s_done, 1u);
+    done = __builtin_amdgcn_readfirstlane(done);
+    if (done + 1u == waves_per_block) { /* the last wave of the work-group */
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        const uint32_t key = *(volatile uint32_t *)&s_key;
+        if (key != 0xFFFFFFFFu && lane < 12u) {
+            const unsigned long long v = *(volatile unsigned long long *)&s_row[lane];
+            if (v != 0) atomicAdd(reinterpret_cast<unsigned long long *>(res + key) + 1 + lane, v);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- eval, small queries
@@ -1815,7 +1878,8 @@ hipError_t mcq_launch_mt_blocks(const mcq_query *d_q, uint32_t n, uint32_t seed3
                        reinterpret_cast<McqMtbEntry *>(d_gentry), d_ovf, d_res);
     hipLaunchKernelGGL(mcq_mtb_expand_kernel, per_group, dim3(kMtbBlock), 0, s, d_q, d_blk_off, d_grp_off, d_exits,
                        reinterpret_cast<const McqMtbEntry *>(d_gentry), reinterpret_cast<McqMtbEntry *>(d_entries));
-    hipLaunchKernelGGL(mcq_mtb_parse_kernel, per_block, dim3(kMtbBlock), 0, s, d_q, d_blk_off, d_raw,
+    const dim3 per_parse_block((max_blocks + kMtbParseBlock / 64 - 1) / (kMtbParseBlock / 64), n);
+    hipLaunchKernelGGL(mcq_mtb_parse_kernel, per_parse_block, dim3(kMtbParseBlock), 0, s, d_q, d_blk_off, d_raw,
                        reinterpret_cast<const McqMtbEntry *>(d_entries), d_ovf, d_draws, d_draw_off, d_res);
     return hipGetLastError();
 }
