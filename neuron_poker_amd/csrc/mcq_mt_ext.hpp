@@ -48,6 +48,8 @@ struct McqMtExtWave {
     uint8_t deck[80], deck0[80]; /* the ordered remaining deck (card ids) now / at the start of an iteration */
     uint8_t vals[80];            /* vals[1 + rank] = value of the accepted word of that rank; vals[0] = the pending r1 */
     uint8_t ring[(MCQ_MTX_MAX_DRAWS + 1u) * MCQ_MT_ROW]; /* rows as in McqMtWave: draw d in row d + 1 */
+    uint64_t pm[52];             /* round 4: pm[a] bit b = class(a, b) is in the set at word offset pm_set (the opponents' set, or ... */
+    uint32_t pm_set;             /* ... the first drawn hand's): the class test of a stage is one lookup and a shift */
 };
 
 struct McqMtExtState { /* wave-uniform */
@@ -110,6 +112,25 @@ MCQ_HD bool mcq_mt_parse_query_ext(W &w, McqMtExtState &st, const McqQueryWords 
         rows += n_deal;
     }
     MCQ_WAVE_SYNC();
+    /* the partner masks of the set most stages test: the opponents' if they are restricted, else the first drawn hand's */
+    {
+        uint32_t set_off = 0xFFFFFFFFu;
+        if (n_players > n_hands && !opp_all) set_off = er.opp_set();
+        else
+            for (uint32_t h = n_hands; h-- > h_first;)
+                if (mcq_ext_hand(q, er, h) >> 16) set_off = mcq_ext_hand_set(er, h);
+        MCQ_FOR_LANES(l) {
+            if (l == 0u) w.pm_set = set_off;
+            if (l < 52u && set_off != 0xFFFFFFFFu) {
+                uint64_t m = 0;
+                for (uint32_t b = 0; b < 52u; b++)
+                    if (b != l && mcq_in_range(w.ext + set_off, l, b)) m |= (uint64_t)1 << b;
+                w.pm[l] = m;
+            }
+        }
+    }
+    MCQ_WAVE_SYNC();
+    const uint32_t pm_set = w.pm_set;
 
     MCQ_PL(uint32_t, y63);
     MCQ_PL(uint32_t, y31);
@@ -218,8 +239,12 @@ MCQ_HD bool mcq_mt_parse_query_ext(W &w, McqMtExtState &st, const McqQueryWords 
                 MCQ_L(ok) = MCQ_L(p1) != MCQ_L(v);
                 if (restricted) {
                     const uint32_t a = w.deck[MCQ_L(p1) & 63u], b = w.deck[MCQ_L(v) & 63u]; /* both on the unpopped list */
-                    const uint32_t i = mcq_class_index(a, b);
-                    MCQ_L(ok) = MCQ_L(ok) && ((w.ext[set_off + (i >> 5)] >> (i & 31u)) & 1u) != 0u;
+                    if (set_off == pm_set) { /* (wave-uniform) a < 52: deck entries behind the deck's end are 0 */
+                        MCQ_L(ok) = MCQ_L(ok) && ((w.pm[a < 52u ? a : 0u] >> (b & 63u)) & 1u) != 0u;
+                    } else {
+                        const uint32_t i = mcq_class_index(a, b);
+                        MCQ_L(ok) = MCQ_L(ok) && ((w.ext[set_off + (i >> 5)] >> (i & 31u)) & 1u) != 0u;
+                    }
                 }
             }
             MCQ_WAVE_SYNC(); /* vals are read: the next step may write them */
