@@ -491,10 +491,12 @@ __device__ __forceinline__ McqMtbPlan mcq_mtb_plan_of(const mcq_query *__restric
 __global__ __launch_bounds__(kMtbBlock) void mcq_mtb_scan_kernel(const mcq_query *__restrict__ queries,
                                                                 const uint32_t *__restrict__ blk_off,
                                                                 const uint32_t *__restrict__ raw, uint32_t *__restrict__ exits) {
-    /* a block has at most MCQ_MTB_LANES = 32 entry states: a wave takes TWO blocks, one per half (round 4: the automaton is
-     * bound by vector issue, and half of every instruction's lanes had been idle: 98 -> 75 us for the 3 900 blocks of a
-     * 6-max 100 000-run query.  Two blocks per HALF, walked word by word in turn -- mcq_mtb_automaton2 -- to hide the
-     * chain's lookups behind each other: 125 us, the two automata's rejections diverge) */
+    /* a block has at most MCQ_MTB_LANES = 32 entry states: a wave takes TWO blocks, one per half (round 4: half of every
+     * instruction's lanes had been idle: 98 -> 75 us for the 3 900 blocks of a 6-max 100 000-run query).  Measured and
+     * dropped: a branch-free step with both candidate table words fetched ahead (78 us), and on top of it two or four
+     * blocks per wave-half walked word by word in turn (106-125 us) -- a wave that is alone on its SIMD issues one vector
+     * instruction per 5-8 cycles whatever their dependence, so fewer, fatter waves lose; what would help is MORE waves
+     * (sub-blocks of 312 words: four waves per SIMD) at the price of twice the units in the stitch. */
     __shared__ __attribute__((aligned(16))) uint8_t s_yb[kMtbBlock / 64][2][MCQ_MT_N + 64u];
     __shared__ uint32_t s_pos[kMtbBlock / 64][MCQ_MTB_POS];
     static_assert(MCQ_MTB_LANES == 32u, "two blocks per wave");
