@@ -196,7 +196,7 @@ def order_run(run, sep):
     moved = sum(1 for i, k in enumerate(first) if k != i)
     prev_slow = False
     for k in rest:
-        if sep and prev_slow and not slow[k]:
+        if sep and prev_slow and (not slow[k] or sep == "all"):
             out.append(("s_nop", "0"))
         out.append(run[k][:2])
         prev_slow = slow[k]

@@ -181,11 +181,45 @@ for _b, _base in (("nolds", v_no_lds), ("full", v_as_compiled)):
     VARIANTS[_b + "_resched_s"] = compose(_base, resched(bitop3=False, reorder=True, sep=True))
     VARIANTS[_b + "_bitop3_resched"] = compose(_base, resched(bitop3=True, reorder=True))
     VARIANTS[_b + "_bitop3_resched_s"] = compose(_base, resched(bitop3=True, reorder=True, sep=True))
+    VARIANTS[_b + "_bitop3_resched_sall"] = compose(_base, resched(bitop3=True, reorder=True, sep="all"))
     VARIANTS[_b + "_bitop3_sink_resched_s"] = compose(_base, resched(bitop3=True, reorder=True, sep=True, sink=True))
     VARIANTS[_b + "_bitop3_sink_resched"] = compose(_base, resched(bitop3=True, reorder=True, sep=False, sink=True))
     VARIANTS[_b + "_bitop3_split_resched_s"] = compose(_base, resched(bitop3=True, reorder=True, sep=True, split=True))
     VARIANTS[_b + "_bitop3_split"] = compose(_base, resched(bitop3=True, reorder=False, split=True))
     VARIANTS[_b + "_bitop3_sepf"] = compose(_base, resched(bitop3=True, reorder=False), sep_with("s_nop", "0", only_before_fast=True))
+
+
+
+def v_no_sgpr_src(body):
+    """every single-SGPR source operand of a VALU instruction becomes a VGPR (v127): what do the constant-bus reads cost?"""
+    out = []
+    for o, a in body:
+        if o.startswith("v_") and not o.startswith(("v_readlane", "v_writelane", "v_readfirstlane")):
+            parts = [p.strip() for p in a.split(",")]
+            n_dst = 2 if o.startswith("v_mad_u64") else 1
+            for k in range(n_dst, len(parts)):
+                if re.fullmatch(r"s\d+", parts[k]):
+                    parts[k] = "v127"
+            a = ", ".join(parts)
+        out.append((o, a))
+    return out
+
+
+def drop_ops(*prefixes):
+    """the stream without the instructions whose opcode starts with one of `prefixes` (what that opcode class costs in situ)"""
+    def f(body):
+        return [(o, a) for o, a in body if not o.startswith(prefixes)]
+    return f
+
+
+for _n, _p in (("mad64", ("v_mad_u64_u32",)), ("cmp", ("v_cmp_",)), ("max", ("v_max",)), ("perm", ("v_perm_b32",)),
+               ("sad", ("v_sad_u8",)), ("add3", ("v_add3_u32",)), ("bcnt", ("v_bcnt_",)), ("lshladd", ("v_lshl_add_u32",)),
+               ("sel64", ("v_cndmask_b32_e64",)), ("bitop3", ("v_bitop3_b32",)), ("andor", ("v_and_b32", "v_or_b32")),
+               ("sub", ("v_sub_u32",)), ("snop", ("s_nop",)), ("salu", ("s_and_b64", "s_or_b64", "s_mov_b64", "s_andn2_b64"))):
+    VARIANTS["nolds_drop_" + _n] = compose(v_no_lds, drop_ops(*_p))
+
+VARIANTS["nolds_nosgpr"] = compose(v_no_lds, v_no_sgpr_src)
+VARIANTS["nolds_nosgpr_nosel"] = compose(v_no_lds, v_no_sgpr_src, drop_ops("v_cndmask_b32_e64"))
 
 TEMPLATE = """\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"
 \t.amdhsa_code_object_version 6
