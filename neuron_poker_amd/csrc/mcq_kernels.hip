@@ -491,27 +491,40 @@ __device__ __forceinline__ McqMtbPlan mcq_mtb_plan_of(const mcq_query *__restric
 __global__ __launch_bounds__(kMtbBlock) void mcq_mtb_scan_kernel(const mcq_query *__restrict__ queries,
                                                                 const uint32_t *__restrict__ blk_off,
                                                                 const uint32_t *__restrict__ raw, uint32_t *__restrict__ exits) {
-    /* a block has at most MCQ_MTB_LANES = 32 entry states: a wave takes TWO blocks, one per half (round 4: half of every
-     * instruction's lanes had been idle: 98 -> 75 us for the 3 900 blocks of a 6-max 100 000-run query).  Measured and
-     * dropped: a branch-free step with both candidate table words fetched ahead (78 us), and on top of it two or four
-     * blocks per wave-half walked word by word in turn (106-125 us) -- a wave that is alone on its SIMD issues one vector
-     * instruction per 5-8 cycles whatever their dependence, so fewer, fatter waves lose; what would help is MORE waves
-     * (sub-blocks of 312 words: four waves per SIMD) at the price of twice the units in the stitch. */
-    __shared__ __attribute__((aligned(16))) uint8_t s_yb[kMtbBlock / 64][2][MCQ_MT_N + 64u];
+    /* A block has n_st = D + n_opp <= 32 entry states, a wave has 64 lanes, and the automaton is a chain: a wave that is
+     * alone or almost alone on its SIMD issues one vector instruction per 5-8 cycles whatever their dependence.  So a wave
+     * takes ONE block and cuts it into U = 2 .. 8 PARTS (as many as 64 / n_st allows: eight for a heads-up query, three
+     * six-max, two with nine or ten players), lane = (part, entry state): every part is walked from every entry state side
+     * by side, and the block's exit words are composed from the parts' as a group's are from its blocks'
+     * (mcq_mtb_compose_step) -- twice the waves of the version before, a chain of 624 / U words instead of 624.
+     * (Round 4.  Measured on the 3 900 blocks of a 6-max 100 000-run query: one block per wave, 32 lanes idle, 98 us; two
+     * blocks per wave 75 us; a branch-free step with both candidate table words fetched ahead 78 us; two or four blocks per
+     * wave-half word by word in turn 106-125 us; two halves of one block 58 us; this: see profiles/r08_mtb_kernels.txt.) */
+    __shared__ __attribute__((aligned(16))) uint8_t s_yb[kMtbBlock / 64][MCQ_MT_N + 64u];
     __shared__ uint32_t s_pos[kMtbBlock / 64][MCQ_MTB_POS];
-    static_assert(MCQ_MTB_LANES == 32u, "two blocks per wave");
+    __shared__ uint32_t s_ex[kMtbBlock / 64][8][MCQ_MTB_LANES];
+    static_assert(MCQ_MT_N % 8u == 0u && MCQ_MT_N % 6u == 0u, "parts of 78, 104, 156, 208, 312 words");
     const uint32_t qi = blockIdx.y, lane = threadIdx.x & 63u, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t first = blk_off[qi], nb = blk_off[qi + 1u] - first, b0 = 2u * (blockIdx.x * (kMtbBlock / 64) + wv);
-    if (b0 >= nb) return; /* (wave-uniform; no block barrier below) */
+    const uint32_t first = blk_off[qi], nb = blk_off[qi + 1u] - first, b = blockIdx.x * (kMtbBlock / 64) + wv;
+    if (b >= nb) return; /* (wave-uniform; no block barrier below) */
     const McqMtbPlan pl = mcq_mtb_plan_of(queries, qi);
+    const uint32_t n_st = pl.D + (pl.two_opp >> 1);                                             /* (wave-uniform) 1 .. 32 */
+    const uint32_t U = n_st <= 8u ? 8u : n_st <= 10u ? 6u : n_st <= 16u ? 4u : n_st <= 21u ? 3u : 2u; /* U * n_st <= 64 */
+    const uint32_t W = MCQ_MT_N / U;
     if (lane < MCQ_MTB_POS) s_pos[wv][lane] = mcq_mtb_pos_word(pl, lane < pl.D ? lane : 0u);
-    mcq_mtb_load_block(raw + (uint64_t)(first + b0) * MCQ_MT_N, s_yb[wv][0], lane); /* (ends with a wave barrier) */
-    const bool two = b0 + 1u < nb;
-    if (two) mcq_mtb_load_block(raw + (uint64_t)(first + b0 + 1u) * MCQ_MT_N, s_yb[wv][1], lane);
-    const uint32_t half = lane >> 5;
-    if (half != 0u && !two) return;
-    const uint32_t x = mcq_mtb_automaton(s_yb[wv][half], s_pos[wv], pl, lane & 31u);
-    exits[(uint64_t)(first + b0 + half) * MCQ_MTB_LANES + (lane & 31u)] = x;
+    mcq_mtb_load_block(raw + (uint64_t)(first + b) * MCQ_MT_N, s_yb[wv], lane); /* (ends with a wave barrier) */
+    const uint32_t u = (lane * ((65536u + n_st - 1u) / n_st)) >> 16, e = lane - u * n_st; /* lane / n_st, lane % n_st (lane < 64) */
+    if (u < U) s_ex[wv][u][e] = mcq_mtb_automaton_n(s_yb[wv] + u * W, W, s_pos[wv], pl, e);
+    MCQ_WAVE_SYNC();
+    if (lane < MCQ_MTB_LANES) {
+        uint32_t x = 0u;
+        if (lane < n_st) {
+            McqMtbWalk s = mcq_mtb_walk_from(pl, lane);
+            for (uint32_t k = 0; k < U; k++) mcq_mtb_compose_step(s_ex[wv][k], pl, s);
+            x = mcq_mtb_walk_word(s) | (s.its << 19);
+        }
+        exits[(uint64_t)(first + b) * MCQ_MTB_LANES + lane] = x;
+    }
 }
 
 // 3. stitch, in two levels (mcq_mt_blocks.hpp).  grp_off[q] .. grp_off[q + 1]: the query's groups of MCQ_MTB_GROUP blocks.
@@ -1856,7 +1869,6 @@ hipError_t mcq_launch_mt_blocks(const mcq_query *d_q, uint32_t n, uint32_t seed3
     constexpr uint32_t kWaves = kMtbBlock / 64;
     const uint32_t max_groups = (max_blocks + MCQ_MTB_GROUP - 1u) / MCQ_MTB_GROUP;
     const dim3 per_block((max_blocks + kWaves - 1) / kWaves, n), per_group((max_groups + kWaves - 1) / kWaves, n);
-    const dim3 per_two_blocks((max_blocks + 2u * kWaves - 1) / (2u * kWaves), n);
     if (!d_part) { /* no jumps (MCQ_MT_JUMP=0): one work-group per query makes all its blocks, one behind the other */
         hipLaunchKernelGGL(mcq_mtb_generate_kernel, dim3(1, n), dim3(kMtbGenBlock), 0, s, d_blk_off, seed32, d_raw, d_part, 0u,
                            max_blocks, 0u);
@@ -1874,7 +1886,7 @@ hipError_t mcq_launch_mt_blocks(const mcq_query *d_q, uint32_t n, uint32_t seed3
                                base, (uint32_t)MCQ_MTB_SEG, 0u);
         }
     }
-    hipLaunchKernelGGL(mcq_mtb_scan_kernel, per_two_blocks, dim3(kMtbBlock), 0, s, d_q, d_blk_off, d_raw, d_exits);
+    hipLaunchKernelGGL(mcq_mtb_scan_kernel, per_block, dim3(kMtbBlock), 0, s, d_q, d_blk_off, d_raw, d_exits);
     hipLaunchKernelGGL(mcq_mtb_compose_kernel, per_group, dim3(kMtbBlock), 0, s, d_q, d_blk_off, d_grp_off, d_exits, d_gword, d_gits);
     hipLaunchKernelGGL(mcq_mtb_stitch_kernel, dim3(n), dim3(64), 0, s, d_q, d_blk_off, d_grp_off, d_gword, d_gits,
                        reinterpret_cast<McqMtbEntry *>(d_gentry), d_ovf, d_res);
