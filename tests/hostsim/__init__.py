@@ -13,6 +13,7 @@ _SRCS = [os.path.join(_HERE, "hostsim.cpp"),
          os.path.join(_HERE, "..", "..", "neuron_poker_amd", "csrc", "mcq_exact.hpp"),
          os.path.join(_HERE, "..", "..", "neuron_poker_amd", "csrc", "mcq_mt.hpp"),
          os.path.join(_HERE, "..", "..", "neuron_poker_amd", "csrc", "mcq_mt_ext.hpp"),
+         os.path.join(_HERE, "..", "..", "neuron_poker_amd", "csrc", "mcq_mt_blocks.hpp"),
          os.path.join(_HERE, "..", "..", "neuron_poker_amd", "csrc", "mcq_layout.hpp"),
          os.path.join(_HERE, "..", "..", "include", "mcq.h")]
 _lib = None
