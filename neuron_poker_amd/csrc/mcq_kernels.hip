@@ -508,23 +508,14 @@ __global__ __launch_bounds__(kMtbBlock) void mcq_mtb_scan_kernel(const mcq_query
     const uint32_t first = blk_off[qi], nb = blk_off[qi + 1u] - first, b = blockIdx.x * (kMtbBlock / 64) + wv;
     if (b >= nb) return; /* (wave-uniform; no block barrier below) */
     const McqMtbPlan pl = mcq_mtb_plan_of(queries, qi);
-    const uint32_t n_st = pl.D + (pl.two_opp >> 1);                                             /* (wave-uniform) 1 .. 32 */
-    const uint32_t U = n_st <= 8u ? 8u : n_st <= 10u ? 6u : n_st <= 16u ? 4u : n_st <= 21u ? 3u : 2u; /* U * n_st <= 64 */
-    const uint32_t W = MCQ_MT_N / U;
+    const uint32_t n_st = pl.D + (pl.two_opp >> 1), U = mcq_mtb_parts(pl), W = MCQ_MT_N / U; /* (wave-uniform) U * n_st <= 64 */
     if (lane < MCQ_MTB_POS) s_pos[wv][lane] = mcq_mtb_pos_word(pl, lane < pl.D ? lane : 0u);
     mcq_mtb_load_block(raw + (uint64_t)(first + b) * MCQ_MT_N, s_yb[wv], lane); /* (ends with a wave barrier) */
     const uint32_t u = (lane * ((65536u + n_st - 1u) / n_st)) >> 16, e = lane - u * n_st; /* lane / n_st, lane % n_st (lane < 64) */
     if (u < U) s_ex[wv][u][e] = mcq_mtb_automaton_n(s_yb[wv] + u * W, W, s_pos[wv], pl, e);
     MCQ_WAVE_SYNC();
-    if (lane < MCQ_MTB_LANES) {
-        uint32_t x = 0u;
-        if (lane < n_st) {
-            McqMtbWalk s = mcq_mtb_walk_from(pl, lane);
-            for (uint32_t k = 0; k < U; k++) mcq_mtb_compose_step(s_ex[wv][k], pl, s);
-            x = mcq_mtb_walk_word(s) | (s.its << 19);
-        }
-        exits[(uint64_t)(first + b) * MCQ_MTB_LANES + lane] = x;
-    }
+    if (lane < MCQ_MTB_LANES)
+        exits[(uint64_t)(first + b) * MCQ_MTB_LANES + lane] = mcq_mtb_exit_from_parts(&s_ex[wv][0][0], U, pl, lane);
 }
 
 // 3. stitch, in two levels (mcq_mt_blocks.hpp).  grp_off[q] .. grp_off[q + 1]: the query's groups of MCQ_MTB_GROUP blocks.

@@ -318,9 +318,21 @@ extern "C" uint64_t hs_mt_parse_blocks(const mcq_query *q, uint32_t seed32, uint
     std::vector<uint32_t> exits((size_t)n_blocks * MCQ_MTB_LANES);
     uint32_t pos_tab[MCQ_MTB_POS];
     for (uint32_t k = 0; k < MCQ_MTB_POS; k++) pos_tab[k] = mcq_mtb_pos_word(pl, k < D ? k : 0u);
-    for (uint32_t b = 0; b < n_blocks; b++)
-        for (uint32_t l = 0; l < MCQ_MTB_LANES; l++)
-            exits[(size_t)b * MCQ_MTB_LANES + l] = mcq_mtb_automaton(&yb[(size_t)b * MCQ_MT_N], pos_tab, pl, l);
+    /* as the kernel does it (a block in U parts, each walked from every entry state, the block's exit words composed from
+     * the parts') -- and checked against the walk of the whole block */
+    const uint32_t U = mcq_mtb_parts(pl), W = MCQ_MT_N / U, n_st = pl.D + (pl.two_opp >> 1);
+    if (U * n_st > 64u || U * W != MCQ_MT_N) return ~0ull - 2u;
+    for (uint32_t b = 0; b < n_blocks; b++) {
+        uint32_t part[8][MCQ_MTB_LANES];
+        for (uint32_t u = 0; u < U; u++)
+            for (uint32_t l = 0; l < MCQ_MTB_LANES; l++)
+                part[u][l] = l < n_st ? mcq_mtb_automaton_n(&yb[(size_t)b * MCQ_MT_N + u * W], W, pos_tab, pl, l) : 0u;
+        for (uint32_t l = 0; l < MCQ_MTB_LANES; l++) {
+            const uint32_t x = mcq_mtb_exit_from_parts(&part[0][0], U, pl, l);
+            if (x != mcq_mtb_automaton(&yb[(size_t)b * MCQ_MT_N], pos_tab, pl, l)) return ~0ull - 2u; /* parts != whole: a bug */
+            exits[(size_t)b * MCQ_MTB_LANES + l] = x;
+        }
+    }
     /* 3. stitch: compose the groups, follow the groups, note every block's entry from its group's */
     const uint32_t n_groups = (n_blocks + MCQ_MTB_GROUP - 1u) / MCQ_MTB_GROUP;
     std::vector<uint32_t> gword((size_t)n_groups * MCQ_MTB_LANES), gits((size_t)n_groups * MCQ_MTB_LANES);
