@@ -8,6 +8,8 @@ task boundaries and a few long ones) and checks, against oracle/ (test infrastru
   * production mode (MCQ_MODE_PHILOX), reference and uniform dealing law, random first_query_id;
   * parity mode (MCQ_MODE_REPLAY_MT19937);
   * shares of an iteration split (mcq_eval_batch_part) add up to the whole;
+  * every eighth round a few LONG queries in parity mode (20 000 .. 400 000 runs: the stream parsed by state blocks, segments by
+    jump-ahead, one or several rounds of them -- csrc/mcq_mt_blocks.hpp);
   * every fourth round a batch of extended queries (ranges, hero range, ghost cards, second known hand) in both modes;
   * every 64th round exact enumerations (1-3 players, river / turn / flop) against tests/hostsim, both laws.
 Prints one summary line; exits non-zero on the first mismatch.
@@ -81,6 +83,26 @@ def ext_round(g, eng):
     return n, int(q["runs"].astype(np.int64).sum())
 
 
+def long_round(g, eng):
+    """A few long queries in parity mode: the walk by state blocks (scan in parts, stitch, parse), the generator in segments
+    with jump-ahead when the estimate says so, more than one round of 4096 blocks now and then."""
+    n = int(g.integers(1, 9))
+    hole, board, npl, runs = [], [], [], []
+    for _ in range(n):
+        nb = int(g.choice([0, 0, 3, 4, 5]))
+        c = g.permutation(52)[:2 + nb]
+        hole.append(c[:2])
+        board.append(list(c[2:]) + [255] * (5 - nb))
+        npl.append(int(g.integers(1, 11)))
+        runs.append(int(g.integers(20000, 400000 if g.random() < 0.15 else 120000)))
+    q = npa.pack_queries(hole, board, npl, runs)
+    s32, first = int(g.integers(0, 2 ** 32)), int(g.integers(0, 2 ** 40))
+    got = eng.eval_batch(q, s32, first_query_id=first, mode=npa.MODE_REPLAY_MT19937).view(np.uint64).reshape(-1, 13)
+    want = O.run_batch(O.MODE_MT, q.view(np.uint8).reshape(-1, 16), s32, first_qid=first, threads=16)
+    assert np.array_equal(got, want), ("long replay", [int(x) for x in npl], runs, s32, first)
+    return n, int(sum(runs))
+
+
 def exact_round(g, eng):
     """Exact enumeration on the GPU against the host build of the same lane code (tests/hostsim), integers."""
     from tests import hostsim as H
@@ -108,7 +130,7 @@ def main():
     g = np.random.default_rng(a.seed)
     eng = npa.Engine(0)
     t0 = time.time()
-    rounds = queries = iters = ext_q = ext_i = exact_n = 0
+    rounds = queries = iters = ext_q = ext_i = exact_n = long_q = long_i = 0
     t_said = t0
     while time.time() - t0 < a.seconds:
         if time.time() - t_said > 60:   # a sign of life for long runs (the GPU pool kills a command that stays silent)
@@ -138,12 +160,16 @@ def main():
             nq, ni = ext_round(g, eng)
             ext_q += 2 * nq
             ext_i += 2 * ni
+        if rounds % 8 == 0:
+            nq, ni = long_round(g, eng)
+            long_q += nq
+            long_i += ni
         if rounds % 64 == 0:
             exact_n += exact_round(g, eng)
     print("fuzz parity: %d rounds, %d query evaluations, %d iterations in 4 configurations; %d extended-query "
           "evaluations, %d iterations in both modes -- all bit-exact against the oracle; %d exact enumerations equal "
-          "to the host build of the lane code (%.0f s, seed %d)"
-          % (rounds, queries, iters, ext_q, ext_i, exact_n, time.time() - t0, a.seed))
+          "to the host build of the lane code; %d long queries (%d iterations) in parity mode by state blocks (%.0f s, seed %d)"
+          % (rounds, queries, iters, ext_q, ext_i, exact_n, long_q, long_i, time.time() - t0, a.seed))
 
 
 if __name__ == "__main__":
