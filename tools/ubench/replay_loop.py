@@ -205,6 +205,28 @@ def v_no_sgpr_src(body):
     return out
 
 
+def renumber(seed):
+    """the same stream with its single VGPRs renamed by a random permutation (registers that appear in a tuple v[a:b] keep
+    their numbers): does the ASSIGNMENT of registers (banks, operand ports) matter for the issue rate?"""
+    def f(body):
+        import random
+        fixed, used = {0, 127}, set()
+        for _, a in body:
+            for m in re.finditer(r"\bv\[(\d+):(\d+)\]", a):
+                fixed.update(range(int(m.group(1)), int(m.group(2)) + 1))
+            for m in re.finditer(r"\bv(\d+)\b", a):
+                used.add(int(m.group(1)))
+        free = sorted(used - fixed)
+        perm = free[:]
+        random.Random(seed).shuffle(perm)
+        mp = dict(zip(free, perm))
+        out = []
+        for o, a in body:
+            out.append((o, re.sub(r"\bv(\d+)\b", lambda m: "v%d" % mp.get(int(m.group(1)), int(m.group(1))), a)))
+        return out
+    return f
+
+
 def drop_ops(*prefixes):
     """the stream without the instructions whose opcode starts with one of `prefixes` (what that opcode class costs in situ)"""
     def f(body):
@@ -218,6 +240,8 @@ for _n, _p in (("mad64", ("v_mad_u64_u32",)), ("cmp", ("v_cmp_",)), ("max", ("v_
                ("sub", ("v_sub_u32",)), ("snop", ("s_nop",)), ("salu", ("s_and_b64", "s_or_b64", "s_mov_b64", "s_andn2_b64"))):
     VARIANTS["nolds_drop_" + _n] = compose(v_no_lds, drop_ops(*_p))
 
+for _k in range(6):
+    VARIANTS["nolds_renum%d" % _k] = compose(v_no_lds, renumber(_k))
 VARIANTS["nolds_nosgpr"] = compose(v_no_lds, v_no_sgpr_src)
 VARIANTS["nolds_nosgpr_nosel"] = compose(v_no_lds, v_no_sgpr_src, drop_ops("v_cndmask_b32_e64"))
 
