@@ -227,6 +227,86 @@ def renumber(seed):
     return f
 
 
+def canon(*keep):
+    """every VALU instruction replaced by a plain representative of its issue class (fast: v_add_u32 d, d, v127; slow:
+    v_bcnt_u32_b32 d, d, v127; d = its own destination register) -- except the opcodes starting with one of `keep`: does the
+    stream then cost the sum of its classes, and which opcodes make it cost more?"""
+    def f(body):
+        out = []
+        for o, a in body:
+            if o.startswith("v_") and not o.startswith(keep if keep else ("\0",)):
+                m = re.match(r"\s*(v\d+)\b", a)
+                d = m.group(1) if m else "v126"
+                out.append(("v_bcnt_u32_b32", "%s, %s, v127" % (d, d)) if is_slow(o, a) else ("v_add_u32_e32", "%s, %s, v127" % (d, d)))
+            else:
+                out.append((o, a))
+        return out
+    return f
+
+
+def v_sepall_strict(body):
+    """an s_nop 0 behind EVERY slow-class instruction that is not already followed by a non-VALU instruction"""
+    out = []
+    for k, (o, a) in enumerate(body):
+        out.append((o, a))
+        if o.startswith("v_") and is_slow(o, a) and k + 1 < len(body) and body[k + 1][0].startswith("v_"):
+            out.append(("s_nop", "0"))
+    return out
+
+
+def v_sorted_classes(body):
+    """(synthetic) all fast-class instructions first, then the slow ones, each followed by s_nop 0"""
+    fast = [(o, a) for o, a in body if o.startswith("v_") and not is_slow(o, a)]
+    slow = [(o, a) for o, a in body if o.startswith("v_") and is_slow(o, a)]
+    out = list(fast)
+    for x in slow:
+        out.append(x)
+        out.append(("s_nop", "0"))
+    return out
+
+
+def blocks_of(nf, ns):
+    """(synthetic) the same instructions dealt into blocks of nf fast then ns slow ones, each slow one followed by s_nop 0"""
+    def f(body):
+        fast = [(o, a) for o, a in body if o.startswith("v_") and not is_slow(o, a)]
+        slow = [(o, a) for o, a in body if o.startswith("v_") and is_slow(o, a)]
+        out = []
+        while fast or slow:
+            out.extend(fast[:nf]); del fast[:nf]
+            for x in slow[:ns]:
+                out.append(x); out.append(("s_nop", "0"))
+            del slow[:ns]
+        return out
+    return f
+
+
+def v_rotate_regs(body):
+    """(synthetic, behind canon()) the canonical instructions on eight registers in turn: no dependence left but one in eight"""
+    out, k = [], 0
+    for o, a in body:
+        if o in ("v_add_u32_e32", "v_bcnt_u32_b32"):
+            out.append((o, "v%d, v%d, v127" % (110 + k % 8, 110 + k % 8)))
+            k += 1
+        elif o == "s_nop":
+            out.append((o, "0"))
+        else:
+            out.append((o, a))
+    return out
+
+
+def chunk_of(k, n):
+    """(synthetic) the k-th of n equal pieces of the stream, repeated to the stream's length: which PART of the order costs
+    more than the sum of its classes?"""
+    def f(body):
+        m = (len(body) + n - 1) // n
+        piece = body[k * m:(k + 1) * m]
+        out = []
+        while len(out) < len(body):
+            out.extend(piece)
+        return out
+    return f
+
+
 def drop_ops(*prefixes):
     """the stream without the instructions whose opcode starts with one of `prefixes` (what that opcode class costs in situ)"""
     def f(body):
@@ -242,6 +322,28 @@ for _n, _p in (("mad64", ("v_mad_u64_u32",)), ("cmp", ("v_cmp_",)), ("max", ("v_
 
 for _k in range(6):
     VARIANTS["nolds_renum%d" % _k] = compose(v_no_lds, renumber(_k))
+VARIANTS["nolds_canon"] = compose(v_no_lds, canon())
+for _n, _p in (("mad64", ("v_mad_u64",)), ("cmp", ("v_cmp",)), ("sel", ("v_cndmask",)), ("vop3", ("v_bitop3", "v_add3", "v_lshl_add", "v_lshl_or", "v_max3", "v_xad", "v_bfe", "v_perm", "v_sad", "v_bcnt")),
+               ("vop2", ("v_and_b32", "v_or_b32", "v_sub_u32", "v_add_u32", "v_xor_b32", "v_lshrrev_b32", "v_lshlrev_b32", "v_mov_b32", "v_max_u32"))):
+    VARIANTS["nolds_canon_keep_" + _n] = compose(v_no_lds, canon(*_p))
+VARIANTS["canon_valu_only"] = compose(v_only_valu, canon())
+VARIANTS["canon_valu_nop"] = compose(lambda b: [(o, a) for o, a in b if o.startswith("v_") or o == "s_nop"], canon())
+VARIANTS["canon_sepall"] = compose(lambda b: [(o, a) for o, a in b if o.startswith("v_") or o == "s_nop"], canon(), v_sepall_strict)
+VARIANTS["canon_sepall_rot"] = compose(lambda b: [(o, a) for o, a in b if o.startswith("v_") or o == "s_nop"], canon(), v_sepall_strict, v_rotate_regs)
+VARIANTS["canon_blocks_1_1_rot"] = compose(v_only_valu, canon(), blocks_of(1, 1), v_rotate_regs)
+for _k in range(12):
+    VARIANTS["canon_sepall_chunk%02d" % _k] = compose(lambda b: [(o, a) for o, a in b if o.startswith("v_") or o == "s_nop"], canon(), v_sepall_strict, v_rotate_regs, chunk_of(_k, 12))
+_vn = lambda b: [(o, a) for o, a in b if o.startswith("v_") or o == "s_nop"]
+for _n, _p in (("mad64", ("v_mad_u64",)), ("cmp", ("v_cmp",)), ("sel", ("v_cndmask",)),
+               ("vop3slow", ("v_add3", "v_lshl_add", "v_lshl_or", "v_max3", "v_xad", "v_bfe", "v_perm", "v_sad", "v_bcnt")),
+               ("bitop3", ("v_bitop3",)), ("max", ("v_max_u32",)), ("lshl", ("v_lshlrev",)),
+               ("vop2fast", ("v_and_b32", "v_or_b32", "v_sub_u32", "v_add_u32", "v_xor_b32", "v_lshrrev_b32", "v_mov_b32")),
+               ("all", ("v_",))):
+    VARIANTS["canon_sepall_keep_" + _n] = compose(_vn, canon(*_p), v_sepall_strict)
+VARIANTS["canon_sorted"] = compose(v_only_valu, canon(), v_sorted_classes)
+VARIANTS["canon_blocks_3_2"] = compose(v_only_valu, canon(), blocks_of(3, 2))
+VARIANTS["canon_blocks_6_4"] = compose(v_only_valu, canon(), blocks_of(6, 4))
+VARIANTS["canon_blocks_1_1"] = compose(v_only_valu, canon(), blocks_of(1, 1))
 VARIANTS["nolds_nosgpr"] = compose(v_no_lds, v_no_sgpr_src)
 VARIANTS["nolds_nosgpr_nosel"] = compose(v_no_lds, v_no_sgpr_src, drop_ops("v_cndmask_b32_e64"))
 
