@@ -307,6 +307,27 @@ def chunk_of(k, n):
     return f
 
 
+def window_alt(w):
+    """(synthetic) inside every window of w VALU instructions: fast and slow ones dealt alternately (f S n f S n ..., the
+    leftover class at the end), each slow one followed by s_nop 0 -- how LOCAL may a re-ordering be and still reach the sum
+    of the classes?"""
+    def f(body):
+        valu = [(o, a) for o, a in body if o.startswith("v_")]
+        out = []
+        for i in range(0, len(valu), w):
+            win = valu[i:i + w]
+            fast = [x for x in win if not is_slow(*x)]
+            slow = [x for x in win if is_slow(*x)]
+            while fast or slow:
+                if fast:
+                    out.append(fast.pop(0))
+                if slow:
+                    out.append(slow.pop(0))
+                    out.append(("s_nop", "0"))
+        return out
+    return f
+
+
 def drop_ops(*prefixes):
     """the stream without the instructions whose opcode starts with one of `prefixes` (what that opcode class costs in situ)"""
     def f(body):
@@ -340,6 +361,8 @@ for _n, _p in (("mad64", ("v_mad_u64",)), ("cmp", ("v_cmp",)), ("sel", ("v_cndma
                ("vop2fast", ("v_and_b32", "v_or_b32", "v_sub_u32", "v_add_u32", "v_xor_b32", "v_lshrrev_b32", "v_mov_b32")),
                ("all", ("v_",))):
     VARIANTS["canon_sepall_keep_" + _n] = compose(_vn, canon(*_p), v_sepall_strict)
+for _w in (4, 8, 16, 32, 64):
+    VARIANTS["canon_winalt%d" % _w] = compose(v_only_valu, canon(), window_alt(_w))
 VARIANTS["canon_sorted"] = compose(v_only_valu, canon(), v_sorted_classes)
 VARIANTS["canon_blocks_3_2"] = compose(v_only_valu, canon(), blocks_of(3, 2))
 VARIANTS["canon_blocks_6_4"] = compose(v_only_valu, canon(), blocks_of(6, 4))
@@ -360,6 +383,7 @@ replay:
 \tv_lshlrev_b32_e32 v127, 2, v127
 {init}
 \ts_waitcnt lgkmcnt(0)
+{prio}
 .Lloop:
 {body}
 \ts_sub_u32 s100, s100, 1
@@ -424,7 +448,44 @@ amdhsa.version:
 """
 
 
-def emit(body, vregs, sregs, lds):
+PRIO_STAGGER = """\tv_readfirstlane_b32 s96, v0
+\ts_lshr_b32 s96, s96, 8
+\ts_cmp_eq_u32 s96, 0
+\ts_cbranch_scc1 .Lp0
+\ts_cmp_eq_u32 s96, 1
+\ts_cbranch_scc1 .Lp1
+\ts_cmp_eq_u32 s96, 2
+\ts_cbranch_scc1 .Lp2
+\ts_setprio 3
+\ts_branch .Lloop
+.Lp0:
+\ts_setprio 0
+\ts_branch .Lloop
+.Lp1:
+\ts_setprio 1
+\ts_branch .Lloop
+.Lp2:
+\ts_setprio 2"""
+
+
+SLEEP_STAGGER = """\tv_readfirstlane_b32 s96, v0
+\ts_lshr_b32 s96, s96, 8
+\ts_cmp_eq_u32 s96, 0
+\ts_cbranch_scc1 .Lloop
+\ts_cmp_eq_u32 s96, 1
+\ts_cbranch_scc1 .Lq1
+\ts_cmp_eq_u32 s96, 2
+\ts_cbranch_scc1 .Lq2
+\ts_sleep {q3}
+\ts_branch .Lloop
+.Lq1:
+\ts_sleep {q1}
+\ts_branch .Lloop
+.Lq2:
+\ts_sleep {q2}"""
+
+
+def emit(body, vregs, sregs, lds, prio=""):
     init = []
     for r in sorted(vregs):
         if r in (0, 127):
@@ -435,7 +496,7 @@ def emit(body, vregs, sregs, lds):
             continue
         init.append("\ts_mov_b32 s%d, 0x%x" % (r, (0x9E3779B9 * (r + 3)) & 0xFFFF))
     text = "\n".join("\t%s %s" % (o, a) for o, a in body)
-    return TEMPLATE.format(init="\n".join(init), body=text, lds=lds)
+    return TEMPLATE.format(init="\n".join(init), body=text, lds=lds, prio=prio)
 
 
 HOST = r'''// replay_host.cpp -- loads a code object made by tools/ubench/replay_loop.py and times its kernel `replay`:
@@ -493,11 +554,16 @@ def main():
     if max(vregs) >= 127 or max(sregs) >= 98:
         raise SystemExit("the loop uses v%d / s%d: the harness's own registers collide" % (max(vregs), max(sregs)))
     for name in (a.variant or list(VARIANTS)):
-        b = VARIANTS[name](body)
+        b = VARIANTS[re.sub(r"(_prio|_stag\d+)$", "", name)](body)
         n_valu = sum(1 for o, _ in b if o.startswith("v_"))
         s_path = os.path.join(a.out, name + ".s")
         with open(s_path, "w") as f:
-            f.write(emit(b, vregs, sregs, a.lds))
+            pre = PRIO_STAGGER if name.endswith("_prio") else ""
+            m_st = re.search(r"_stag(\d+)$", name)
+            if m_st:
+                q = int(m_st.group(1))
+                pre = SLEEP_STAGGER.format(q1=q, q2=2 * q, q3=3 * q)
+            f.write(emit(b, vregs, sregs, a.lds, pre))
         obj = os.path.join(a.out, name + ".o")
         subprocess.check_call([LLVM + "/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", s_path, "-o", obj])
         subprocess.check_call([LLVM + "/lld", "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", "-o",
