@@ -328,6 +328,54 @@ def window_alt(w):
     return f
 
 
+def shuffled(seed, period=0):
+    """(synthetic) the VALU instructions in a random order (period > 0: a random order of the first `period` of them,
+    repeated), each slow one followed by s_nop 0"""
+    def f(body):
+        import random
+        valu = [(o, a) for o, a in body if o.startswith("v_")]
+        if period:
+            piece = valu[:period]
+            random.Random(seed).shuffle(piece)
+            valu = (piece * (len(valu) // period + 1))[:len(valu)]
+        else:
+            random.Random(seed).shuffle(valu)
+        out = []
+        for x in valu:
+            out.append(x)
+            if is_slow(*x):
+                out.append(("s_nop", "0"))
+        return out
+    return f
+
+
+def chunk_sorted(n):
+    """(synthetic) the stream cut into n pieces, inside each piece the fast ones first, then the slow ones with separators"""
+    def f(body):
+        valu = [(o, a) for o, a in body if o.startswith("v_")]
+        m = (len(valu) + n - 1) // n
+        out = []
+        for i in range(0, len(valu), m):
+            out.extend(v_sorted_classes(valu[i:i + m]))
+        return out
+    return f
+
+
+def barrier_every(k):
+    """an s_barrier behind every k-th VALU instruction (at a point where a non-VALU instruction already stands, if one is
+    near): do the waves of a SIMD pair their fast-class instructions better when they are kept in step?"""
+    def f(body):
+        out, n = [], 0
+        for o, a in body:
+            out.append((o, a))
+            if o.startswith("v_"):
+                n += 1
+                if n % k == 0:
+                    out.append(("s_barrier", ""))
+        return out
+    return f
+
+
 def drop_ops(*prefixes):
     """the stream without the instructions whose opcode starts with one of `prefixes` (what that opcode class costs in situ)"""
     def f(body):
@@ -363,6 +411,16 @@ for _n, _p in (("mad64", ("v_mad_u64",)), ("cmp", ("v_cmp",)), ("sel", ("v_cndma
     VARIANTS["canon_sepall_keep_" + _n] = compose(_vn, canon(*_p), v_sepall_strict)
 for _w in (4, 8, 16, 32, 64):
     VARIANTS["canon_winalt%d" % _w] = compose(v_only_valu, canon(), window_alt(_w))
+VARIANTS["canon_shuffle0"] = compose(v_only_valu, canon(), shuffled(0))
+VARIANTS["canon_shuffle1"] = compose(v_only_valu, canon(), shuffled(1))
+for _pd in (8, 16, 32, 64, 128, 256):
+    VARIANTS["canon_shuffle_p%d" % _pd] = compose(v_only_valu, canon(), shuffled(3, _pd))
+for _n in (4, 12, 32):
+    VARIANTS["canon_chunksorted%d" % _n] = compose(v_only_valu, canon(), chunk_sorted(_n))
+for _k in (16, 32, 64, 128):
+    VARIANTS["canon_sepall_bar%d" % _k] = compose(_vn, canon(), v_sepall_strict, barrier_every(_k))
+    VARIANTS["canon_chunksorted12_bar%d" % _k] = compose(v_only_valu, canon(), chunk_sorted(12), barrier_every(_k))
+    VARIANTS["nolds_bar%d" % _k] = compose(v_no_lds, barrier_every(_k))
 VARIANTS["canon_sorted"] = compose(v_only_valu, canon(), v_sorted_classes)
 VARIANTS["canon_blocks_3_2"] = compose(v_only_valu, canon(), blocks_of(3, 2))
 VARIANTS["canon_blocks_6_4"] = compose(v_only_valu, canon(), blocks_of(6, 4))
